@@ -1,0 +1,13 @@
+"""knn_svc_amd — MI355X-native kNN-SVC inference path.
+
+(The spec names the package ``knn-svc_amd``; a hyphen is not a legal Python
+identifier, so the importable name uses an underscore.)
+
+Python here is the host side only: it mirrors the reference's entry points
+(``ddsp_hubconf.knn_vc``, ``KNeighborsVC.special_match`` / ``bulk_match`` /
+``vocode``, the ``ddsp_inference.py`` CLI) and calls ``libknnsvc_hip.so`` — a
+C-ABI library of hand-written gfx950 kernels (``csrc/``, ``include/knnsvc_hip.h``)
+— through ctypes.  There is no CPU fallback: every op raises if the library
+is missing.
+"""
+__all__ = ["config", "synthetic", "audio_io"]

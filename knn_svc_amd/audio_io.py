@@ -1,0 +1,114 @@
+"""Audio file plumbing for the host side: RIFF/WAVE reader and PCM_32 writer.
+
+The reference goes through ``torchaudio.load`` (ddsp_prematch_dataset.py:332) and
+``soundfile.write(..., subtype='PCM_32')`` (lib_ongaku_test.py:118-120).  Neither
+library is in this image, so WAV is handled here with numpy; other containers
+(.flac/.mp3) are delegated to torchaudio/soundfile when importable and refused
+otherwise.  Sample values follow torchaudio's convention: integer PCM is scaled
+by 2**-(bits-1) to float32 in [-1, 1).
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+
+
+def read_wav(path: str):
+    """-> (float32 [channels, samples], sample_rate)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos = 12
+    fmt = None
+    pcm = None
+    while pos + 8 <= len(data):
+        cid = data[pos:pos + 4]
+        (sz,) = struct.unpack("<I", data[pos + 4:pos + 8])
+        body = data[pos + 8:pos + 8 + sz]
+        if cid == b"fmt ":
+            tag, ch, sr, _br, _ba, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and len(body) >= 26:          # WAVE_FORMAT_EXTENSIBLE
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + sz + (sz & 1)
+    if fmt is None or pcm is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, ch, sr, bits = fmt
+    if tag == 1:
+        if bits == 16:
+            x = np.frombuffer(pcm, "<i2").astype(np.float32) / 32768.0
+        elif bits == 32:
+            x = (np.frombuffer(pcm, "<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+        elif bits == 24:
+            b = np.frombuffer(pcm, np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v & 0x800000, v - 0x1000000, v)
+            x = (v.astype(np.float64) / 8388608.0).astype(np.float32)
+        elif bits == 8:
+            x = (np.frombuffer(pcm, np.uint8).astype(np.float32) - 128.0) / 128.0
+        else:
+            raise ValueError(f"{path}: unsupported PCM width {bits}")
+    elif tag == 3:
+        x = np.frombuffer(pcm, "<f4" if bits == 32 else "<f8").astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported WAVE format tag {tag}")
+    n = len(x) // ch
+    return np.ascontiguousarray(x[:n * ch].reshape(n, ch).T), sr
+
+
+def load_audio(path: str):
+    """torchaudio.load stand-in: -> (float32 ndarray [channels, samples], sr)."""
+    ext = os.path.splitext(path)[-1].lower()
+    if ext == ".wav":
+        return read_wav(path)
+    try:                                    # optional decoders; absent in this image
+        import soundfile as sf
+        x, sr = sf.read(path, dtype="float32", always_2d=True)
+        return np.ascontiguousarray(x.T), sr
+    except ImportError:
+        pass
+    raise RuntimeError(f"{path}: only .wav can be decoded without soundfile/torchaudio installed")
+
+
+def to_pcm32(wave: np.ndarray) -> np.ndarray:
+    """The reference's save_audio scaling (lib_ongaku_test.py:102-112): divide by the
+    peak only when it exceeds 1, multiply by 2**31-1, truncate toward zero."""
+    wave = np.asarray(wave)
+    if wave.dtype == np.int32:
+        return wave
+    peak = np.max(np.abs(wave)) if wave.size else 0.0
+    if peak > 1:
+        wave = wave / peak
+    return (wave * (2 ** 31 - 1)).astype(np.int32)
+
+
+def write_wav_pcm32(path: str, wave: np.ndarray, sr: int) -> None:
+    """PCM_32 little-endian WAV; ``wave`` is [samples] or [channels, samples] float or int32."""
+    pcm = to_pcm32(wave)
+    if pcm.ndim == 2:
+        pcm = pcm.T if pcm.shape[0] in (1, 2) else pcm
+        ch = pcm.shape[1]
+    else:
+        ch = 1
+    raw = np.ascontiguousarray(pcm).astype("<i4").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE"
+    hdr += b"fmt " + struct.pack("<IHHIIHH", 16, 1, ch, sr, sr * ch * 4, ch * 4, 32)
+    hdr += b"data" + struct.pack("<I", len(raw))
+    with open(path, "wb") as f:
+        f.write(hdr + raw)
+
+
+def write_wav_pcm16(path: str, wave: np.ndarray, sr: int) -> None:
+    """Helper for synthetic test inputs (mono float -> PCM_16)."""
+    pcm = np.clip(np.round(np.asarray(wave, np.float64) * 32768.0), -32768, 32767).astype("<i2")
+    raw = pcm.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE"
+    hdr += b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16)
+    hdr += b"data" + struct.pack("<I", len(raw))
+    with open(path, "wb") as f:
+        f.write(hdr + raw)

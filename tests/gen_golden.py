@@ -1,0 +1,386 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported read-only from
+/root/reference) on seeded inputs.  Runs only in the build container; the
+fixtures (inputs' seeds + reference outputs) are committed, the reference is not.
+
+    python tests/gen_golden.py            # rewrites tests/golden/
+
+torchaudio / soundfile are absent here.  They are replaced by stand-ins that
+follow their documented defaults (``torchaudio.load`` -> knn_svc_amd.audio_io.read_wav,
+``Spectrogram`` -> torch.stft with a periodic Hann window, reflect centre padding,
+power=1; ``soundfile.write`` -> captured array), so the fixtures pin everything on
+the path *except* those two libraries' own arithmetic (PARITY UNPINNED there).
+
+While generating, every oracle function is checked against the reference output
+it restates; a mismatch aborts generation.
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+REF = "/root/reference"
+OUT = ROOT / "tests" / "golden"
+
+from knn_svc_amd import audio_io, config as C, synthetic as S   # noqa: E402
+from oracle import knn_ref, pipeline_ref, select_ref, smooth_ref, synth_ref, vocoder_ref, wavlm_ref  # noqa: E402
+
+
+# ---------------------------------------------------------------- reference import
+def _install_stubs():
+    ta = types.ModuleType("torchaudio")
+    tt = types.ModuleType("torchaudio.transforms")
+    tf = types.ModuleType("torchaudio.functional")
+
+    def load(p):
+        x, sr = audio_io.read_wav(str(p))
+        return torch.from_numpy(x), sr
+
+    class Spectrogram:
+        def __init__(self, n_fft, hop_length, center=True, power=1):
+            assert center and power == 1
+            self.n_fft, self.hop = n_fft, hop_length
+
+        def __call__(self, x):
+            win = torch.hann_window(self.n_fft, periodic=True)
+            s = torch.stft(x, self.n_fft, hop_length=self.hop, win_length=self.n_fft, window=win,
+                           center=True, pad_mode="reflect", normalized=False, onesided=True,
+                           return_complex=True)
+            return s.abs()
+
+    ta.load = load
+    tt.Spectrogram = Spectrogram
+    ta.transforms, ta.functional = tt, tf
+    sys.modules.update({"torchaudio": ta, "torchaudio.transforms": tt, "torchaudio.functional": tf})
+    sf = types.ModuleType("soundfile")
+    sf.captured = {}
+    sf.write = lambda fn, data, samplerate, subtype: sf.captured.__setitem__(fn, (np.array(data), samplerate, subtype))
+    sys.modules["soundfile"] = sf
+    return sf
+
+
+SF = _install_stubs()
+sys.path.insert(0, REF)
+with contextlib.redirect_stdout(io.StringIO()):
+    import ddsp_prematch_dataset as R_dp            # noqa: E402
+    import lib_ongaku_test as R_lo                  # noqa: E402
+    from wavlm.WavLM import WavLM, WavLMConfig      # noqa: E402
+    from hifigan import ddsp_models as R_mix, ddsp_models_f0 as R_f0   # noqa: E402
+    from hifigan.utils import AttrDict              # noqa: E402
+    import ddsp_matcher as R_m                      # noqa: E402
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def ref_wavlm(cfg, sd):
+    m = WavLM(WavLMConfig(dict(cfg)))
+    ref_keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    mine = {k: tuple(v.shape) for k, v in sd.items()}
+    missing = {k: s for k, s in ref_keys.items() if k not in mine and k != "mask_emb" and not k.startswith("encoder.layer_norm")}
+    assert not missing, f"spec misses reference params: {missing}"
+    for k, s in mine.items():
+        assert ref_keys[k] == s, (k, s, ref_keys[k])
+    m.load_state_dict(sd, strict=False)
+    return m.eval()
+
+
+def ref_generator(h, kind, sd):
+    mod = R_mix if kind == "mix" else R_f0
+    g = mod.SynthesizerTrn(AttrDict(dict(h)))
+    ref_keys = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    assert ref_keys == {k: tuple(v.shape) for k, v in sd.items()}, "generator spec != reference state_dict"
+    g.load_state_dict(sd)
+    return g.eval()
+
+
+def save(name, **arrs):
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / f"{name}.npz", **{k: np.asarray(v) for k, v in arrs.items()})
+    sz = (OUT / f"{name}.npz").stat().st_size
+    print(f"  wrote {name}.npz ({sz / 1024:.0f} KiB)")
+
+
+def eq(a, b, what, tol=0.0):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype.is_floating_point:
+        d = (a.double() - b.double()).abs().max().item() if a.numel() else 0.0
+        assert d <= tol, f"oracle != reference for {what}: max|d|={d}"
+    else:
+        assert torch.equal(a, b), f"oracle != reference for {what}"
+
+
+# ---------------------------------------------------------------- G1/G2/G9: WavLM
+def gen_wavlm():
+    print("G1 tiny WavLM")
+    cfg = C.WAVLM_TINY
+    sd = S.seeded_state(S.wavlm_param_spec(cfg), seed=11)
+    m = ref_wavlm(cfg, sd)
+    wav, _ = S.synth_clip(20800, seed=3)
+    x = torch.from_numpy(np.pad(wav, (0, 320)))[None]
+    with torch.inference_mode():
+        (rep, lr), _ = m.extract_features(x, output_layer=cfg["encoder_layers"], ret_layer_results=True)
+    layers = [t.transpose(0, 1)[0] for t, _ in lr]
+    mine = wavlm_ref.extract_layer(sd, cfg, x, cfg["encoder_layers"], all_layers=True)
+    for i, (a, b) in enumerate(zip(layers, mine)):
+        eq(a, b[0], f"tiny layer_results[{i}]", tol=2e-5)
+    with torch.inference_mode():
+        conv = m.feature_extractor(x)
+    eq(conv, wavlm_ref.feature_extractor(sd, cfg, x), "tiny conv features", tol=1e-6)
+    save("g1_wavlm_tiny", seed=11, clip_seed=3, n_samples=20800, checksum=S.state_checksum(sd),
+         conv=conv[0].numpy(), **{f"layer{i}": l.numpy() for i, l in enumerate(layers)})
+
+    print("G1b tiny WavLM, chunked 31 s clip (get_full_wavlm_features)")
+    wav, _ = S.synth_clip(31 * 16000 + 123, seed=4)
+    with torch.inference_mode():
+        feats = R_dp.get_full_wavlm_features(torch.from_numpy(wav)[None], 16000, m, "cpu")
+    onehot = torch.zeros(cfg["encoder_layers"] + 1); onehot[2] = 1
+    ref_l2 = (feats * onehot[:, None, None]).sum(0)
+    mine = wavlm_ref.full_features(sd, cfg, torch.from_numpy(wav), 2)
+    eq(ref_l2, mine, "chunked layer-2 features", tol=2e-5)
+    save("g1b_wavlm_chunked", seed=11, clip_seed=4, n_samples=31 * 16000 + 123, n_frames=ref_l2.shape[0],
+         rows=ref_l2[::10].numpy())
+
+    print("G1c full-dim WavLM-Large, 1 layer, 1 s clip")
+    cfgL = dict(C.WAVLM_LARGE, encoder_layers=1)
+    sdL = S.seeded_state(S.wavlm_param_spec(cfgL), seed=12)
+    mL = ref_wavlm(cfgL, sdL)
+    wav, _ = S.synth_clip(16000, seed=5)
+    x = torch.from_numpy(np.pad(wav, (0, 320)))[None]
+    with torch.inference_mode():
+        (rep, lr), _ = mL.extract_features(x, output_layer=1, ret_layer_results=True)
+    l0, l1 = lr[0][0][:, 0], lr[1][0][:, 0]
+    mine = wavlm_ref.extract_layer(sdL, cfgL, x, 1, all_layers=True)
+    eq(l0, mine[0][0], "large layer0", tol=5e-5)
+    eq(l1, mine[1][0], "large layer1", tol=5e-5)
+    save("g1c_wavlm_large1", seed=12, clip_seed=5, n_samples=16000, checksum=S.state_checksum(sdL),
+         layer0=l0.numpy(), layer1=l1.numpy())
+
+    print("G2 relative-position bucket table, T=1500")
+    att = mL.encoder.layers[0].self_attn
+    T = 1500
+    rel = torch.arange(T)[None, :] - torch.arange(T)[:, None]
+    b = att._relative_positions_bucket(rel, bidirectional=True)
+    lut = wavlm_ref.rel_bucket_table(T, 320, 800)
+    eq(b, lut[rel + T - 1], "bucket table")
+    save("g2_bucket_table", T=T, table=lut.numpy().astype(np.int16))
+
+    print("G9 frame-count law")
+    lens = [320 * 50, 320 * 50 + 1, 320 * 50 - 1, 480000, 480512, 480000 + 320, 480000 + 321, 960512]
+    counts = []
+    for ln in lens:
+        with torch.inference_mode():
+            f = R_dp.get_full_wavlm_features(torch.zeros(1, ln), 16000, m, "cpu")
+        counts.append(f.shape[1])
+        mine = sum(wavlm_ref.n_frames(l + p, cfg) for (_s, l, p) in wavlm_ref.chunk_plan(ln))
+        assert mine == f.shape[1], (ln, mine, f.shape[1])
+    save("g9_frame_law", lengths=np.array(lens), frames=np.array(counts))
+
+
+# ---------------------------------------------------------------- G3: kNN
+def gen_knn():
+    print("G3 kNN top-32 on clustered features")
+    q = S.clustered_features(200, 1024, seed=21)
+    p = S.clustered_features(4096, 1024, seed=22)
+    idxs, vals = [], []
+    for s in range(0, len(q), 20):
+        d = R_lo.fast_cosine_dist(q[s:s + 20], p)
+        t = d.topk(k=32, dim=-1, largest=False)
+        idxs.append(t.indices); vals.append(t.values)
+    idx, val = torch.cat(idxs), torch.cat(vals)
+    mi, mv = knn_ref.knn_topk(q, p, 32)
+    eq(idx, mi, "knn idx"); eq(val, mv, "knn dist")
+    # small-matrix (non-mm cdist) route, as used by knn_with_concat_cost
+    small = R_lo.fast_cosine_dist(q[:4], p[:8])
+    eq(small, knn_ref.cosine_dist(q[:4], p[:8]), "small cdist")
+    save("g3_knn", q_seed=21, p_seed=22, nq=200, np_=4096, idx=idx.numpy().astype(np.int32), dist=val.numpy(),
+         small=small.numpy())
+
+
+# ---------------------------------------------------------------- G4: selection
+def _f0_track(n, seed):
+    _, f0 = S.synth_clip(n * 320, seed)
+    return torch.from_numpy(f0[:n].copy())
+
+
+def gen_select():
+    print("G4 f0 shift / re-rank / concat re-selection")
+    nq, npool = 150, 2000
+    q = S.clustered_features(nq, 1024, seed=31, n_centres=40)
+    p = S.clustered_features(npool, 1024, seed=32, n_centres=40)
+    # give the sequences temporal continuity so that concat costs matter
+    q = (q + torch.roll(q, 1, 0) + torch.roll(q, 2, 0)) / 3
+    p = (p + torch.roll(p, 1, 0) + torch.roll(p, 2, 0)) / 3
+    qf0, pf0 = _f0_track(nq, 33) * 1.3, _f0_track(npool, 34)
+    nn32, _ = knn_ref.knn_topk(q, p, 32)
+    # f0 shift: lines 1224-1233 executed literally
+    import copy
+    qm = torch.median(torch.log(qf0[qf0 != 0])); pm = torch.median(torch.log(pf0[pf0 != 0]))
+    shifted = copy.deepcopy(qf0); shifted[qf0 != 0] = torch.exp(torch.log(qf0[qf0 != 0]) + pm - qm)
+    eq(shifted, select_ref.shift_query_f0(qf0, pf0), "shifted f0")
+    ranked = R_dp.sort_by_f0_compatibility(shifted, pf0, nn32)
+    eq(ranked, select_ref.rerank_by_f0(shifted, pf0, nn32), "f0 rerank")
+    with quiet():
+        sel_a = R_lo.knn_with_concat_cost(copy.deepcopy(nn32[:, :4]), q, p, concat_weight=0.2)
+        sel_b = R_lo.knn_with_concat_cost(copy.deepcopy(ranked[:, :4]), q, p, shifted, pf0, concat_weight=0.2)
+    eq(sel_a, select_ref.concat_reselect(nn32[:, :4].clone(), q, p, concat_weight=0.2), "concat (no f0)")
+    eq(sel_b, select_ref.concat_reselect(ranked[:, :4].clone(), q, p, shifted, pf0, concat_weight=0.2), "concat (f0)")
+    save("g4_select", nq=nq, npool=npool, qf0=qf0.numpy(), pf0=pf0.numpy(), shifted=shifted.numpy(),
+         nn32=nn32.numpy().astype(np.int32), ranked=ranked.numpy().astype(np.int32),
+         sel_plain=sel_a.numpy().astype(np.int32), sel_f0=sel_b.numpy().astype(np.int32))
+    for po, want in [("post_opt_0.2", (0.2, True)), ("no_post_opt", (-1, False)), ("post_opt_extra", (0.3, True)),
+                     ("post_opt_0.05", (0.05, True))]:
+        assert select_ref.parse_post_opt(po) == want
+
+
+# ---------------------------------------------------------------- G5: Adam weights
+def gen_smooth():
+    print("G5 smoothness weights (Adam loops)")
+    n, npool = 80, 600
+    p = S.clustered_features(npool, 1024, seed=41, n_centres=30)
+    p = (p + torch.roll(p, 1, 0) + torch.roll(p, 2, 0)) / 3
+    g = torch.Generator().manual_seed(42)
+    idx = torch.randint(0, npool, (n, 4), generator=g)
+    idx[0, 0] = 0; idx[1, 1] = npool - 1          # exercise the clamps
+    with quiet():
+        w_ref = R_dp.compute_wavlm_weight(idx.clone(), p)
+    w_mine, it = smooth_ref.smooth_weights(idx, p, 0.1, return_iters=True)
+    eq(w_ref, w_mine, "wavlm weights", tol=0.0)
+    ph = torch.rand(npool, 49, generator=g) * 0.05
+    with quiet():
+        wh_ref = R_dp.compute_extended_weight(idx.clone(), ph, "sum_to_1_geq", [1])
+    wh_mine, ith = smooth_ref.smooth_weights(idx, ph, 1000.0, return_iters=True)
+    eq(wh_ref.detach(), wh_mine, "harmonic weights", tol=0.0)
+    save("g5_smooth", n=n, npool=npool, p_seed=41, idx=idx.numpy().astype(np.int32), harm_pool=ph.numpy(),
+         w_wavlm=w_ref.detach().numpy(), iters_wavlm=it, w_harm=wh_ref.detach().numpy(), iters_harm=ith)
+
+
+# ---------------------------------------------------------------- G6/G8: synth + harmonics
+def gen_synth():
+    print("G6 additive synth / G8 harmonic amplitudes")
+    n = 50
+    f0 = _f0_track(n, 51) * 2.2                      # pushes upper harmonics past Nyquist
+    g = torch.Generator().manual_seed(52)
+    amp = torch.rand(n, 49, generator=g) * 0.02
+    y = R_dp.get_bulk_dsp_choral(f0[None, :, None], amp[None])
+    eq(y, synth_ref.additive_synth(f0[None, :, None], amp[None]), "additive synth")
+    wav, f0w = S.synth_clip(320 * 120, seed=53)
+    spec = synth_ref.stft_mag(torch.from_numpy(wav))[:120]
+    f0w = torch.from_numpy(f0w[:120].copy())
+    # harmonic extraction: reference lines 391-404 executed literally
+    import torch.nn.functional as F
+    mh = f0w[:, None] * torch.arange(1, 50)[None, :]
+    interp = F.interpolate(spec[None, :], scale_factor=8, mode="linear").squeeze(0)
+    mi = torch.round(torch.clamp(mh * 2 * interp.shape[-1] / 16000, max=interp.shape[-1])).to(int)
+    ht = torch.gather(F.pad(interp, (0, 1)), dim=-1, index=mi)
+    ht[:, 1:][f0w == 0] = 0
+    ht[:, 0][f0w == 0] = torch.max(spec, dim=1)[0][f0w == 0]
+    ht = 0.0108 * ht
+    eq(ht, synth_ref.harmonic_amps(spec, f0w), "harmonic amps")
+    save("g6_synth", f0=f0.numpy(), amp=amp.numpy(), wave=y[0, :, 0].numpy(),
+         clip_seed=53, spec=spec.numpy(), f0w=f0w.numpy(), harm=ht.numpy())
+
+
+# ---------------------------------------------------------------- G7: generators
+def gen_vocoder():
+    print("G7 tiny generators (mix, f0)")
+    h = C.HIFIGAN_TINY
+    n = 40
+    g = torch.Generator().manual_seed(61)
+    c = torch.randn(1, n, h["hubert_dim"], generator=g)
+    f0 = (_f0_track(n, 62))[None, :, None]
+    harm = torch.rand(1, n, 49, generator=g) * 0.02
+    out = {}
+    for kind, seed in (("mix", 63), ("f0", 64)):
+        sd = S.seeded_state(S.generator_param_spec(h, kind), seed)
+        gen = ref_generator(h, kind, sd)
+        with torch.inference_mode():
+            y = gen(c, f0, harm) if kind == "mix" else gen(c, f0)
+        mine = vocoder_ref.synthesizer(sd, h, kind, c, f0, harm if kind == "mix" else None)
+        eq(y, mine, f"generator {kind}", tol=1e-6)
+        out["wave_" + kind] = y[0, 0].numpy()
+        out["checksum_" + kind] = S.state_checksum(sd)
+    print("     full-size spec check (names/shapes only)")
+    for kind in ("mix", "f0"):
+        sd = S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, kind), 1)
+        ref_generator(C.HIFIGAN_V1, kind, sd)
+    save("g7_vocoder", n=n, seed_in=61, f0=f0[0, :, 0].numpy(), harm=harm[0].numpy(), c=c[0].numpy(), **out)
+
+
+# ---------------------------------------------------------------- G10/G11: save_audio + end to end
+def gen_e2e():
+    print("G10 save_audio scaling")
+    g = np.random.default_rng(71)
+    for nm, w in (("quiet", 0.5 * g.standard_normal(1000).astype(np.float32).clip(-1, 1)),
+                  ("loud", 3.0 * g.standard_normal(1000).astype(np.float32))):
+        R_lo.save_audio(f"/tmp/{nm}.wav", torch.from_numpy(w), 16000)
+        got = SF.captured[f"/tmp/{nm}.wav"][0]
+        assert np.array_equal(got, pipeline_ref.to_pcm32(w)), nm
+        assert np.array_equal(got, audio_io.to_pcm32(w)), nm
+    save("g10_pcm", loud_in=w, loud_out=got)
+
+    print("G11 end-to-end tiny pipeline through the reference's match_at_inference_time + vocode")
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    sdw = S.seeded_state(S.wavlm_param_spec(cfg), seed=11)
+    m = ref_wavlm(cfg, sdw)
+    tmp = Path(tempfile.mkdtemp())
+    (tmp / "a").mkdir(); (tmp / "b").mkdir()
+    src_wav, src_f0 = S.synth_clip(3 * 16000 + 77, seed=81)
+    pool = [S.synth_clip(4 * 16000 + 5 * i, seed=82 + i) for i in range(3)]
+    # PCM16 round trip so that the file content is what both sides read
+    audio_io.write_wav_pcm16(str(tmp / "a" / "src.wav"), src_wav, 16000)
+    np.save(tmp / "a" / "src_f0.npy", src_f0 * 1.25)
+    for i, (w, f) in enumerate(pool):
+        audio_io.write_wav_pcm16(str(tmp / "b" / f"u{i}.wav"), w, 16000)
+        np.save(tmp / "b" / f"u{i}_f0.npy", f)
+    src_w = torch.from_numpy(audio_io.read_wav(str(tmp / "a" / "src.wav"))[0][0])
+    pool_w = [torch.from_numpy(audio_io.read_wav(str(tmp / "b" / f"u{i}.wav"))[0][0]) for i in range(3)]
+    src_f = torch.from_numpy(src_f0 * 1.25)
+    pool_f = [torch.from_numpy(f) for _, f in pool]
+    onehot = torch.zeros(cfg["encoder_layers"] + 1); onehot[2] = 1      # "layer 6" of the tiny model
+    weights = onehot[:, None]
+    res = {}
+    for kind, ckpt, post_opt, seed in (("mix", "mix", "post_opt_0.2", 63), ("mix", "mix", "no_post_opt", 63),
+                                       ("f0", "wavlm_only", "no_post_opt", 64)):
+        sdg = S.seeded_state(S.generator_param_spec(h, kind), seed)
+        gen = ref_generator(h, kind, sdg)
+        knn = R_m.KNeighborsVC(m, gen, AttrDict(dict(h)), "cpu")
+        knn.weighting = weights
+        srcp = str(tmp / "a" / "src.wav")
+        with quiet():
+            if kind == "mix":
+                of, hf, _, sf0 = R_dp.match_at_inference_time(Path(srcp), tmp / "b", m, weights, weights, device="cpu",
+                                                               prioritize_f0=True, ckpt_type=ckpt, post_opt=post_opt,
+                                                               tgt_dataset_path=tmp, duration_limit=7)
+                y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None], hf[srcp][None]).squeeze()
+            else:
+                of, _, sf0 = R_dp.match_at_inference_time(Path(srcp), tmp / "b", m, weights, weights, device="cpu",
+                                                          prioritize_f0=True, ckpt_type=ckpt,
+                                                          tgt_dataset_path=tmp, duration_limit=7)
+                y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None]).squeeze()
+        mine = pipeline_ref.convert(sdw, cfg, sdg, h, kind, src_w, src_f, pool_w, pool_f, ckpt, post_opt,
+                                    duration_limit=7, n_layers=2)
+        eq(y, mine, f"e2e {ckpt} {post_opt}", tol=2e-5)
+        res[f"{ckpt}__{post_opt}"] = y.numpy()
+        print(f"     {ckpt} {post_opt}: {tuple(y.shape)} rms {y.pow(2).mean().sqrt():.4f}")
+    save("g11_e2e", src_seed=81, pool_seed0=82, f0_scale=1.25, duration_limit=7, **res)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["wavlm", "knn", "select", "smooth", "synth", "vocoder", "e2e"]
+    for w in which:
+        globals()["gen_" + w]()
+    print("done")
