@@ -1,0 +1,174 @@
+/*
+ * libknnsvc_hip.so — C ABI of the MI355X (gfx950) kNN-SVC inference kernels.
+ *
+ * The reference (SmoothKen/knn-svc) has no FFI: its seams are Python callables
+ * executed by PyTorch ATen.  Each entry point below replaces one of those
+ * callables; the comment above it cites the reference file:line.  A maintainer
+ * binds them with ctypes (see INTEGRATION.md for the stubs).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless named host_*;
+ *   - activations are channel-last: a [T, C] matrix with row stride `ld*` (floats);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); nothing synchronises, nothing allocates — callers own every buffer and
+ *     workspace, so each call is hipGraph-capturable;
+ *   - return value: 0 on success, a KNNSVC_E* code otherwise; knnsvc_last_error()
+ *     gives the thread-local message.
+ */
+#ifndef KNNSVC_HIP_H
+#define KNNSVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNNSVC_OK        0
+#define KNNSVC_EINVAL    1   /* bad shape / alignment / argument          */
+#define KNNSVC_EWORKSPACE 2  /* workspace too small                        */
+#define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
+#define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
+
+#define KNNSVC_ABI_VERSION 1
+
+int knnsvc_abi_version(void);
+const char* knnsvc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces F.conv1d / F.conv_transpose1d / F.linear as used by
+ *   wavlm/WavLM.py:401,514-527 (feature extractor, pos_conv), wavlm/WavLM.py:347-348, 671-672,
+ *   wavlm/modules.py:540-563 (q/k/v/out projections),
+ *   hifigan/ddsp_models.py:113-168,176-233 (every conv of the Generator), :416 (sin_prenet).
+ *
+ *   out[b,g][m, n] = epilogue( sum_{tap,c} A(m,tap,c) * W[g][n][tap*cin + c] )
+ *   A(m,tap,c)     = lrelu_{a_slope}( X[b,g][m*stride + tap*dil - pad][c] )   (0 outside [0,t_in))
+ *   epilogue(v)    = ((act(v + bias[n % bias_period]) + resid[m,n]) + (accumulate ? out[m,n] : 0)) / div
+ * With convt_u > 0 the output element (m, n) is scattered to row m*convt_u + n/convt_cout - convt_pad,
+ * column n % convt_cout (rows outside [0,t_out) dropped): a stride-u transposed convolution whose
+ * kernel is taps*u wide, written as one GEMM over K = taps*cin, N = u*cout.
+ * ------------------------------------------------------------------------------------------ */
+enum { KNNSVC_ACT_NONE = 0, KNNSVC_ACT_GELU = 1, KNNSVC_ACT_LRELU = 2, KNNSVC_ACT_TANH = 3 };
+
+typedef struct knnsvc_conv_desc {
+    const float* x;  int64_t x_bstride; int64_t x_gstride; int32_t ldx; int32_t t_in;
+    int32_t cin; int32_t taps; int32_t stride; int32_t dil; int32_t pad;
+    float a_slope;                     /* 1.0f = no prologue activation                   */
+    const float* w;  int64_t w_gstride; int32_t n;
+    const float* bias; int64_t bias_gstride; int32_t bias_period;   /* bias may be NULL  */
+    float* out; int64_t o_bstride; int64_t o_gstride; int32_t ldo; int32_t m;
+    int32_t act; float act_slope;
+    const float* resid; int64_t r_bstride; int64_t r_gstride; int32_t ldr;   /* may be NULL */
+    int32_t accumulate; float div;     /* div == 1.0f = off                               */
+    int32_t batches; int32_t groups;
+    int32_t convt_u; int32_t convt_cout; int32_t convt_pad; int32_t t_out;
+} knnsvc_conv_desc;
+
+int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-wise layer norm over the last dim (eps 1e-5, affine), optional exact-erf GELU after it.
+ * Replaces F.layer_norm at wavlm/WavLM.py:342, 415 (+nn.GELU :418), 692, 706.  In place allowed.
+ * ------------------------------------------------------------------------------------------ */
+int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32_t ldx, const float* gamma,
+                     const float* beta, int32_t gelu, float* out, int32_t ldo, void* stream);
+
+/* Gated relative-position multiplier, wavlm/modules.py:523-533:
+ *   gate[row, h] = ga*(gb*grep_a[h] - 1) + 2, (ga, gb) = sigmoid(W2 @ xn[row, h*hd:(h+1)*hd] + b2)
+ * where W2 [2, hd] / b2 [2] are grep_linear's weight rows / bias summed in groups of four. */
+int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head_dim, int32_t ldx,
+                      const float* w2, const float* b2, const float* grep_a, float* gate, void* stream);
+
+/* Fused bidirectional self-attention with the gated bucketed relative-position bias
+ * (wavlm/modules.py:504-506, 533-563 -> F.multi_head_attention_forward, need_weights=False):
+ *   O[b, i, h, :] = softmax_j( q_i.k_j * head_dim^-0.5 + gate[b,i,h] * table[h][j - i + T - 1] ) @ V
+ * qkv is [batches*T, 3*E] (q | k | v column blocks, E = heads*64), table is [heads][2T-1]
+ * (bucket LUT already applied), gate [batches*T, heads], out [batches*T, E].  head_dim must be 64.
+ * Nothing of size T x T is ever written to HBM. */
+int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
+                           int32_t T, int32_t heads, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cosine-distance kNN (lib_ongaku_test.py:148-175 fast_cosine_dist + Tensor.topk(k, largest=False),
+ * driver loop ddsp_prematch_dataset.py:1195-1210).
+ * ------------------------------------------------------------------------------------------ */
+/* norm[r] = sqrt(sum x^2) (torch.norm, lib_ongaku_test.py:150-151); sq[r] = sum x^2 (cdist's own term) */
+int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, float* norm, float* sq, void* stream);
+
+size_t knnsvc_knn_workspace_bytes(int64_t nq, int64_t np, int32_t k);
+
+/* Ascending top-k of d(q_i, p_j) per query row, d evaluated with the reference's operation
+ * sequence on top of an MFMA dot product.  Ties: lower pool index first.  Indices are written
+ * as idx_offset + j (so that a pool shard reports global rows).  k <= 32. */
+int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int64_t nq,
+                    const float* pool, const float* p_norm, const float* p_sq, int64_t np,
+                    int32_t dim, int32_t k, int64_t idx_offset,
+                    int64_t* out_idx, float* out_dist, void* workspace, size_t workspace_bytes,
+                    int32_t* nan_flag, void* stream);
+
+/* Merge `parts` per-shard top-k lists ([parts][nq][k], e.g. after an RCCL all-gather) into one. */
+int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx, int32_t parts, int64_t nq,
+                     int32_t k, int64_t* out_idx, float* out_dist, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Neighbour post-processing.
+ * ------------------------------------------------------------------------------------------ */
+/* lower median of log(f0) over voiced frames (torch.median, ddsp_prematch_dataset.py:1224-1225);
+ * result[0] = median, result[1] = voiced count (as float).  workspace: n floats. */
+int knnsvc_log_f0_median(const float* f0, int64_t n, float* result, float* workspace, void* stream);
+
+/* shifted[i] = f0[i] ? exp(log f0[i] + (pool_median - query_median)) : 0   (:1232-1233) */
+int knnsvc_shift_f0(const float* f0, int64_t n, const float* query_median, const float* pool_median,
+                    float* shifted, void* stream);
+
+/* sort_by_f0_compatibility (ddsp_prematch_dataset.py:954-1016): stable ascending re-order of each
+ * row's k neighbours by |log2(pool_f0[idx]+1e-5) - log2(shifted[i]+1e-5)|. k <= 64. */
+int knnsvc_f0_rerank(const int64_t* nn_idx, int64_t nq, int32_t k, const float* shifted_f0,
+                     const float* pool_f0, int64_t* out_idx, void* stream);
+
+/* knn_with_concat_cost (lib_ongaku_test.py:270-369), frame-sequential, one workgroup per sequence.
+ * idx_in/out [nq, 4]; use_f0 selects the pitched variant. */
+int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, const float* q_norm, int64_t nq,
+                           const float* pool, const float* p_norm, int64_t np, int32_t dim,
+                           const float* shifted_f0, const float* pool_f0, int32_t use_f0,
+                           float concat_weight, int64_t* idx_out, void* stream);
+
+/* compute_wavlm_weight / compute_extended_weight (ddsp_prematch_dataset.py:574-680, 807-924):
+ * Adam(amsgrad) on softmax weights with the reference's stopping rules, run entirely on the
+ * device (no per-iteration host sync).  scale = 0.1 (WavLM) or 1000 (harmonics).
+ * out_w [nq,4]; out_iters[0] = iterations executed.  workspace from knnsvc_smooth_workspace_bytes. */
+size_t knnsvc_smooth_workspace_bytes(int64_t nq);
+int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float* pool, int64_t np, int32_t dim,
+                          int32_t ld, float scale, int32_t max_iter, float* out_w, int32_t* out_iters,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i,:] = sum_k w[i,k] * pool[idx[i,k], :]   (ddsp_prematch_dataset.py:1358, 1444; w NULL = mean of 4
+ * for harmonics :1446 / softmax(ones) :1361-1364) */
+int knnsvc_weighted_gather(const int64_t* idx, const float* w, int64_t nq, int32_t k, const float* pool,
+                           int32_t dim, int32_t ld, int32_t mean_mode, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pool side features and the additive synthesiser.
+ * ------------------------------------------------------------------------------------------ */
+/* reflect-pad by `pad` samples each side (torch.stft center=True) : out[n + 2*pad] */
+int knnsvc_reflect_pad(const float* x, int64_t n, int32_t pad, float* out, void* stream);
+/* |re + i im| of a [rows, 2*bins] (cos block | sin block) DFT product -> [rows, bins] */
+int knnsvc_complex_mag(const float* reim, int64_t rows, int32_t bins, int32_t ld, float* out, void* stream);
+/* harmonic amplitudes (ddsp_prematch_dataset.py:391-404): spec [T,200], f0 [T] -> harm [T,49] */
+int knnsvc_harmonic_amps(const float* spec, const float* f0, int64_t T, int32_t bins, int32_t n_harm,
+                         float* harm, void* stream);
+/* get_bulk_dsp_choral (ddsp_prematch_dataset.py:165-208) fused with sin_prenet
+ * (hifigan/ddsp_models.py:416,476): f0 [N], amp [N,H] -> cond [N*hop, n_ch] channel-last, and
+ * optionally the raw excitation exc [N*hop].  mode 0 = additive (mix), 1 = plain sine of f0
+ * (hifigan/ddsp_models_f0.py:348-356; amp ignored).  frame_phase: N doubles of workspace. */
+int knnsvc_additive_synth(const float* f0, const float* amp, int64_t N, int32_t H, int32_t hop,
+                          int32_t sample_rate, int32_t mode, const float* prenet_w, const float* prenet_b,
+                          int32_t n_ch, float* cond, int32_t ld_cond, float* exc, double* frame_phase,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNNSVC_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libknnsvc_hip.so (the C ABI in include/knnsvc_hip.h).
+
+There is deliberately no fallback: if the library is missing or a symbol is
+absent, importing an op raises.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C knn_svc_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libknnsvc_hip.so")
+ABI_VERSION = 1
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    """struct knnsvc_conv_desc (field order and types must match the header)."""
+    _fields_ = [
+        ("x", vp), ("x_bstride", i64), ("x_gstride", i64), ("ldx", i32), ("t_in", i32),
+        ("cin", i32), ("taps", i32), ("stride", i32), ("dil", i32), ("pad", i32),
+        ("a_slope", f32),
+        ("w", vp), ("w_gstride", i64), ("n", i32),
+        ("bias", vp), ("bias_gstride", i64), ("bias_period", i32),
+        ("out", vp), ("o_bstride", i64), ("o_gstride", i64), ("ldo", i32), ("m", i32),
+        ("act", i32), ("act_slope", f32),
+        ("resid", vp), ("r_bstride", i64), ("r_gstride", i64), ("ldr", i32),
+        ("accumulate", i32), ("div", f32),
+        ("batches", i32), ("groups", i32),
+        ("convt_u", i32), ("convt_cout", i32), ("convt_pad", i32), ("t_out", i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol the header declares
+SIGNATURES = {
+    "knnsvc_abi_version": (i32, []),
+    "knnsvc_last_error": (C.c_char_p, []),
+    "knnsvc_conv_gemm": (i32, [C.POINTER(ConvDesc), vp]),
+    "knnsvc_layernorm": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "knnsvc_knn_workspace_bytes": (sz, [i64, i64, i32]),
+    "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, vp, vp, vp, sz, vp, vp]),
+    "knnsvc_knn_merge": (i32, [vp, vp, i32, i64, i32, vp, vp, vp]),
+    "knnsvc_log_f0_median": (i32, [vp, i64, vp, vp, vp]),
+    "knnsvc_shift_f0": (i32, [vp, i64, vp, vp, vp, vp]),
+    "knnsvc_f0_rerank": (i32, [vp, i64, i32, vp, vp, vp, vp]),
+    "knnsvc_concat_reselect": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, i32, f32, vp, vp]),
+    "knnsvc_smooth_workspace_bytes": (sz, [i64]),
+    "knnsvc_smooth_weights": (i32, [vp, i64, vp, i64, i32, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "knnsvc_weighted_gather": (i32, [vp, vp, i64, i32, vp, i32, i32, i32, vp, vp]),
+    "knnsvc_reflect_pad": (i32, [vp, i64, i32, vp, vp]),
+    "knnsvc_complex_mag": (i32, [vp, i64, i32, i32, vp, vp]),
+    "knnsvc_harmonic_amps": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "knnsvc_additive_synth": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class KnnSvcError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the shared library; raises if it is absent — no CPU fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise KnnSvcError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  knn_svc_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    got = lib.knnsvc_abi_version()
+    if got != ABI_VERSION:
+        raise KnnSvcError(f"libknnsvc_hip ABI {got} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().knnsvc_last_error().decode("utf-8", "replace")
+        raise KnnSvcError(f"libknnsvc_hip {what} failed (code {rc}): {msg}")

@@ -1,0 +1,218 @@
+// Implicit-GEMM convolution / linear / transposed convolution on fp32 MFMA.
+// See include/knnsvc_hip.h (knnsvc_conv_gemm) for the operator definition and the
+// reference call sites it replaces.
+#include "gemm_core.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x; long x_bstride, x_gstride; int ldx, t_in, cin, taps, stride, dil, pad; float a_slope;
+    const float* w; long w_gstride; int n;
+    const float* bias; long bias_gstride; int bias_period;
+    float* out; long o_bstride, o_gstride; int ldo, m;
+    int act; float act_slope;
+    const float* resid; long r_bstride, r_gstride; int ldr;
+    int accumulate; float div;
+    int groups;
+    int convt_u, convt_cout, convt_pad, t_out;
+    int K;
+};
+
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+
+// ---- A operand: im2col view of the channel-last activation matrix ------------------------
+template <int VEC, int NF4>
+struct ALoader {
+    const float* x; int ldx, t_in, cin, stride, dil, pad, K; float slope;
+    int rowbase[NF4];          // m*stride - pad, or INT_MIN/2 when m is out of range
+    int k_cur, tap, c;         // state of the VEC==4 path (k = slab*32 + (tid&7)*4)
+    __device__ ALoader(const ConvArgs& a, const float* xz, int m0, int tid)
+        : x(xz), ldx(a.ldx), t_in(a.t_in), cin(a.cin), stride(a.stride), dil(a.dil), pad(a.pad), K(a.K),
+          slope(a.a_slope) {
+#pragma unroll
+        for (int j = 0; j < NF4; ++j) {
+            int m = m0 + (tid >> 3) + 32 * j;
+            rowbase[j] = (m < a.m) ? m * stride - pad : -(1 << 30);
+        }
+        k_cur = (tid & 7) * 4;
+        tap = k_cur / cin;
+        c = k_cur - tap * cin;
+    }
+    __device__ __forceinline__ f32x4 operator()(int kt, int j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int k = kt * 32 + (threadIdx.x & 7) * 4;
+        if (VEC == 4) {
+            if (k != k_cur) {                     // advance (tap, c) by whole slabs
+                c += k - k_cur;
+                k_cur = k;
+                while (c >= cin) { c -= cin; ++tap; }
+            }
+            const int row = rowbase[j] + tap * dil;
+            if (k < K && row >= 0 && row < t_in) v = *(const f32x4*)(x + (long)row * ldx + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ke = k + e;
+                const int tp = ke / cin, cc = ke - tp * cin;
+                const int row = rowbase[j] + tp * dil;
+                if (ke < K && row >= 0 && row < t_in) v[e] = x[(long)row * ldx + cc];
+            }
+        }
+        if (slope != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], slope);
+        }
+        return v;
+    }
+};
+
+// ---- B operand: weights [n][K], K contiguous ----------------------------------------------
+template <int VEC, int NF4>
+struct BLoader {
+    const float* w; int N, K, n0;
+    __device__ BLoader(const float* wz, int N_, int K_, int n0_) : w(wz), N(N_), K(K_), n0(n0_) {}
+    __device__ __forceinline__ f32x4 operator()(int kt, int j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int n = n0 + (threadIdx.x >> 3) + 32 * j;
+        const int k = kt * 32 + (threadIdx.x & 7) * 4;
+        if (n < N) {
+            if (VEC == 4) {
+                if (k < K) v = *(const f32x4*)(w + (long)n * K + k);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < K) v[e] = w[(long)n * K + k + e];
+            }
+        }
+        return v;
+    }
+};
+
+template <class G, int VEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const float* wz = a.w + g * a.w_gstride;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    ALoader<VEC, G::A_F4> al(a, xz, m0, threadIdx.x);
+    BLoader<VEC, G::B_F4> bl(wz, a.n, a.K, n0);
+    G::mainloop(lds, (a.K + 31) / 32, al, bl, acc);
+
+    // ---- epilogue -------------------------------------------------------------------------
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
+    const float* rz = a.resid ? a.resid + b * a.r_bstride + g * a.r_gstride : nullptr;
+    const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j) {
+        const int n = n0 + G::acc_col(wave, lane, j);
+        if (n >= a.n) continue;
+        const float bv = bz ? bz[a.bias_period ? n % a.bias_period : n] : 0.f;
+        int phase = 0, col = n;
+        if (a.convt_u) { phase = n / a.convt_cout; col = n - phase * a.convt_cout; }
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + G::acc_row(wave, lane, i, r);
+                if (m >= a.m) continue;
+                long orow = m;
+                if (a.convt_u) {
+                    orow = (long)m * a.convt_u + phase - a.convt_pad;
+                    if (orow < 0 || orow >= a.t_out) continue;
+                }
+                float v = acc[i][j][r] + bv;
+                if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
+                else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
+                if (rz) v += rz[orow * a.ldr + col];
+                float* op = oz + orow * a.ldo + col;
+                if (a.accumulate) v += *op;
+                if (a.div != 1.0f) v = v / a.div;
+                *op = v;
+            }
+        }
+    }
+}
+
+template <class G, int VEC>
+int launch(const ConvArgs& a, int batches, hipStream_t st) {
+    dim3 grid((unsigned)cdiv64(a.m, G::BM), (unsigned)cdiv64(a.n, G::BN), (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm_kernel<G, VEC>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm");
+}
+
+using G128 = GemmTile<128, 128, 2, 2, 2, 2>;
+using G64 = GemmTile<128, 64, 4, 1, 1, 2>;
+using G32 = GemmTile<128, 32, 4, 1, 1, 1>;
+
+template <class G>
+int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
+    static bool done4 = false, done1 = false;
+    if (!done4) {
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<G, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess) return 1;
+        done4 = true;
+    }
+    if (!done1) {
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<G, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess) return 1;
+        done1 = true;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
+    KN_REQUIRE(d && d->x && d->w && d->out, "conv_gemm: null operand");
+    KN_REQUIRE(d->cin > 0 && d->taps > 0 && d->n > 0 && d->m >= 0 && d->t_in >= 0, "conv_gemm: bad sizes");
+    KN_REQUIRE(d->batches > 0 && d->groups > 0, "conv_gemm: batches/groups must be positive");
+    KN_REQUIRE(d->ldx >= d->cin && d->stride > 0, "conv_gemm: ldx < cin or stride <= 0");
+    KN_REQUIRE((long)d->batches * d->groups <= 65535, "conv_gemm: batches*groups > 65535");
+    KN_REQUIRE(cdiv64(d->n, 32) <= 65535, "conv_gemm: n too large for grid.y");
+    if (d->convt_u) {
+        KN_REQUIRE(d->convt_cout > 0 && d->n % d->convt_cout == 0 && d->n / d->convt_cout == d->convt_u,
+                   "conv_gemm: transposed mode needs n == u*cout");
+        KN_REQUIRE(d->ldo >= d->convt_cout, "conv_gemm: ldo < cout");
+    } else {
+        KN_REQUIRE(d->ldo >= d->n, "conv_gemm: ldo < n");
+    }
+    if (d->resid) KN_REQUIRE(d->ldr > 0, "conv_gemm: resid without ldr");
+    if (d->m == 0) return KNNSVC_OK;
+
+    ConvArgs a;
+    a.x = d->x; a.x_bstride = d->x_bstride; a.x_gstride = d->x_gstride; a.ldx = d->ldx; a.t_in = d->t_in;
+    a.cin = d->cin; a.taps = d->taps; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.a_slope = d->a_slope;
+    a.w = d->w; a.w_gstride = d->w_gstride; a.n = d->n;
+    a.bias = d->bias; a.bias_gstride = d->bias_gstride; a.bias_period = d->bias_period;
+    a.out = d->out; a.o_bstride = d->o_bstride; a.o_gstride = d->o_gstride; a.ldo = d->ldo; a.m = d->m;
+    a.act = d->act; a.act_slope = d->act_slope;
+    a.resid = d->resid; a.r_bstride = d->r_bstride; a.r_gstride = d->r_gstride; a.ldr = d->ldr;
+    a.accumulate = d->accumulate; a.div = d->div == 0.f ? 1.0f : d->div;
+    a.groups = d->groups;
+    a.convt_u = d->convt_u; a.convt_cout = d->convt_cout; a.convt_pad = d->convt_pad; a.t_out = d->t_out;
+    a.K = d->cin * d->taps;
+
+    // 16-byte vector path needs every float4 of A and W to be aligned and inside one tap
+    const bool vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
+                      (((uintptr_t)d->w & 15) == 0) && (d->x_bstride % 4 == 0) && (d->x_gstride % 4 == 0) &&
+                      (d->w_gstride % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (prepare<G128>() || prepare<G64>() || prepare<G32>())
+        return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+    if (d->n > 64) return vec4 ? launch<G128, 4>(a, d->batches, st) : launch<G128, 1>(a, d->batches, st);
+    if (d->n > 32) return vec4 ? launch<G64, 4>(a, d->batches, st) : launch<G64, 1>(a, d->batches, st);
+    return vec4 ? launch<G32, 4>(a, d->batches, st) : launch<G32, 1>(a, d->batches, st);
+}

@@ -1,0 +1,208 @@
+// Small HBM-bound kernels: layer norm (+GELU), gated rel-pos multiplier, weighted neighbour
+// gather, reflect padding, complex magnitude, harmonic-amplitude extraction.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// one wave per row; row kept in registers (dim <= 2048), two-pass mean / variance
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long rows, int dim, int ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int gelu, float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * (long)ldx;
+    float* orow = out + row * (long)ldo;
+    constexpr int MAXV = 8;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < dim) { v[i] = *(const f32x4*)(xr + c); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < dim) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float var = wave_sum(q) / (float)dim;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < dim) {
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (v[i][e] - mean) * rstd * g[e] + b[e];
+                y[e] = gelu ? gelu_erf(t) : t;
+            }
+            *(f32x4*)(orow + c) = y;
+        }
+    }
+}
+
+// one wave per row; lane l covers channels 16l..16l+15 (a quarter of a 64-wide head)
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ xn, long rows, int heads, int ldx,
+                                                  const float* __restrict__ w2, const float* __restrict__ b2,
+                                                  const float* __restrict__ grep_a, float* __restrict__ gate) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int h = lane >> 2, part = lane & 3;
+    float sa = 0.f, sb = 0.f;
+    if (h < heads) {
+        const float* xr = xn + row * (long)ldx + lane * 16;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+            const f32x4 xv = *(const f32x4*)(xr + e);
+            const f32x4 wa = *(const f32x4*)(w2 + part * 16 + e), wb = *(const f32x4*)(w2 + 64 + part * 16 + e);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { sa += xv[t] * wa[t]; sb += xv[t] * wb[t]; }
+        }
+    }
+    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
+    sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
+    if (h < heads && part == 0) {
+        const float ga = 1.0f / (1.0f + expf(-(sa + b2[0])));
+        const float gb = 1.0f / (1.0f + expf(-(sb + b2[1])));
+        gate[row * heads + h] = ga * (gb * grep_a[h] - 1.0f) + 2.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void weighted_gather_kernel(const long* __restrict__ idx, const float* __restrict__ w,
+                                                             long nq, int k, const float* __restrict__ pool, int dim,
+                                                             int ld, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const long row = blockIdx.x;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const float wj = w ? w[row * k + j] : 1.0f / (float)k;
+            const float t = pool[idx[row * k + j] * (long)ld + c] * wj;
+            acc = j == 0 ? t : acc + t;
+        }
+        out[row * (long)dim + c] = acc;
+    }
+}
+
+__global__ void reflect_pad_kernel(const float* __restrict__ x, long n, int pad, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n + 2 * (long)pad) return;
+    long j = i - pad;
+    if (j < 0) j = -j;
+    if (j >= n) j = 2 * (n - 1) - j;
+    out[i] = x[j];
+}
+
+__global__ void complex_mag_kernel(const float* __restrict__ reim, long rows, int bins, int ld, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * bins) return;
+    const long r = i / bins; const int b = (int)(i - r * bins);
+    out[i] = hypotf(reim[r * ld + b], reim[r * ld + bins + b]);
+}
+
+// ddsp_prematch_dataset.py:391-404
+__global__ void harmonic_amps_kernel(const float* __restrict__ spec, const float* __restrict__ f0, long T, int bins,
+                                     int n_harm, float* __restrict__ harm) {
+#pragma clang fp contract(off)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * n_harm) return;
+    const long t = i / n_harm; const int k = (int)(i - t * n_harm) + 1;
+    const float f = f0[t];
+    const float* s = spec + t * bins;
+    float v;
+    if (f == 0.f) {
+        if (k == 1) { v = s[0]; for (int b = 1; b < bins; ++b) v = fmaxf(v, s[b]); }
+        else v = 0.f;
+    } else {
+        const int nb = bins * 8;
+        float pos = ((f * (float)k) * 2.0f) * (float)nb / 16000.0f;       // same operation order as the reference
+        pos = fminf(pos, (float)nb);
+        const int gi = (int)rintf(pos);                                    // torch.round: half to even
+        if (gi >= nb) v = 0.f;                                             // the zero pad bin
+        else {
+            // F.interpolate(scale_factor=8, mode='linear', align_corners=False): src = (dst + .5)/8 - .5, clamped at 0
+            float src = ((float)gi + 0.5f) * 0.125f - 0.5f;
+            if (src < 0.f) src = 0.f;
+            const int i0 = (int)src;
+            const int i1 = i0 + (i0 < bins - 1 ? 1 : 0);
+            const float l1 = src - (float)i0, l0 = 1.0f - l1;
+            v = l0 * s[i0] + l1 * s[i1];
+        }
+    }
+    harm[i] = 0.0108f * v;
+}
+
+}  // namespace
+
+extern "C" int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32_t ldx, const float* gamma,
+                                const float* beta, int32_t gelu, float* out, int32_t ldo, void* stream) {
+    KN_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
+    KN_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "layernorm: dim must be a multiple of 4 and <= 2048");
+    KN_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= dim && ldo >= dim, "layernorm: bad row strides");
+    KN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
+               ((uintptr_t)beta & 15) == 0, "layernorm: pointers must be 16-byte aligned");
+    if (rows <= 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, (long)rows, dim, ldx, gamma, beta, gelu, out, ldo);
+    return knnsvc_check_launch("layernorm");
+}
+
+extern "C" int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head_dim, int32_t ldx,
+                                 const float* w2, const float* b2, const float* grep_a, float* gate, void* stream) {
+    KN_REQUIRE(xn && w2 && b2 && grep_a && gate, "wavlm_gate: null pointer");
+    KN_REQUIRE(head_dim == 64 && heads >= 1 && heads <= 16, "wavlm_gate: head_dim must be 64, heads <= 16");
+    KN_REQUIRE(ldx % 4 == 0 && ldx >= heads * 64 && ((uintptr_t)xn & 15) == 0 && ((uintptr_t)w2 & 15) == 0,
+               "wavlm_gate: alignment");
+    if (rows <= 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       xn, (long)rows, heads, ldx, w2, b2, grep_a, gate);
+    return knnsvc_check_launch("wavlm_gate");
+}
+
+extern "C" int knnsvc_weighted_gather(const int64_t* idx, const float* w, int64_t nq, int32_t k, const float* pool,
+                                      int32_t dim, int32_t ld, int32_t mean_mode, float* out, void* stream) {
+    (void)mean_mode;   // mean of k == sum of x * (1/k) bit for bit when k is a power of two (k = 4 on the path)
+    KN_REQUIRE(idx && pool && out && k > 0 && dim > 0 && ld >= dim, "weighted_gather: bad arguments");
+    KN_REQUIRE(w || (k & (k - 1)) == 0, "weighted_gather: uniform weights need a power-of-two k");
+    if (nq <= 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(weighted_gather_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)idx, w, (long)nq, k, pool, dim, ld, out);
+    return knnsvc_check_launch("weighted_gather");
+}
+
+extern "C" int knnsvc_reflect_pad(const float* x, int64_t n, int32_t pad, float* out, void* stream) {
+    KN_REQUIRE(x && out && n > pad && pad >= 0, "reflect_pad: needs n > pad >= 0");
+    const long tot = n + 2 * (long)pad;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, (long)n, pad, out);
+    return knnsvc_check_launch("reflect_pad");
+}
+
+extern "C" int knnsvc_complex_mag(const float* reim, int64_t rows, int32_t bins, int32_t ld, float* out, void* stream) {
+    KN_REQUIRE(reim && out && bins > 0 && ld >= 2 * bins, "complex_mag: bad arguments");
+    if (rows <= 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(complex_mag_kernel, dim3((unsigned)cdiv64(rows * bins, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reim, (long)rows, bins, ld, out);
+    return knnsvc_check_launch("complex_mag");
+}
+
+extern "C" int knnsvc_harmonic_amps(const float* spec, const float* f0, int64_t T, int32_t bins, int32_t n_harm,
+                                    float* harm, void* stream) {
+    KN_REQUIRE(spec && f0 && harm && bins > 0 && n_harm > 0, "harmonic_amps: bad arguments");
+    if (T <= 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(harmonic_amps_kernel, dim3((unsigned)cdiv64(T * n_harm, 256)), dim3(256), 0,
+                       (hipStream_t)stream, spec, f0, (long)T, bins, n_harm, harm);
+    return knnsvc_check_launch("harmonic_amps");
+}

@@ -1,0 +1,298 @@
+// Cosine-distance kNN: fp32-MFMA q.p^T tile GEMM fused with the reference's distance
+// epilogue and a wavefront bitonic top-k.  Reference: lib_ongaku_test.py:148-175
+// (fast_cosine_dist), ddsp_prematch_dataset.py:1195-1210 (20-row chunks + topk(32)).
+//
+// Grid: x = 128-row query tile, y = pool split.  A block walks its pool slice in tiles of
+// 128 rows; after each tile's K loop the 128x128 distances go to LDS and every wave scans
+// its 32 query rows against the row's current 32nd-best key.  Survivors are merged into the
+// row's sorted list (LDS) by a 64-lane bitonic sort.  Per-split lists are merged by a second
+// small kernel.  Keys are (order-preserving bits of the f32 distance) << 32 | pool index, so
+// ties resolve to the lower pool index on every device count.
+#include "gemm_core.h"
+
+namespace {
+
+using G = GemmTile<128, 128, 2, 2, 2, 2>;
+constexpr int KMAX = 32;
+constexpr unsigned long long KEY_INF = 0xFFFFFFFFFFFFFFFFull;
+
+__device__ __forceinline__ unsigned sortable(float d) {
+    unsigned u = __float_as_uint(d);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unsortable(unsigned s) {
+    unsigned u = (s & 0x80000000u) ? (s & 0x7FFFFFFFu) : ~s;
+    return __uint_as_float(u);
+}
+
+// ascending bitonic sort of one u64 per lane across the 64-lane wave
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long o = __shfl_xor(v, j, 64);
+            const bool up = ((lane & k) == 0);          // ascending block
+            const bool lower = ((lane & j) == 0);
+            const bool take_min = (up == lower);
+            const unsigned long long mn = v < o ? v : o, mx = v < o ? o : v;
+            v = take_min ? mn : mx;
+        }
+    }
+    return v;
+}
+
+// the reference's operation sequence on top of dot = sum_k q_k p_k :
+//   cdist (mm route) : r = -2*dot + |q|^2 + |p|^2 ; cd = sqrt(max(r, 1e-30))
+//   fast_cosine_dist : 1 - (((-cd*cd + qn*qn) + pn*pn) / 2) / (qn*pn)
+__device__ __forceinline__ float ref_distance(float dot, float qsq, float psq, float qn, float pn) {
+#pragma clang fp contract(off)      // every product below is rounded on its own, as in the reference
+    float r = (-2.0f * dot + qsq) + psq;
+    float cd = sqrtf(fmaxf(r, 1e-30f));
+    float dp = ((-(cd * cd)) + qn * qn) + pn * pn;
+    dp = dp / 2.0f;
+    return 1.0f - dp / (qn * pn);
+}
+
+struct RowLoader {      // rows of a [rows][dim] row-major matrix, 16-byte vectors
+    const float* base; long rows; int dim; long r0;
+    __device__ __forceinline__ f32x4 operator()(int kt, int j) const {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const long r = r0 + (threadIdx.x >> 3) + 32 * j;
+        const int k = kt * 32 + (threadIdx.x & 7) * 4;
+        if (r < rows && k < dim) v = *(const f32x4*)(base + r * dim + k);
+        return v;
+    }
+};
+
+constexpr int LDD = 128;                                  // distance tile pitch
+constexpr int LDS_STAGE = G::LDS_FLOATS;                  // 18432 floats (>= 128*128)
+constexpr int KNN_LDS_BYTES = LDS_STAGE * 4 + 128 * KMAX * 8 /*lists*/ + 4 * 128 * 8 /*scratch*/ + 128 * 4 * 2;
+
+__global__ __launch_bounds__(256) void knn_tile_kernel(
+    const float* __restrict__ q, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
+    const float* __restrict__ pool, const float* __restrict__ pn, const float* __restrict__ psq, long np,
+    int dim, int k, long rows_per_split, unsigned long long* __restrict__ part, int* nan_flag) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dist = lds;                                                       // [128][LDD] (aliases staging)
+    unsigned long long* lists = (unsigned long long*)(lds + LDS_STAGE);      // [128][32]
+    unsigned long long* scratch = lists + 128 * KMAX;                        // [4 waves][128]
+    float* s_qn = (float*)(scratch + 4 * 128);
+    float* s_qsq = s_qn + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long q0 = (long)blockIdx.x * 128;
+    const long p_begin = (long)blockIdx.y * rows_per_split;
+    const long p_end = p_begin + rows_per_split < np ? p_begin + rows_per_split : np;
+
+    for (int i = tid; i < 128 * KMAX; i += 256) lists[i] = KEY_INF;
+    if (tid < 128) {
+        const long r = q0 + tid;
+        s_qn[tid] = r < nq ? qn[r] : 1.f;
+        s_qsq[tid] = r < nq ? qsq[r] : 0.f;
+    }
+    __syncthreads();
+
+    const int nk = (dim + 31) / 32;
+    bool saw_nan = false;
+    for (long p0 = p_begin; p0 < p_end; p0 += 128) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        RowLoader al{q, nq, dim, q0};
+        RowLoader bl{pool, p_end, dim, p0};
+        G::mainloop(lds, nk, al, bl, acc);            // ends with __syncthreads(): staging LDS is free
+
+        // distances -> LDS tile [query][pool]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = G::acc_col(wave, lane, j);
+            const long p = p0 + c;
+            const bool pv = p < p_end;
+            const float v_pn = pv ? pn[p] : 1.f, v_psq = pv ? psq[p] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = G::acc_row(wave, lane, i, r);
+                    float d = ref_distance(acc[i][j][r], s_qsq[row], v_psq, s_qn[row], v_pn);
+                    if (pv && (q0 + row) < nq && d != d) saw_nan = true;
+                    dist[row * LDD + c] = pv ? d : __builtin_inff();
+                }
+        }
+        __syncthreads();
+
+        // selection: wave w owns query rows 32w .. 32w+31
+        unsigned long long* my_scratch = scratch + wave * 128;
+        for (int rr = 0; rr < 32; ++rr) {
+            const int row = wave * 32 + rr;
+            if (q0 + row >= nq) break;
+            unsigned long long* lst = lists + row * KMAX;
+            unsigned long long thr = lst[k - 1];
+            const float d0 = dist[row * LDD + lane], d1 = dist[row * LDD + 64 + lane];
+            // NaN / +inf never enter: their sortable bits are >= those of +inf
+            unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)(p0 + lane);
+            unsigned long long k1 = ((unsigned long long)sortable(d1) << 32) | (unsigned)(p0 + 64 + lane);
+            const bool f0 = (d0 < __builtin_inff()) && k0 < thr;
+            const bool f1 = (d1 < __builtin_inff()) && k1 < thr;
+            const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+            if ((b0 | b1) == 0ull) continue;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int c0 = __popcll(b0), total = c0 + __popcll(b1);
+            if (f0) my_scratch[__popcll(b0 & lt)] = k0;
+            if (f1) my_scratch[c0 + __popcll(b1 & lt)] = k1;
+            __builtin_amdgcn_wave_barrier();
+            for (int base = 0; base < total; base += 32) {
+                unsigned long long v;
+                if (lane < 32) v = lane < k ? lst[lane] : KEY_INF;
+                else v = (base + lane - 32) < total ? my_scratch[base + lane - 32] : KEY_INF;
+                v = wave_sort64(v, lane);
+                if (lane < k) lst[lane] = v;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();      // dist tile is about to be overwritten by the next tile's staging
+    }
+    if (saw_nan) atomicOr(nan_flag, 1);
+
+    // per-split lists -> workspace  part[split][q][k]
+    for (int i = tid; i < 128 * k; i += 256) {
+        const int row = i / k, e = i - row * k;
+        if (q0 + row < nq) part[((long)blockIdx.y * nq + q0 + row) * k + e] = lists[row * KMAX + e];
+    }
+}
+
+// one wave per query row: fold `parts` sorted key lists into one
+__global__ __launch_bounds__(256) void knn_merge_keys_kernel(const unsigned long long* __restrict__ part,
+                                                            int parts, long nq, int k, long idx_offset,
+                                                            long* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    unsigned long long best = lane < k ? part[row * k + lane] : KEY_INF;
+    for (int s = 1; s < parts; ++s) {
+        unsigned long long v = best;
+        if (lane >= 32) v = (lane - 32) < k ? part[((long)s * nq + row) * k + lane - 32] : KEY_INF;
+        else if (lane >= k) v = KEY_INF;
+        best = wave_sort64(v, lane);
+    }
+    if (lane < k) {
+        out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull) + idx_offset;
+        out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
+    }
+}
+
+// merge of (dist, global idx) lists coming from other devices
+__global__ __launch_bounds__(256) void knn_merge_pairs_kernel(const float* __restrict__ pd, const long* __restrict__ pi,
+                                                             int parts, long nq, int k,
+                                                             long* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    auto load = [&](int s, int e) -> unsigned long long {
+        const long o = ((long)s * nq + row) * k + e;
+        const float d = pd[o];
+        if (!(d < __builtin_inff())) return KEY_INF;
+        return ((unsigned long long)sortable(d) << 32) | (unsigned)pi[o];
+    };
+    unsigned long long best = lane < k ? load(0, lane) : KEY_INF;
+    best = wave_sort64(best, lane);
+    for (int s = 1; s < parts; ++s) {
+        unsigned long long v = best;
+        if (lane >= 32) v = (lane - 32) < k ? load(s, lane - 32) : KEY_INF;
+        else if (lane >= k) v = KEY_INF;
+        best = wave_sort64(v, lane);
+    }
+    if (lane < k) {
+        out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull);
+        out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
+    }
+}
+
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ x, long rows, int dim, int ldx,
+                                                       float* __restrict__ norm, float* __restrict__ sq) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * (long)ldx;
+    double s = 0.0;
+    for (int c = lane; c < dim; c += 64) { const double v = xr[c]; s += v * v; }
+    s = wave_sum_d(s);
+    if (lane == 0) {
+        if (sq) sq[row] = (float)s;
+        if (norm) norm[row] = (float)sqrt(s);
+    }
+}
+
+int split_count(long nq, long np) {
+    const long qtiles = cdiv64(nq, 128), ptiles = cdiv64(np, 128);
+    long s = cdiv64(768, qtiles);           // aim for ~3 waves of blocks over 256 CUs
+    if (s > ptiles) s = ptiles;
+    if (s < 1) s = 1;
+    if (s > 4096) s = 4096;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, float* norm, float* sq,
+                                void* stream) {
+    KN_REQUIRE(x && rows >= 0 && dim > 0 && ldx >= dim, "row_norms: bad arguments");
+    if (rows == 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, (long)rows, dim, ldx, norm, sq);
+    return knnsvc_check_launch("row_norms");
+}
+
+extern "C" size_t knnsvc_knn_workspace_bytes(int64_t nq, int64_t np, int32_t k) {
+    if (nq <= 0 || np <= 0 || k <= 0) return 0;
+    return (size_t)split_count(nq, np) * (size_t)nq * (size_t)k * 8;
+}
+
+extern "C" int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int64_t nq,
+                               const float* pool, const float* p_norm, const float* p_sq, int64_t np,
+                               int32_t dim, int32_t k, int64_t idx_offset, int64_t* out_idx, float* out_dist,
+                               void* workspace, size_t workspace_bytes, int32_t* nan_flag, void* stream) {
+    KN_REQUIRE(q && q_norm && q_sq && pool && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_topk: null pointer");
+    KN_REQUIRE(nq > 0 && np > 0, "knn_topk: empty query or pool");
+    KN_REQUIRE(k >= 1 && k <= KMAX, "knn_topk: k must be in 1..32");
+    KN_REQUIRE(np >= k, "knn_topk: pool smaller than k (the reference's topk would raise)");
+    KN_REQUIRE(dim > 0 && dim % 4 == 0, "knn_topk: dim must be a multiple of 4");
+    KN_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)pool & 15) == 0, "knn_topk: q/pool must be 16-byte aligned");
+    KN_REQUIRE(np < (1ll << 32), "knn_topk: pool rows must fit 32 bits");
+    const int S = split_count(nq, np);
+    const size_t need = (size_t)S * nq * k * 8;
+    if (workspace_bytes < need || !workspace)
+        return knnsvc_fail(KNNSVC_EWORKSPACE, "knn_topk: workspace %zu < %zu bytes", workspace_bytes, need);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)knn_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                KNN_LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "knn_topk: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    const long ptiles = cdiv64(np, 128);
+    const long rows_per_split = cdiv64(ptiles, S) * 128;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv64(nq, 128), (unsigned)S);
+    hipLaunchKernelGGL(knn_tile_kernel, grid, dim3(256), KNN_LDS_BYTES, st, q, q_norm, q_sq, (long)nq, pool, p_norm,
+                       p_sq, (long)np, dim, k, rows_per_split, (unsigned long long*)workspace, nan_flag);
+    int rc = knnsvc_check_launch("knn_tile");
+    if (rc) return rc;
+    hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, st,
+                       (const unsigned long long*)workspace, S, (long)nq, k, (long)idx_offset, (long*)out_idx, out_dist);
+    return knnsvc_check_launch("knn_merge_keys");
+}
+
+extern "C" int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx, int32_t parts, int64_t nq, int32_t k,
+                                int64_t* out_idx, float* out_dist, void* stream) {
+    KN_REQUIRE(part_dist && part_idx && out_idx && out_dist, "knn_merge: null pointer");
+    KN_REQUIRE(parts >= 1 && nq > 0 && k >= 1 && k <= KMAX, "knn_merge: bad sizes");
+    hipLaunchKernelGGL(knn_merge_pairs_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream,
+                       part_dist, (const long*)part_idx, parts, (long)nq, k, (long*)out_idx, out_dist);
+    return knnsvc_check_launch("knn_merge_pairs");
+}

@@ -1,0 +1,259 @@
+// Neighbour post-processing kernels: median log-f0 (radix select), f0 shift, stable f0
+// re-rank, and the frame-sequential concatenation-cost re-selection.
+// Reference: ddsp_prematch_dataset.py:1224-1233, 954-1016; lib_ongaku_test.py:270-369.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned f2s(float d) {
+    unsigned u = __float_as_uint(d);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float s2f(unsigned s) {
+    return __uint_as_float((s & 0x80000000u) ? (s & 0x7FFFFFFFu) : ~s);
+}
+
+// lower median (torch.median) of log(f0) over f0 != 0, by 4-pass byte radix select in one block
+__global__ __launch_bounds__(1024) void log_f0_median_kernel(const float* __restrict__ f0, long n,
+                                                            float* __restrict__ result, float* __restrict__ ws) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_rank, s_count;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    unsigned local = 0;
+    for (long i = tid; i < n; i += 1024) {
+        const float f = f0[i];
+        if (f != 0.f) { ws[i] = logf(f); ++local; } else ws[i] = __builtin_nanf("");
+    }
+    atomicAdd(&s_count, local);
+    __syncthreads();
+    const unsigned nv = s_count;
+    if (nv == 0) { if (tid == 0) { result[0] = __builtin_nanf(""); result[1] = 0.f; } return; }
+    if (tid == 0) { s_prefix = 0; s_rank = (nv - 1) / 2; }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (long i = tid; i < n; i += 1024) {
+            const float v = ws[i];
+            if (v == v) {
+                const unsigned s = f2s(v);
+                if ((s & himask) == prefix) atomicAdd(&hist[(s >> shift) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned r = s_rank, b = 0;
+            for (; b < 256; ++b) { if (r < hist[b]) break; r -= hist[b]; }
+            s_rank = r;
+            s_prefix = prefix | (b << shift);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { result[0] = s2f(s_prefix); result[1] = (float)nv; }
+}
+
+__global__ void shift_f0_kernel(const float* __restrict__ f0, long n, const float* __restrict__ qmed,
+                                const float* __restrict__ pmed, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float f = f0[i];
+    out[i] = f != 0.f ? expf((logf(f) + pmed[0]) - qmed[0]) : f;
+}
+
+// half a wave (32 lanes) per query row; rank by counting gives torch.sort(stable=True) order
+__global__ __launch_bounds__(256) void f0_rerank_kernel(const long* __restrict__ nn, long nq, int k,
+                                                       const float* __restrict__ sf0, const float* __restrict__ pf0,
+                                                       long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    const bool act = lane < k;
+    const long id = act ? nn[row * k + lane] : 0;
+    const float key = act ? fabsf(log2f(pf0[id] + 1e-5f) - log2f(sf0[row] + 1e-5f)) : __builtin_inff();
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+        const float kj = __shfl(key, j, 64);
+        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+    }
+    if (act) out[row * k + rank] = id;
+}
+
+// ---------------------------------------------------------------------------------------------
+// knn_with_concat_cost.  One block (4 waves) walks the frames of one sequence.  Candidate rows
+// live in a two-slot LDS ring so that the previous frame's selection is still resident when the
+// concat costs are formed.  Distances follow fast_cosine_dist on torch.cdist's direct route
+// (both sides <= 25 rows): cd = sqrt(sum (x-y)^2); d = 1 - (((-cd^2 + |x|^2) + |y|^2)/2)/(|x||y|).
+// ---------------------------------------------------------------------------------------------
+constexpr int KC = 4;        // neighbours kept per frame
+constexpr int NC = 2 * KC;   // candidates per frame
+
+__device__ __forceinline__ float cos_from_cd(float ss, float xn, float yn) {
+#pragma clang fp contract(off)
+    const float cd = sqrtf(ss);
+    float dp = ((-(cd * cd)) + xn * xn) + yn * yn;
+    dp = dp / 2.0f;
+    return 1.0f - dp / (xn * yn);
+}
+
+__device__ __forceinline__ float sqdiff(const float* __restrict__ x, const float* __restrict__ y, int dim, int lane) {
+    float s = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+        const f32x4 a = *(const f32x4*)(x + c), b = *(const f32x4*)(y + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = a[e] - b[e]; s += d * d; }
+    }
+    return wave_sum(s);
+}
+
+__global__ __launch_bounds__(256) void concat_reselect_kernel(
+    const long* __restrict__ idx_in, const float* __restrict__ q, const float* __restrict__ qn, long nq,
+    const float* __restrict__ pool, const float* __restrict__ pn, long np, int dim,
+    const float* __restrict__ sf0, const float* __restrict__ pf0, int use_f0, float concat_weight,
+    long* __restrict__ idx_out) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ring = sm;                               // [2][NC][dim]
+    float* qrow = ring + 2 * NC * dim;              // [2][dim]
+    __shared__ float s_match[NC], s_cc[KC][NC], s_base;
+    __shared__ long s_cand[2][NC];
+    __shared__ int s_prev_slot[KC];                 // slots (in the previous ring half) of the kept rows
+    __shared__ long s_prev_idx[KC];
+    __shared__ float s_w;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // frame 0 keeps its neighbours
+    if (tid < KC) {
+        const long id = idx_in[tid];
+        idx_out[tid] = id;
+        s_prev_idx[tid] = id; s_prev_slot[tid] = tid; s_cand[0][tid] = id;
+    }
+    if (tid == 0) s_w = concat_weight;
+    __syncthreads();
+    for (int r = 0; r < KC; ++r)
+        for (int c = tid * 4; c < dim; c += 1024) *(f32x4*)&ring[(0 * NC + r) * dim + c] = *(const f32x4*)(pool + s_cand[0][r] * (long)dim + c);
+    for (int c = tid * 4; c < dim; c += 1024) *(f32x4*)&qrow[c] = *(const f32x4*)(q + c);
+    __syncthreads();
+
+    for (long i = 1; i < nq; ++i) {
+        const int cur = (int)(i & 1), prv = cur ^ 1;
+        if (tid < NC) {
+            long id;
+            if (tid < KC) id = idx_in[i * KC + tid];
+            else { id = s_prev_idx[tid - KC] + 1; if (id >= np) id = np - 1; }
+            s_cand[cur][tid] = id;
+        }
+        __syncthreads();
+        // stage the 8 candidate rows and q[i]
+        for (int r = 0; r < NC; ++r) {
+            const float* src = pool + s_cand[cur][r] * (long)dim;
+            for (int c = tid * 4; c < dim; c += 1024) *(f32x4*)&ring[(cur * NC + r) * dim + c] = *(const f32x4*)(src + c);
+        }
+        for (int c = tid * 4; c < dim; c += 1024) *(f32x4*)&qrow[cur * dim + c] = *(const f32x4*)(q + i * (long)dim + c);
+        __syncthreads();
+        // 8 match + 32 concat + 1 baseline squared distances, spread over the 4 waves
+        for (int job = wave; job < NC + KC * NC + 1; job += 4) {
+            if (job < NC) {
+                const float ss = sqdiff(&qrow[cur * dim], &ring[(cur * NC + job) * dim], dim, lane);
+                if (lane == 0) s_match[job] = cos_from_cd(ss, qn[i], pn[s_cand[cur][job]]);
+            } else if (job < NC + KC * NC) {
+                const int a = (job - NC) / NC, b = (job - NC) % NC;
+                const float ss = sqdiff(&ring[(prv * NC + s_prev_slot[a]) * dim], &ring[(cur * NC + b) * dim], dim, lane);
+                if (lane == 0) s_cc[a][b] = cos_from_cd(ss, pn[s_prev_idx[a]], pn[s_cand[cur][b]]);
+            } else {
+                const float ss = sqdiff(&qrow[prv * dim], &qrow[cur * dim], dim, lane);
+                if (lane == 0) s_base = cos_from_cd(ss, qn[i - 1], qn[i]) * 2.0f;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float total = __builtin_inff();
+            const float base = s_base;
+            float w = s_w;
+            if (use_f0 && !(base < 0.08f)) w = 0.f;            // sticky: stays 0 for every later frame
+            if (lane < NC) {
+                float c4[KC];
+#pragma unroll
+                for (int a = 0; a < KC; ++a) {
+                    float c = s_cc[a][lane];
+                    if (use_f0) { if (base < 0.08f && c < 5.0f * base) c = 0.f; }
+                    else if (c > base) c = 1.5f * c - base;
+                    c4[a] = c;
+                }
+                // lower median of four = second smallest
+                float lo01 = fminf(c4[0], c4[1]), hi01 = fmaxf(c4[0], c4[1]);
+                float lo23 = fminf(c4[2], c4[3]), hi23 = fmaxf(c4[2], c4[3]);
+                const float med = fminf(fmaxf(lo01, lo23), fminf(hi01, hi23));
+                total = w * med + s_match[lane];
+                if (use_f0) {
+                    const float lp = log2f(pf0[s_cand[cur][lane]] + 1e-5f), lq = log2f(sf0[i] + 1e-5f);
+                    total = total + fabsf(lp - lq);
+                }
+            }
+            int rank = 0;
+            for (int j = 0; j < NC; ++j) {
+                const float tj = __shfl(total, j, 64);
+                rank += (tj < total || (tj == total && j < lane)) ? 1 : 0;
+            }
+            if (lane < NC && rank < KC) {
+                const long id = s_cand[cur][lane];
+                s_prev_idx[rank] = id; s_prev_slot[rank] = lane;
+                idx_out[i * KC + rank] = id;
+            }
+            if (lane == 0) s_w = w;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int knnsvc_log_f0_median(const float* f0, int64_t n, float* result, float* workspace, void* stream) {
+    KN_REQUIRE(f0 && result && workspace && n > 0, "log_f0_median: bad arguments");
+    hipLaunchKernelGGL(log_f0_median_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, f0, (long)n, result, workspace);
+    return knnsvc_check_launch("log_f0_median");
+}
+
+extern "C" int knnsvc_shift_f0(const float* f0, int64_t n, const float* query_median, const float* pool_median,
+                               float* shifted, void* stream) {
+    KN_REQUIRE(f0 && query_median && pool_median && shifted && n > 0, "shift_f0: bad arguments");
+    hipLaunchKernelGGL(shift_f0_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, f0, (long)n,
+                       query_median, pool_median, shifted);
+    return knnsvc_check_launch("shift_f0");
+}
+
+extern "C" int knnsvc_f0_rerank(const int64_t* nn_idx, int64_t nq, int32_t k, const float* shifted_f0,
+                                const float* pool_f0, int64_t* out_idx, void* stream) {
+    KN_REQUIRE(nn_idx && shifted_f0 && pool_f0 && out_idx && nq > 0, "f0_rerank: bad arguments");
+    KN_REQUIRE(k >= 1 && k <= 64, "f0_rerank: k must be in 1..64");
+    hipLaunchKernelGGL(f0_rerank_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)nn_idx, (long)nq, k, shifted_f0, pool_f0, (long*)out_idx);
+    return knnsvc_check_launch("f0_rerank");
+}
+
+extern "C" int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, const float* q_norm, int64_t nq,
+                                      const float* pool, const float* p_norm, int64_t np, int32_t dim,
+                                      const float* shifted_f0, const float* pool_f0, int32_t use_f0,
+                                      float concat_weight, int64_t* idx_out, void* stream) {
+    KN_REQUIRE(idx_in && q && q_norm && pool && p_norm && idx_out, "concat_reselect: null pointer");
+    KN_REQUIRE(nq > 0 && np > 0 && dim > 0 && dim % 4 == 0, "concat_reselect: bad sizes");
+    KN_REQUIRE(!use_f0 || (shifted_f0 && pool_f0), "concat_reselect: f0 variant needs both f0 arrays");
+    KN_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)pool & 15) == 0, "concat_reselect: 16-byte alignment");
+    const size_t lds = (size_t)(2 * NC + 2) * dim * 4;
+    KN_REQUIRE(lds <= 150 * 1024, "concat_reselect: feature dim too large for LDS");
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute((const void*)concat_reselect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "concat_reselect: hipFuncSetAttribute failed");
+        attr = lds;
+    }
+    hipLaunchKernelGGL(concat_reselect_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, (const long*)idx_in, q,
+                       q_norm, (long)nq, pool, p_norm, (long)np, dim, shifted_f0, pool_f0, use_f0, concat_weight,
+                       (long*)idx_out);
+    return knnsvc_check_launch("concat_reselect");
+}

@@ -1,0 +1,231 @@
+// Concatenation-smoothness weight optimisation, fully on the device.
+// Reference: ddsp_prematch_dataset.py:574-680 (compute_wavlm_weight), :807-924
+// (compute_extended_weight), :426-428 (softmax weights), :449-461 (the two MSE costs).
+//
+// The reference runs autograd + torch.optim.Adam(amsgrad) with a host sync per iteration and
+// re-reads 3 x [N,4,D] gathered features every step.  The loss is a quadratic form in the
+// softmax weights, so this implementation
+//   1. reduces the features once to two 8x8 Gram matrices per adjacent frame pair
+//      (gram_kernel; vectors are centred on their mean first — the weights of each frame sum
+//      to one, so centring changes neither loss nor softmax gradient but removes cancellation);
+//   2. runs the whole Adam loop — loss, analytic gradient, amsgrad update, best-iterate
+//      tracking and the reference's three stopping rules — inside ONE persistent workgroup
+//      (adam_kernel), O(N*128) flops per iteration and no host round trips.
+#include "common.h"
+
+namespace {
+
+constexpr int KW = 4;           // neighbours per frame
+constexpr int GE = 36;          // unique entries of a symmetric 8x8
+
+__device__ __forceinline__ int tri(int i, int j) { return i <= j ? i * 8 - i * (i - 1) / 2 + (j - i) : j * 8 - j * (j - 1) / 2 + (i - j); }
+
+// block per frame pair t: rows of term a: F[idx[t+1,k]-1] (k<4), F[idx[t,k]] ; term b: F[idx[t+1,k]], F[idx[t,k]+1]
+__global__ __launch_bounds__(256) void gram_kernel(const long* __restrict__ idx, long nq, const float* __restrict__ pool,
+                                                  long np, int dim, int ld, float* __restrict__ gram) {
+    extern __shared__ float sm[];           // [8][dim] centred vectors of the current term
+    const long t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int term = 0; term < 2; ++term) {
+        __syncthreads();
+        for (int c = tid; c < dim; c += 256) {
+            float v[8], mean = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                long id;
+                if (r < 4) id = idx[(t + 1) * KW + r] + (term == 0 ? -1 : 0);
+                else id = idx[t * KW + (r - 4)] + (term == 0 ? 0 : 1);
+                id = id < 0 ? 0 : (id > np - 1 ? np - 1 : id);
+                v[r] = pool[id * (long)ld + c];
+                mean += v[r];
+            }
+            mean *= 0.125f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sm[r * dim + c] = v[r] - mean;
+        }
+        __syncthreads();
+        for (int e = wave; e < GE; e += 4) {
+            int i = 0, rem = e;                       // unpack e -> (i <= j)
+            while (rem >= 8 - i) { rem -= 8 - i; ++i; }
+            const int j = i + rem;
+            double s = 0.0;
+            for (int c = lane; c < dim; c += 64) s += (double)sm[i * dim + c] * (double)sm[j * dim + c];
+            s = wave_sum_d(s);
+            if (lane == 0) gram[((long)(term * GE + e)) * nq + t] = (float)s;
+        }
+    }
+}
+
+struct LoopState { double min_loss, conv_min; int since; };
+
+__global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scale, int max_iter,
+                                                   const float* __restrict__ gram, float* __restrict__ state,
+                                                   float* __restrict__ xch_global, int use_lds,
+                                                   float* __restrict__ out_w, int* __restrict__ out_iters) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double red[16];
+    __shared__ float s_loss;
+    float* xw = use_lds ? sm : xch_global;                 // [nq][4] softmax weights
+    float* xg = xw + nq * KW;                              // [nq][4] gradient w.r.t. w from the pair (t-1, t)
+    f32x4* theta = (f32x4*)state;
+    f32x4* m1 = theta + nq; f32x4* v2 = m1 + nq; f32x4* vmax = v2 + nq; f32x4* best = vmax + nq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double S = (double)scale / ((double)dim * (double)(nq - 1));
+    const float twoS = (float)(2.0 * S);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long t = tid; t < nq; t += 1024) { theta[t] = zero; m1[t] = zero; v2[t] = zero; vmax[t] = zero; best[t] = zero; }
+    __syncthreads();
+
+    double min_loss = 20000.0, conv_min = 20000.0;
+    int since = 0, it = 0;
+    const float b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
+    double pb1 = 1.0, pb2 = 1.0;
+    for (it = 0; it < max_iter; ++it) {
+        // ---- phase 1: softmax weights ---------------------------------------------------------
+        for (long t = tid; t < nq; t += 1024) {
+            const f32x4 th = theta[t];
+            const float mx = fmaxf(fmaxf(th[0], th[1]), fmaxf(th[2], th[3]));
+            f32x4 e = {expf(th[0] - mx), expf(th[1] - mx), expf(th[2] - mx), expf(th[3] - mx)};
+            const float den = (e[0] + e[1]) + (e[2] + e[3]);
+            *(f32x4*)&xw[t * KW] = e / den;
+        }
+        __syncthreads();
+        // ---- phase 2: per pair quadratic forms, gradient w.r.t. the weights ---------------------
+        double lsum = 0.0;
+        for (long t = tid; t < nq - 1; t += 1024) {
+            const f32x4 w1 = *(const f32x4*)&xw[(t + 1) * KW], w0 = *(const f32x4*)&xw[t * KW];
+            const float c[8] = {w1[0], w1[1], w1[2], w1[3], -w0[0], -w0[1], -w0[2], -w0[3]};
+            float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int term = 0; term < 2; ++term) {
+                float g[GE];
+#pragma unroll
+                for (int e = 0; e < GE; ++e) g[e] = gram[((long)(term * GE + e)) * nq + t];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += g[tri(i, j)] * c[j];
+                    y[i] += s;
+                }
+            }
+            float qf = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf += c[i] * y[i];
+            lsum += (double)qf;
+            f32x4 gf = {twoS * y[0], twoS * y[1], twoS * y[2], twoS * y[3]};
+            *(f32x4*)&xg[(t + 1) * KW] = gf;                       // d/dw[t+1,:] from pair t
+            // d/dw[t,:] from pair t is kept in the (unused) slot layout of the state pass below
+            f32x4 gs = {-twoS * y[4], -twoS * y[5], -twoS * y[6], -twoS * y[7]};
+            best[nq + t] = gs;                                     // scratch row after `best`
+        }
+        lsum = wave_sum_d(lsum);
+        if (lane == 0) red[wave] = lsum;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < 16; ++i) tot += red[i];
+            s_loss = (float)(S * tot);
+        }
+        __syncthreads();
+        const float loss = s_loss;
+        // ---- phase 3: the reference's loop control (uniform across the block) -------------------
+        if (it % 100 == 1) {
+            if (fabs(min_loss - conv_min) < 1e-5) break;
+            conv_min = min_loss;
+        }
+        const bool improved = loss < (float)min_loss;
+        if (improved) { min_loss = (double)loss; since = 0; } else ++since;
+        if (since >= 1000) break;
+        // ---- phase 4: gradient through softmax + Adam(amsgrad) ----------------------------------
+        pb1 *= 0.9; pb2 *= 0.999;
+        const float step_size = (float)(-(0.1 / (1.0 - pb1)));
+        const float bc2_sqrt = (float)sqrt(1.0 - pb2);
+        for (long t = tid; t < nq; t += 1024) {
+            const f32x4 w = *(const f32x4*)&xw[t * KW];
+            f32x4 g = zero;
+            if (t >= 1) g = *(const f32x4*)&xg[t * KW];
+            if (t < nq - 1) g += best[nq + t];
+            const float dotwg = (w[0] * g[0] + w[1] * g[1]) + (w[2] * g[2] + w[3] * g[3]);
+            f32x4 gt = w * (g - dotwg);
+            f32x4 th = theta[t];
+            if (improved) best[t] = th;
+            f32x4 mm = m1[t], vv = v2[t], vm = vmax[t];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mm[k] = mm[k] + (gt[k] - mm[k]) * omb1;
+                vv[k] = vv[k] * b2 + (omb2 * gt[k]) * gt[k];
+                vm[k] = fmaxf(vm[k], vv[k]);
+                const float denom = sqrtf(vm[k]) / bc2_sqrt + eps;
+                th[k] = th[k] + step_size * (mm[k] / denom);
+            }
+            theta[t] = th; m1[t] = mm; v2[t] = vv; vmax[t] = vm;
+        }
+        __syncthreads();
+    }
+    // softmax(best)
+    __syncthreads();
+    for (long t = tid; t < nq; t += 1024) {
+        const f32x4 th = best[t];
+        const float mx = fmaxf(fmaxf(th[0], th[1]), fmaxf(th[2], th[3]));
+        f32x4 e = {expf(th[0] - mx), expf(th[1] - mx), expf(th[2] - mx), expf(th[3] - mx)};
+        const float den = (e[0] + e[1]) + (e[2] + e[3]);
+        *(f32x4*)&out_w[t * KW] = e / den;
+    }
+    if (tid == 0 && out_iters) out_iters[0] = it;
+}
+
+__global__ void fill_quarter_kernel(float* w, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = 0.25f;
+}
+
+inline size_t ws_floats(long nq) { return (size_t)(2 * GE) * nq + (size_t)6 * 4 * nq + (size_t)2 * 4 * nq; }
+
+}  // namespace
+
+extern "C" size_t knnsvc_smooth_workspace_bytes(int64_t nq) { return nq > 0 ? ws_floats(nq) * 4 + 64 : 0; }
+
+extern "C" int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float* pool, int64_t np, int32_t dim,
+                                     int32_t ld, float scale, int32_t max_iter, float* out_w, int32_t* out_iters,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    KN_REQUIRE(idx && pool && out_w && workspace, "smooth_weights: null pointer");
+    KN_REQUIRE(nq > 0 && np > 0 && dim > 0 && ld >= dim && max_iter > 0, "smooth_weights: bad sizes");
+    KN_REQUIRE(((uintptr_t)out_w & 15) == 0, "smooth_weights: out_w must be 16-byte aligned");
+    if (workspace_bytes < knnsvc_smooth_workspace_bytes(nq))
+        return knnsvc_fail(KNNSVC_EWORKSPACE, "smooth_weights: workspace %zu < %zu bytes", workspace_bytes,
+                           knnsvc_smooth_workspace_bytes(nq));
+    hipStream_t st = (hipStream_t)stream;
+    if (nq < 2) {      // no adjacent pair: the reference's loss is NaN and never improves -> softmax(0)
+        hipLaunchKernelGGL(fill_quarter_kernel, dim3(1), dim3(64), 0, st, out_w, (long)nq * 4);
+        if (out_iters) (void)hipMemsetAsync(out_iters, 0, sizeof(int), st);
+        return knnsvc_check_launch("smooth_weights(fill)");
+    }
+    float* base = (float*)(((uintptr_t)workspace + 63) & ~(uintptr_t)63);
+    float* gram = base;                                 // [72][nq]
+    float* state = gram + (size_t)(2 * GE) * nq;        // theta, m, v, vmax, best, scratch : 6 x [nq] float4
+    float* xch = state + (size_t)6 * 4 * nq;            // [2][nq][4] when LDS is too small
+    const size_t gl = (size_t)8 * dim * 4;
+    KN_REQUIRE(gl <= 150 * 1024, "smooth_weights: feature dim too large for LDS");
+    static size_t gattr = 0, aattr = 0;
+    if (gl > gattr) {
+        if (hipFuncSetAttribute((const void*)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gl) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "smooth_weights: hipFuncSetAttribute failed");
+        gattr = gl;
+    }
+    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nq - 1)), dim3(256), gl, st, (const long*)idx, (long)nq, pool, (long)np,
+                       dim, ld, gram);
+    int rc = knnsvc_check_launch("gram");
+    if (rc) return rc;
+    size_t al = (size_t)nq * 2 * KW * 4;
+    int use_lds = al <= 144 * 1024;
+    if (!use_lds) al = 0;
+    if (al > aattr) {
+        if (hipFuncSetAttribute((const void*)adam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)al) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "smooth_weights: hipFuncSetAttribute failed");
+        aattr = al;
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(1024), al, st, (long)nq, dim, scale, max_iter, (const float*)gram, state,
+                       xch, use_lds, out_w, out_iters);
+    return knnsvc_check_launch("adam");
+}

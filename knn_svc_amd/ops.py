@@ -1,0 +1,256 @@
+"""Thin tensor-level wrappers over the C ABI (include/knnsvc_hip.h).
+
+PyTorch-ROCm is used for device memory and streams only: every function takes
+contiguous fp32 tensors on the GPU, passes raw device pointers plus the current
+HIP stream to ``libknnsvc_hip.so`` and returns tensors.  No op has a torch
+fallback — a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, KnnSvcError, check
+
+ACT_NONE, ACT_GELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need(t, dtype=torch.float32, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise KnnSvcError(f"{name}: expected a GPU tensor (knn_svc_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise KnnSvcError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+# ------------------------------------------------------------------ weight packing (host side, once per load)
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """Conv1d weight [Cout, Cin, k] -> GEMM B operand [Cout, k*Cin] (tap major, channel minor)."""
+    return w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def pack_grouped_conv_weight(w: torch.Tensor, groups: int) -> torch.Tensor:
+    """Grouped Conv1d weight [Cout, Cin/g, k] -> [g, Cout/g, k*Cin/g]."""
+    co, cig, k = w.shape
+    return w.reshape(groups, co // groups, cig, k).permute(0, 1, 3, 2).reshape(groups, co // groups, k * cig).contiguous()
+
+
+def pack_convT_weight(w: torch.Tensor, u: int) -> torch.Tensor:
+    """ConvTranspose1d weight [Cin, Cout, k] (stride u, k % u == 0) -> [u*Cout, (k/u)*Cin] with
+    row p*Cout+co, column r*Cin+c holding w[c, co, p + r*u]: output phase p of input step q sums
+    x[q-r] . w[:, co, p + r*u] over the k/u taps r."""
+    cin, cout, k = w.shape
+    assert k % u == 0, "transposed conv kernel must be a multiple of its stride"
+    r = k // u
+    return w.reshape(cin, cout, r, u).permute(3, 1, 2, 0).reshape(u * cout, r * cin).contiguous()
+
+
+# ------------------------------------------------------------------ implicit-GEMM convolution
+def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None, ldx=None, ldo=None,
+              bias=None, bias_period=0, act=ACT_NONE, act_slope=0.0, a_slope=1.0, resid=None, ldr=None,
+              accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
+              bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
+              convt_u=0, convt_cout=0, convt_pad=0, t_out=0):
+    """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr)."""
+    lib = _lib.load()
+    d = ConvDesc()
+    d.x = x.data_ptr(); d.x_bstride = x_bstride; d.x_gstride = x_gstride
+    d.ldx = ldx if ldx is not None else cin; d.t_in = t_in if t_in is not None else m
+    d.cin = cin; d.taps = taps; d.stride = stride; d.dil = dil; d.pad = pad; d.a_slope = a_slope
+    d.w = w.data_ptr(); d.w_gstride = w_gstride; d.n = n
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.bias_gstride = bias_gstride; d.bias_period = bias_period
+    d.out = out.data_ptr(); d.o_bstride = o_bstride; d.o_gstride = o_gstride
+    d.ldo = ldo if ldo is not None else n; d.m = m
+    d.act = act; d.act_slope = act_slope
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.r_bstride = r_bstride; d.r_gstride = r_gstride; d.ldr = ldr if ldr is not None else (d.ldo if resid is not None else 0)
+    d.accumulate = 1 if accumulate else 0; d.div = div
+    d.batches = batches; d.groups = groups
+    d.convt_u = convt_u; d.convt_cout = convt_cout; d.convt_pad = convt_pad; d.t_out = t_out
+    check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
+    return out
+
+
+def linear(x2d, w, bias=None, act=ACT_NONE, resid=None, out=None):
+    """out[M,N] = act(x2d[M,K] @ w[N,K]^T + bias) (+ resid)."""
+    _need(x2d, name="linear.x"); _need(w, name="linear.w")
+    M, K = x2d.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    return conv_gemm(x2d, w, out, m=M, n=N, cin=K, bias=bias, act=act, resid=resid)
+
+
+# ------------------------------------------------------------------ WavLM pieces
+def layernorm(x2d, gamma, beta, gelu=False, out=None):
+    _need(x2d, name="layernorm.x")
+    rows, dim = x2d.shape
+    if out is None:
+        out = torch.empty_like(x2d)
+    check(_lib.load().knnsvc_layernorm(_p(x2d), rows, dim, x2d.stride(0), _p(gamma), _p(beta), 1 if gelu else 0,
+                                       _p(out), out.stride(0), _stream()), "layernorm")
+    return out
+
+
+def wavlm_gate(xn2d, heads, w2, b2, grep_a):
+    rows = xn2d.shape[0]
+    gate = torch.empty(rows, heads, device=xn2d.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_wavlm_gate(_p(xn2d), rows, heads, 64, xn2d.stride(0), _p(w2), _p(b2), _p(grep_a),
+                                        _p(gate), _stream()), "wavlm_gate")
+    return gate
+
+
+def wavlm_attention(qkv, gate, table, batches, T, heads):
+    out = torch.empty(batches * T, heads * 64, device=qkv.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_wavlm_attention(_p(qkv), _p(gate), _p(table), batches, T, heads, _p(out), _stream()),
+          "wavlm_attention")
+    return out
+
+
+# ------------------------------------------------------------------ kNN
+def row_norms(x2d):
+    """-> (norm [rows], sumsq [rows])"""
+    _need(x2d, name="row_norms.x")
+    rows, dim = x2d.shape
+    norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    sq = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_row_norms(_p(x2d), rows, dim, x2d.stride(0), _p(norm), _p(sq), _stream()), "row_norms")
+    return norm, sq
+
+
+def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True):
+    """Ascending cosine-distance top-k of each q row among pool rows -> (idx int64 [nq,k], dist f32 [nq,k])."""
+    _need(q, name="knn.q"); _need(pool, name="knn.pool")
+    if not (q.is_contiguous() and pool.is_contiguous()):
+        raise KnnSvcError("knn_topk: q and pool must be contiguous")
+    lib = _lib.load()
+    nq, dim = q.shape
+    npool = pool.shape[0]
+    qn, qs = q_stats if q_stats is not None else row_norms(q)
+    pn, ps = p_stats if p_stats is not None else row_norms(pool)
+    ws_bytes = lib.knnsvc_knn_workspace_bytes(nq, npool, k)
+    ws = torch.empty(max(ws_bytes, 8), device=q.device, dtype=torch.uint8)
+    idx = torch.empty(nq, k, device=q.device, dtype=torch.int64)
+    dist = torch.empty(nq, k, device=q.device, dtype=torch.float32)
+    flag = torch.zeros(1, device=q.device, dtype=torch.int32)
+    check(lib.knnsvc_knn_topk(_p(q), _p(qn), _p(qs), nq, _p(pool), _p(pn), _p(ps), npool, dim, k, idx_offset,
+                              _p(idx), _p(dist), _p(ws), ws_bytes, _p(flag), _stream()), "knn_topk")
+    if check_nan and int(flag.item()) != 0:
+        raise KnnSvcError("containing nan")        # the reference prints this and sys.exit()s (lib_ongaku_test.py:166-169)
+    return idx, dist
+
+
+def knn_merge(part_dist, part_idx):
+    """[parts, nq, k] per-shard lists (global indices) -> merged (idx, dist)."""
+    parts, nq, k = part_dist.shape
+    idx = torch.empty(nq, k, device=part_dist.device, dtype=torch.int64)
+    dist = torch.empty(nq, k, device=part_dist.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_knn_merge(_p(part_dist.contiguous()), _p(part_idx.contiguous()), parts, nq, k,
+                                       _p(idx), _p(dist), _stream()), "knn_merge")
+    return idx, dist
+
+
+# ------------------------------------------------------------------ neighbour post-processing
+def log_f0_median(f0):
+    """-> tensor [2] on device: (lower median of log f0 over voiced frames, voiced count)."""
+    _need(f0, name="f0")
+    res = torch.empty(2, device=f0.device, dtype=torch.float32)
+    ws = torch.empty(f0.numel(), device=f0.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_log_f0_median(_p(f0), f0.numel(), _p(res), _p(ws), _stream()), "log_f0_median")
+    return res
+
+
+def shift_f0(f0, qmed, pmed):
+    out = torch.empty_like(f0)
+    check(_lib.load().knnsvc_shift_f0(_p(f0), f0.numel(), _p(qmed), _p(pmed), _p(out), _stream()), "shift_f0")
+    return out
+
+
+def f0_rerank(nn_idx, shifted_f0, pool_f0):
+    _need(nn_idx, torch.int64, "nn_idx")
+    out = torch.empty_like(nn_idx)
+    nq, k = nn_idx.shape
+    check(_lib.load().knnsvc_f0_rerank(_p(nn_idx), nq, k, _p(shifted_f0), _p(pool_f0), _p(out), _stream()), "f0_rerank")
+    return out
+
+
+def concat_reselect(idx4, q, q_norm, pool, p_norm, shifted_f0=None, pool_f0=None, concat_weight=0.2):
+    _need(idx4, torch.int64, "idx4")
+    idx4 = idx4.contiguous()
+    out = torch.empty_like(idx4)
+    use_f0 = shifted_f0 is not None
+    check(_lib.load().knnsvc_concat_reselect(_p(idx4), _p(q), _p(q_norm), q.shape[0], _p(pool), _p(p_norm),
+                                             pool.shape[0], q.shape[1], _p(shifted_f0), _p(pool_f0), 1 if use_f0 else 0,
+                                             float(concat_weight), _p(out), _stream()), "concat_reselect")
+    return out
+
+
+def smooth_weights(idx4, pool, scale, max_iter=100000, return_iters=False):
+    _need(idx4, torch.int64, "idx4"); _need(pool, name="pool")
+    lib = _lib.load()
+    idx4 = idx4.contiguous()
+    nq = idx4.shape[0]
+    npool, dim = pool.shape
+    ws_bytes = lib.knnsvc_smooth_workspace_bytes(nq)
+    ws = torch.empty(ws_bytes, device=pool.device, dtype=torch.uint8)
+    w = torch.empty(nq, 4, device=pool.device, dtype=torch.float32)
+    iters = torch.zeros(1, device=pool.device, dtype=torch.int32)
+    check(lib.knnsvc_smooth_weights(_p(idx4), nq, _p(pool), npool, dim, pool.stride(0), float(scale), int(max_iter),
+                                    _p(w), _p(iters), _p(ws), ws_bytes, _stream()), "smooth_weights")
+    return (w, iters) if return_iters else w
+
+
+def weighted_gather(idx4, w, pool):
+    _need(idx4, torch.int64, "idx4")
+    idx4 = idx4.contiguous()
+    nq, k = idx4.shape
+    dim = pool.shape[1]
+    out = torch.empty(nq, dim, device=pool.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_weighted_gather(_p(idx4), _p(w), nq, k, _p(pool), dim, pool.stride(0), 0, _p(out),
+                                             _stream()), "weighted_gather")
+    return out
+
+
+# ------------------------------------------------------------------ side features + synth
+def reflect_pad(x1d, pad):
+    out = torch.empty(x1d.numel() + 2 * pad, device=x1d.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_reflect_pad(_p(x1d), x1d.numel(), pad, _p(out), _stream()), "reflect_pad")
+    return out
+
+
+def complex_mag(reim, bins):
+    rows = reim.shape[0]
+    out = torch.empty(rows, bins, device=reim.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_complex_mag(_p(reim), rows, bins, reim.stride(0), _p(out), _stream()), "complex_mag")
+    return out
+
+
+def harmonic_amps(spec, f0, n_harm=49):
+    T, bins = spec.shape
+    out = torch.empty(T, n_harm, device=spec.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_harmonic_amps(_p(spec.contiguous()), _p(f0), T, bins, n_harm, _p(out), _stream()),
+          "harmonic_amps")
+    return out
+
+
+def additive_synth(f0, amp, prenet_w, prenet_b, cond, ld_cond, *, hop=320, sr=16000, mode=0, want_exc=False):
+    """f0 [N], amp [N,H] (None in sine mode) -> writes cond (a [N*hop, >=n_ch] view); returns exc or None."""
+    N = f0.numel()
+    n_ch = prenet_b.numel()
+    H = amp.shape[1] if amp is not None else 0
+    exc = torch.empty(N * hop, device=f0.device, dtype=torch.float32) if want_exc else None
+    ph = torch.empty(N, device=f0.device, dtype=torch.float64)
+    check(_lib.load().knnsvc_additive_synth(_p(f0), _p(amp), N, H, hop, sr, mode, _p(prenet_w), _p(prenet_b), n_ch,
+                                            _p(cond), ld_cond, _p(exc), _p(ph), _stream()), "additive_synth")
+    return exc

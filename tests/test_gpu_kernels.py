@@ -1,0 +1,308 @@
+"""GPU: each HIP kernel against the CPU oracle / a plain torch fp32 reference of the same op,
+called through the C ABI (knn_svc_amd.ops -> libknnsvc_hip.so)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from knn_svc_amd import config as C, synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from knn_svc_amd import ops
+    return ops
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max()), float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ------------------------------------------------------------------ implicit GEMM conv
+@pytest.mark.parametrize("M,K,N", [(65, 64, 40), (300, 1024, 1024), (1500, 1024, 3072), (129, 36, 130), (7, 4, 3)])
+def test_linear(M, K, N):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = F.gelu(F.linear(x, w, b)) + r
+    out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=ops.ACT_GELU, resid=r.to(DEV))
+    assert _err(out, ref)[0] < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,k,s,d,T", [(1, 64, 10, 5, 1, 1000), (64, 64, 3, 2, 1, 199), (32, 32, 11, 1, 5, 700),
+                                             (512, 512, 3, 2, 1, 301), (8, 16, 4, 2, 1, 640), (34, 34, 16, 8, 1, 800),
+                                             (32, 1, 7, 1, 1, 500)])
+def test_conv1d(cin, cout, k, s, d, T):
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin * 7 + k)
+    B = 2
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    pad = (k * d - d) // 2 if s == 1 else k // 2
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=pad, dilation=d)
+    To = ref.shape[-1]
+    xcl = x.transpose(1, 2).contiguous().to(DEV)
+    out = torch.empty(B, To, cout, device=DEV)
+    ops.conv_gemm(xcl, ops.pack_conv_weight(w).to(DEV), out, m=To, n=cout, cin=cin, taps=k, stride=s, dil=d, pad=pad,
+                  t_in=T, bias=b.to(DEV), a_slope=0.1, batches=B, x_bstride=T * cin, o_bstride=To * cout)
+    assert _err(out.transpose(1, 2), ref)[0] < 2e-5
+
+
+def test_conv_epilogue_chain():
+    """residual + accumulate + divide, output into a wider (concat) buffer."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    T, ch = 333, 32
+    x = torch.randn(1, ch, T, generator=g); w = torch.randn(ch, ch, 7, generator=g) / 15; b = torch.randn(ch, generator=g)
+    prev = torch.randn(T, ch, generator=g)
+    ref = ((F.conv1d(x, w, b, padding=3)[0].T + x[0].T) + prev) / 3
+    wide = torch.zeros(T, 2 * ch)
+    wide[:, ch:] = prev
+    wide = wide.to(DEV)
+    xcl = x[0].T.contiguous().to(DEV)
+    ops.conv_gemm(xcl, ops.pack_conv_weight(w).to(DEV), wide[:, ch:], m=T, n=ch, cin=ch, taps=7, pad=3, t_in=T,
+                  bias=b.to(DEV), resid=xcl, ldr=ch, ldo=2 * ch, accumulate=True, div=3.0)
+    assert _err(wide[:, ch:], ref)[0] < 1e-5
+    assert float(wide[:, :ch].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cin,cout,k,u,T", [(64, 32, 20, 10, 57), (16, 8, 4, 2, 301), (512, 256, 16, 8, 40)])
+def test_conv_transpose(cin, cout, k, u, T):
+    ops = _ops()
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(1, cin, T, generator=g)
+    w = torch.randn(cin, cout, k, generator=g) / (cin * 2) ** 0.5
+    b = torch.randn(cout, generator=g)
+    pad = (k - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=pad)[0].T
+    To = ref.shape[0]
+    assert To == T * u
+    xcl = x[0].T.contiguous().to(DEV)
+    out = torch.zeros(To, cout, device=DEV)
+    R = k // u
+    ops.conv_gemm(xcl, ops.pack_convT_weight(w, u).to(DEV), out, m=T + R - 1, n=u * cout, cin=cin, taps=R, stride=1,
+                  dil=-1, pad=0, t_in=T, bias=b.to(DEV), bias_period=cout, a_slope=0.1, ldo=cout,
+                  convt_u=u, convt_cout=cout, convt_pad=pad, t_out=To)
+    assert _err(out, ref)[0] < 2e-5
+
+
+def test_grouped_pos_conv():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    E, G, K, T, B = 128, 16, 128, 150, 2
+    x = torch.randn(B, T, E, generator=g)
+    w = torch.randn(E, E // G, K, generator=g) / (E // G * K) ** 0.5
+    b = torch.randn(E, generator=g)
+    pc = F.conv1d(x.transpose(1, 2), w, b, padding=K // 2, groups=G)[:, :, :-1]
+    ref = x + F.gelu(pc).transpose(1, 2)
+    xd = x.to(DEV)
+    out = torch.empty_like(xd)
+    cg = E // G
+    ops.conv_gemm(xd, ops.pack_grouped_conv_weight(w, G).to(DEV), out, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T,
+                  ldx=E, ldo=E, bias=b.to(DEV), act=ops.ACT_GELU, resid=xd, ldr=E, batches=B, groups=G,
+                  x_bstride=T * E, x_gstride=cg, w_gstride=cg * cg * K, bias_gstride=cg, o_bstride=T * E, o_gstride=cg,
+                  r_bstride=T * E, r_gstride=cg)
+    assert _err(out, ref)[0] < 2e-5
+
+
+# ------------------------------------------------------------------ WavLM pieces
+def test_layernorm_gelu():
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    for dim in (64, 512, 1024):
+        x = torch.randn(301, dim, generator=g) * 3 + 1
+        ga, be = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+        ref = F.gelu(F.layer_norm(x, (dim,), ga, be, 1e-5))
+        out = ops.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), gelu=True)
+        assert _err(out, ref)[0] < 1e-5
+
+
+def test_attention_and_gate():
+    from oracle import wavlm_ref
+    ops = _ops()
+    cfg = dict(C.WAVLM_LARGE, encoder_layers=1)
+    H, E, T, B = 16, 1024, 333, 2
+    sd = S.seeded_state([s for s in S.wavlm_param_spec(cfg) if s[0].startswith("encoder.layers.0.self_attn")], 3)
+    g = torch.Generator().manual_seed(2)
+    xn = torch.randn(T, B, E, generator=g)
+    p = "encoder.layers.0.self_attn."
+    gate_ref = wavlm_ref.gate(sd, cfg, 0, xn)                                   # [B,H,T,1]
+    w8, b8 = sd[p + "grep_linear.weight"], sd[p + "grep_linear.bias"]
+    w2 = torch.stack([w8[:4].sum(0), w8[4:].sum(0)]).contiguous()
+    b2 = torch.stack([b8[:4].sum(), b8[4:].sum()])
+    xbt = xn.transpose(0, 1).reshape(B * T, E).contiguous().to(DEV)
+    gate = ops.wavlm_gate(xbt, H, w2.to(DEV), b2.to(DEV), sd[p + "grep_a"].reshape(-1).to(DEV))
+    assert _err(gate.reshape(B, T, H).permute(0, 2, 1), gate_ref[..., 0])[0] < 1e-5
+    # attention with that gate
+    pb = wavlm_ref.position_bias(sd, cfg, T)                                   # [H,T,T]
+    q = F.linear(xn, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"])
+    k = F.linear(xn, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
+    v = F.linear(xn, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    sh = lambda t: t.reshape(T, B * H, 64).transpose(0, 1).reshape(B, H, T, 64)
+    ref = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), attn_mask=gate_ref * pb[None])
+    ref = ref.permute(0, 2, 1, 3).reshape(B * T, E)
+    lut = wavlm_ref.rel_bucket_table(T, 320, 800)
+    table = sd[p + "relative_attention_bias.weight"][lut].T.contiguous()        # [H, 2T-1]
+    qkv = torch.cat([q, k, v], -1).transpose(0, 1).reshape(B * T, 3 * E).contiguous().to(DEV)
+    out = ops.wavlm_attention(qkv, gate, table.to(DEV), B, T, H)
+    assert _err(out, ref)[0] < 2e-5
+
+
+# ------------------------------------------------------------------ kNN
+def test_knn_golden(golden):
+    from oracle import knn_ref
+    ops = _ops()
+    g = golden("g3_knn")
+    q = S.clustered_features(int(g["nq"]), 1024, int(g["q_seed"]))
+    p = S.clustered_features(int(g["np_"]), 1024, int(g["p_seed"]))
+    idx, dist = ops.knn_topk(q.to(DEV), p.to(DEV), 32)
+    idx, dist = idx.cpu(), dist.cpu()
+    ref_idx = _t(g["idx"]).long()
+    st = knn_ref.topk_agreement(ref_idx, idx, knn_ref.cosine_dist_f64(q, p), tau=5e-7)
+    print("kNN agreement vs reference fixture:", st)
+    # index parity is defined up to the reference's own fp32 rounding gaps (SURVEY §7 hard part 1):
+    # every disagreement must sit inside a gap <= tau of the exact distance
+    assert st["unexplained"] == 0, st
+    assert st["top4"] >= 0.97 and st["sets"] >= 0.95, st
+    assert float((dist - _t(g["dist"])).abs().max()) < 1e-6
+    # internal consistency: sorted ascending, indices in range, no duplicates
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    assert int(idx.min()) >= 0 and int(idx.max()) < len(p)
+    assert all(len(set(r.tolist())) == 32 for r in idx)
+
+
+@pytest.mark.parametrize("nq,npool,k", [(1, 32, 32), (37, 129, 5), (130, 1000, 32), (257, 4099, 32)])
+def test_knn_ragged(nq, npool, k):
+    from oracle import knn_ref
+    ops = _ops()
+    q = S.clustered_features(nq, 64, 1, n_centres=10)
+    p = S.clustered_features(npool, 64, 2, n_centres=10)
+    idx, dist = ops.knn_topk(q.to(DEV), p.to(DEV), k, idx_offset=1000)
+    ref_idx, ref_d = knn_ref.knn_topk(q, p, k)
+    st = knn_ref.topk_agreement(ref_idx, idx.cpu() - 1000, knn_ref.cosine_dist_f64(q, p), tau=5e-7)
+    assert st["unexplained"] == 0, st
+    assert float((dist.cpu() - ref_d).abs().max()) < 1e-6
+
+
+def test_knn_shard_merge_equals_single():
+    ops = _ops()
+    q = S.clustered_features(300, 1024, 5).to(DEV)
+    p = S.clustered_features(5000, 1024, 6).to(DEV)
+    idx, dist = ops.knn_topk(q, p, 32)
+    cuts = [0, 1300, 2600, 3777, 5000]
+    pd, pi = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        i, d = ops.knn_topk(q, p[a:b].contiguous(), 32, idx_offset=a)
+        pi.append(i); pd.append(d)
+    midx, mdist = ops.knn_merge(torch.stack(pd), torch.stack(pi))
+    assert torch.equal(midx, idx) and torch.equal(mdist, dist)
+
+
+def test_knn_nan_raises():
+    ops = _ops()
+    from knn_svc_amd._lib import KnnSvcError
+    q = torch.zeros(4, 64, device=DEV)
+    p = torch.randn(64, 64, device=DEV)
+    with pytest.raises(KnnSvcError):
+        ops.knn_topk(q, p, 4)
+
+
+# ------------------------------------------------------------------ selection
+def _select_inputs(g):
+    nq, npool = int(g["nq"]), int(g["npool"])
+    q = S.clustered_features(nq, 1024, seed=31, n_centres=40)
+    p = S.clustered_features(npool, 1024, seed=32, n_centres=40)
+    q = (q + torch.roll(q, 1, 0) + torch.roll(q, 2, 0)) / 3
+    p = (p + torch.roll(p, 1, 0) + torch.roll(p, 2, 0)) / 3
+    return q, p
+
+
+def test_f0_shift_and_rerank(golden):
+    ops = _ops()
+    g = golden("g4_select")
+    qf0, pf0 = _t(g["qf0"]).to(DEV), _t(g["pf0"]).to(DEV)
+    qm, pm = ops.log_f0_median(qf0), ops.log_f0_median(pf0)
+    lq = torch.log(_t(g["qf0"])[_t(g["qf0"]) != 0]); lp = torch.log(_t(g["pf0"])[_t(g["pf0"]) != 0])
+    assert abs(float(qm[0]) - float(torch.median(lq))) < 1e-6 and int(qm[1]) == len(lq)
+    assert abs(float(pm[0]) - float(torch.median(lp))) < 1e-6
+    sh = ops.shift_f0(qf0, qm, pm)
+    assert _err(sh, _t(g["shifted"]))[1] < 1e-6
+    nn32 = _t(g["nn32"]).long().to(DEV)
+    rk = ops.f0_rerank(nn32, _t(g["shifted"]).to(DEV), pf0)
+    match = float((rk.cpu() == _t(g["ranked"]).long()).all(dim=1).float().mean())
+    print("f0 rerank exact-row match:", match)
+    assert match >= 0.98
+
+
+def test_concat_reselect(golden):
+    ops = _ops()
+    g = golden("g4_select")
+    q, p = _select_inputs(g)
+    qd, pd = q.to(DEV), p.to(DEV)
+    qn, _ = ops.row_norms(qd); pn, _ = ops.row_norms(pd)
+    a = ops.concat_reselect(_t(g["nn32"]).long()[:, :4].contiguous().to(DEV), qd, qn, pd, pn, concat_weight=0.2)
+    b = ops.concat_reselect(_t(g["ranked"]).long()[:, :4].contiguous().to(DEV), qd, qn, pd, pn,
+                            _t(g["shifted"]).to(DEV), _t(g["pf0"]).to(DEV), concat_weight=0.2)
+    ma = float((a.cpu() == _t(g["sel_plain"]).long()).all(dim=1).float().mean())
+    mb = float((b.cpu() == _t(g["sel_f0"]).long()).all(dim=1).float().mean())
+    print("concat reselect exact-row match: plain", ma, "f0", mb)
+    assert ma >= 0.95 and mb >= 0.95
+
+
+# ------------------------------------------------------------------ smoothness weights
+def test_smooth_weights(golden):
+    ops = _ops()
+    g = golden("g5_smooth")
+    npool = int(g["npool"])
+    p = S.clustered_features(npool, 1024, seed=int(g["p_seed"]), n_centres=30)
+    p = (p + torch.roll(p, 1, 0) + torch.roll(p, 2, 0)) / 3
+    idx = _t(g["idx"]).long().to(DEV)
+    w, it = ops.smooth_weights(idx, p.to(DEV), 0.1, return_iters=True)
+    e = _err(w, _t(g["w_wavlm"]))[0]
+    print("wavlm weights max|d|", e, "iters", int(it), "ref", int(g["iters_wavlm"]))
+    assert e < 5e-3
+    assert abs(float(w.sum(1).mean()) - 1.0) < 1e-5
+    wh, ith = ops.smooth_weights(idx, _t(g["harm_pool"]).to(DEV), 1000.0, return_iters=True)
+    e = _err(wh, _t(g["w_harm"]))[0]
+    print("harm weights max|d|", e, "iters", int(ith), "ref", int(g["iters_harm"]))
+    assert e < 5e-3
+    # weighted gather
+    out = ops.weighted_gather(idx, w, p.to(DEV))
+    ref = (p[idx.cpu().reshape(-1)].reshape(-1, 4, 1024) * w.cpu()[..., None]).sum(1)
+    assert _err(out, ref)[0] < 1e-5
+
+
+# ------------------------------------------------------------------ synth / side features
+def test_additive_synth(golden):
+    ops = _ops()
+    g = golden("g6_synth")
+    f0, amp = _t(g["f0"]).to(DEV), _t(g["amp"]).to(DEV)
+    N = f0.numel()
+    pw = torch.randn(32, 1, 3); pb = torch.randn(32)
+    cond = torch.empty(N * 320, 64, device=DEV)
+    exc = ops.additive_synth(f0, amp, pw.reshape(32, 3).contiguous().to(DEV), pb.to(DEV), cond[:, 32:], 64, want_exc=True)
+    e = _err(exc, _t(g["wave"]))[0]
+    print("additive synth max|d|", e)
+    assert e < 2e-5
+    ref_cond = F.conv1d(_t(g["wave"])[None, None], pw, pb, padding=1)[0].T
+    assert _err(cond[:, 32:], ref_cond)[0] < 5e-5
+
+
+def test_stft_and_harmonics(golden):
+    from knn_svc_amd import features
+    ops = _ops()
+    g = golden("g6_synth")
+    wav, _ = S.synth_clip(320 * 120, int(g["clip_seed"]))
+    spec = features.stft_mag(torch.from_numpy(wav).to(DEV))[:120]
+    assert _err(spec, _t(g["spec"]))[0] < 2e-4
+    harm = ops.harmonic_amps(_t(g["spec"]).to(DEV), _t(g["f0w"]).to(DEV))
+    assert _err(harm, _t(g["harm"]))[0] < 1e-6
