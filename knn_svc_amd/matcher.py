@@ -1,0 +1,123 @@
+"""``KNeighborsVC`` — the orchestrator object the reference's entry points hand out.
+
+Mirror of ddsp_matcher.py:303-1155 restricted to its live methods: ``vocode``
+(:375-406), ``special_match`` (:937-1023) and ``bulk_match`` (:1027-1155), with the
+same argument names, output file naming and ignored arguments (``topk``,
+``tgt_loudness_db``).  Differences that are deliberate: ``special_match`` returns
+the waveform instead of calling ``sys.exit()`` after saving (the CLI exits 0, the
+observable behaviour), and ``bulk_match`` does not ``rm -rf`` a hard-coded cache
+directory (ddsp_matcher.py:1066-1068).
+"""
+from __future__ import annotations
+
+import csv
+import os
+from pathlib import Path
+
+import torch
+
+from . import audio_io, config as C
+from .matching import match_at_inference_time
+from .vocoder import Vocoder
+from .wavlm import WavLMEncoder
+
+# one-hot on layer 6 of 25 (ddsp_matcher.py:88-89, knnvc_utils.py:3-6)
+SPEAKER_INFORMATION_WEIGHTS = [1.0 if i == C.MATCH_LAYER else 0.0 for i in range(25)]
+
+
+class KNeighborsVC:
+    def __init__(self, wavlm: WavLMEncoder, hifigan: Vocoder, hifigan_cfg: dict, device="cuda") -> None:
+        self.wavlm = wavlm
+        self.hifigan = hifigan
+        self.h = hifigan_cfg
+        self.device = torch.device(device)
+        self.weighting = torch.zeros(wavlm.cfg["encoder_layers"] + 1)
+        self.weighting[wavlm.n_layers] = 1.0
+        self.sr = hifigan_cfg["sampling_rate"]
+        self.hop_length = 320
+
+    @torch.inference_mode()
+    def vocode(self, c, f0=None, harmonics_out_feats_weighted=None):
+        """c (bs, seq_len, c_dim), f0 (bs, seq_len, 1), harmonics (bs, seq_len, 49) -> (bs, seq_len*320)."""
+        if f0 is None:
+            raise NotImplementedError("the f0-free 'wavlm_only_original' generator (hifigan/models.py) is missing "
+                                      "from the reference snapshot and unsupported")
+        outs = []
+        for b in range(c.shape[0]):
+            harm = harmonics_out_feats_weighted[b] if harmonics_out_feats_weighted is not None else None
+            outs.append(self.hifigan.forward(c[b].to(self.device).float(), f0[b].reshape(-1).to(self.device).float(),
+                                             None if harm is None else harm.to(self.device).float()))
+        return torch.stack(outs, 0)
+
+    @torch.inference_mode()
+    def special_match(self, src_wav_file, ref_wav_file, topk: int = 4, device=None, prioritize_f0=True,
+                      ckpt_type="wavlm_only", tgt_loudness_db=-16, post_opt="no_post_opt", save=True):
+        f0only = "wavlm_only" in ckpt_type or "no_harm_no_amp" in ckpt_type
+        if "wavlm_only_original" in ckpt_type:
+            raise NotImplementedError("wavlm_only_original needs hifigan/models.py, absent upstream")
+        key = str(src_wav_file)
+        if not f0only:
+            of, hw, _a, sf0 = match_at_inference_time(Path(src_wav_file), Path(ref_wav_file), self.wavlm,
+                                                      self.weighting, self.weighting, topk=topk, device=self.device,
+                                                      prioritize_f0=prioritize_f0, ckpt_type=ckpt_type, post_opt=post_opt)
+            pred = self.vocode(of[key][None], sf0[key][None, :, None], hw[key][None]).squeeze()
+        else:
+            # the reference does not forward post_opt on this branch (ddsp_matcher.py:970)
+            of, _a, sf0 = match_at_inference_time(Path(src_wav_file), Path(ref_wav_file), self.wavlm,
+                                                  self.weighting, self.weighting, topk=topk, device=self.device,
+                                                  prioritize_f0=prioritize_f0, ckpt_type=ckpt_type)
+            pred = self.vocode(of[key][None], sf0[key][None, :, None]).squeeze()
+        src_id = os.path.basename(src_wav_file).split(".")[0]
+        ref_id = os.path.basename(ref_wav_file).split(".")[0]
+        out_file = str(Path(src_wav_file).parent) + "/" + src_id + "_to_" + ref_id + f"_knn_{ckpt_type}_{post_opt}.wav"
+        if save:
+            print("->", out_file)
+            audio_io.save_audio(out_file, pred.detach().cpu().numpy(), sample_rate=16000)
+        return pred
+
+    @torch.inference_mode()
+    def bulk_match(self, src_dataset_path, tgt_dataset_path, converted_audio_dir, topk: int = 4, device=None,
+                   prioritize_f0=True, ckpt_type="mix", tgt_loudness_db=-16, required_subset_file=None,
+                   post_opt="no_post_opt", duration_limit=None):
+        assert os.path.isdir(src_dataset_path) and os.path.isdir(tgt_dataset_path)
+        Path(converted_audio_dir).mkdir(parents=True, exist_ok=True)
+        spk = lambda root: sorted([p for p in Path(root).iterdir() if p.is_dir() and "f0_cache" not in os.path.basename(p)])
+        src_spk, tgt_spk = spk(src_dataset_path), spk(tgt_dataset_path)
+        if src_dataset_path != tgt_dataset_path:
+            assert len(set(src_spk).intersection(set(tgt_spk))) == 0
+        assert len(src_spk) > 0, [f"Are you sure {src_dataset_path} is a FOLDER containing speaker folders, i.e. dataset root"]
+        assert len(tgt_spk) > 0, [f"Are you sure {tgt_dataset_path} is a FOLDER containing speaker folders, i.e. dataset root"]
+        required = None
+        if required_subset_file:
+            with open(required_subset_file, "r") as fp:
+                rows = list(csv.reader(fp, delimiter=",", quotechar='"'))
+            required = [r[2] for i, r in enumerate(rows) if i != 0 and r[-1] == "0"]
+        f0only = "wavlm_only" in ckpt_type or "no_harm_no_amp" in ckpt_type
+        written = []
+        for i, s in enumerate(src_spk):
+            for j, t in enumerate(tgt_spk):
+                if src_dataset_path == tgt_dataset_path and i == j:
+                    continue
+                print(f"{s} -> {t}")
+                common = dict(topk=topk, device=self.device, prioritize_f0=prioritize_f0, ckpt_type=ckpt_type,
+                              src_dataset_path=src_dataset_path, tgt_dataset_path=tgt_dataset_path,
+                              required_subset=required, duration_limit=duration_limit)
+                preds = {}
+                if not f0only:
+                    of, hw, _a, sf0 = match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting,
+                                                              post_opt=post_opt, **common)
+                    for k in of:
+                        preds[k] = self.vocode(of[k][None], sf0[k][None, :, None], hw[k][None]).squeeze()
+                else:
+                    of, _a, sf0 = match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting, **common)
+                    for k in of:
+                        preds[k] = self.vocode(of[k][None], sf0[k][None, :, None]).squeeze()
+                for k, pred in preds.items():
+                    out = os.path.join(converted_audio_dir, os.path.basename(s), os.path.basename(k).split(".")[0],
+                                       os.path.basename(t) + "." + os.path.basename(k).split(".")[-1])
+                    Path(out).parent.mkdir(parents=True, exist_ok=True)
+                    assert pred.dim() == 1
+                    audio_io.save_audio(out, pred[None, :].cpu().numpy(), sample_rate=self.sr)
+                    written.append(out)
+                print(f"{os.path.basename(s)}, {os.path.basename(t)} -> {converted_audio_dir}")
+        return written

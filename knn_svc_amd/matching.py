@@ -1,0 +1,182 @@
+"""Feature-pool building and frame matching on the GPU.
+
+Host-side mirror of the reference's ``get_complete_spk_pool`` and
+``match_at_inference_time`` (ddsp_prematch_dataset.py:301-414, 1074-1459): same
+arguments, same returned dict-of-tensors keyed by ``str(path)``, same quirks
+(k hard-coded to 32 -> first 4, ``--dur_limit`` in seconds overshooting by one file,
+``post_opt`` parsing, ``prioritize_f0`` must be True, pool rebuilt per call).
+All arithmetic is done by libknnsvc_hip.so kernels on device-resident tensors; the
+only host work is file I/O and the chunk bookkeeping.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import audio_io, config as C, features, ops
+from .wavlm import WavLMEncoder, chunk_plan
+
+AUDIO_EXT = {".flac", ".wav", ".mp3"}
+
+
+def parse_post_opt(post_opt: str):
+    """(concat_weight, run_adam): float of the last '_' token, 'extra' -> 0.3, else -1 (off);
+    the Adam stage is skipped iff 'no_post_opt' is a substring (ddsp_prematch_dataset.py:1273-1279, 1356)."""
+    tail = post_opt.split("_")[-1]
+    try:
+        w = float(tail)
+    except ValueError:
+        w = 0.3 if tail == "extra" else -1
+    return w, ("no_post_opt" not in post_opt)
+
+
+def list_audio(path) -> list:
+    """A single audio file, or every audio file under a folder in sorted rglob order (:313-319)."""
+    path = Path(path)
+    if os.path.isfile(path) and os.path.splitext(path)[-1] in AUDIO_EXT:
+        return [path]
+    files = sorted([p for p in path.rglob("**/*") if p.suffix.lower() in AUDIO_EXT])
+    assert len(files) != 0, [f"directory not containing any audio {path}"]
+    return files
+
+
+def load_utterance(pth):
+    """-> (wav float32 [L] mono 16 kHz on the host, f0 float32 array).  Channel mean for multi-channel
+    input (:333-335); f0 from ``<stem>_f0.npy`` (:373-382)."""
+    x, sr = audio_io.load_audio(str(pth))
+    if x.shape[0] > 1:
+        x = x.mean(axis=0, keepdims=True)
+    if sr != C.SAMPLE_RATE:
+        x = audio_io.resample(x, sr, C.SAMPLE_RATE)
+    f0_path = os.path.splitext(str(pth))[0] + "_f0.npy"
+    if not os.path.isfile(f0_path):
+        raise FileNotFoundError(
+            f"{f0_path} not found.  The reference would run pyworld.harvest here (ddsp_prematch_dataset.py:121-128, "
+            "376-379); pyworld is not available in this build — provide the f0 cache next to the audio file.")
+    f0 = np.asarray(np.load(f0_path, allow_pickle=True), dtype=np.float32)
+    return np.ascontiguousarray(x[0], dtype=np.float32), f0
+
+
+def frames_of(n_samples: int, enc: WavLMEncoder) -> int:
+    return sum(enc.n_frames(l + p) for (_s, l, p) in chunk_plan(n_samples))
+
+
+def side_features(wav_gpu: torch.Tensor, f0_host: np.ndarray, T: int):
+    """STFT magnitude -> harmonic amplitudes for one utterance (:361-404).  Returns (f0 [T], harm [T,49], spec [T,200])."""
+    assert wav_gpu.numel() >= C.HOP * T
+    spec = features.stft_mag(wav_gpu)
+    assert spec.shape[0] >= T
+    spec = spec[:T].contiguous()
+    assert abs(len(f0_host) - T) <= 1 and len(f0_host) >= T, [len(f0_host), T]
+    f0 = torch.from_numpy(np.ascontiguousarray(f0_host[:T])).to(wav_gpu.device)
+    harm = ops.harmonic_amps(spec, f0, C.N_HARM)
+    return f0, harm, spec
+
+
+def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_weights=None, device="cuda",
+                          duration_limit=None, vad_trigger_level=0):
+    """Per-file dicts (matching_pool, synth_pool, audio_synth_pool, spec_synth_pool, f0_pool, harmonics_pool),
+    like the reference.  matching == synth features (both weightings are the same one-hot on the live path);
+    ``audio_synth_pool`` is kept as None values: the live path never reads it (audio_out_feats_weighted = None,
+    ddsp_prematch_dataset.py:1368)."""
+    dev = wavlm.device
+    files = list_audio(path)
+    kept, wavs, f0s, Ts = [], [], [], []
+    dur = 0.0
+    for pth in files:
+        w, f0 = load_utterance(pth)
+        T = frames_of(len(w), wavlm)
+        kept.append(str(pth)); wavs.append(torch.from_numpy(w).to(dev)); f0s.append(f0); Ts.append(T)
+        dur += T * C.HOP / C.SAMPLE_RATE
+        if duration_limit is not None and dur >= duration_limit:
+            break
+    feats = wavlm.encode_many(wavs)
+    matching, synth, audio, specs, f0p, harmp = {}, {}, {}, {}, {}, {}
+    for key, w, f0h, T, ft in zip(kept, wavs, f0s, Ts, feats):
+        assert ft.shape[0] == T
+        f0, harm, spec = side_features(w, f0h, T)
+        matching[key] = ft; synth[key] = ft; audio[key] = None; specs[key] = spec; f0p[key] = f0; harmp[key] = harm
+    return matching, synth, audio, specs, f0p, harmp
+
+
+def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
+                   return_debug=False):
+    """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors."""
+    q = query_seq.contiguous()
+    P = matching_list
+    qn, qs = ops.row_norms(q)
+    pn, ps = ops.row_norms(P)
+    nn32, _ = ops.knn_topk(q, P, C.KNN_K, q_stats=(qn, qs), p_stats=(pn, ps))
+    qmed, pmed = ops.log_f0_median(query_f0), ops.log_f0_median(matching_f0)
+    shifted = ops.shift_f0(query_f0, qmed, pmed)
+    cw, run_adam = parse_post_opt(post_opt)
+    idx = nn32[:, :C.KNN_USE].contiguous()
+    if cw != -1:
+        idx = ops.concat_reselect(idx, q, qn, P, pn, concat_weight=cw)
+    w = ops.smooth_weights(idx, P, 0.1) if run_adam else None
+    out_feats = ops.weighted_gather(idx, w, P)
+    ranked = ops.f0_rerank(nn32, shifted, matching_f0)
+    idx2 = ranked[:, :C.KNN_USE].contiguous()
+    if cw != -1:
+        idx2 = ops.concat_reselect(idx2, q, qn, P, pn, shifted, matching_f0, concat_weight=cw)
+    harm_w = None
+    w2 = None
+    if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type:
+        w2 = ops.smooth_weights(idx2, harmonics_list, 1000.0) if run_adam else None
+        harm_w = ops.weighted_gather(idx2, w2, harmonics_list)
+    if return_debug:
+        return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2)
+    return out_feats, harm_w, shifted
+
+
+def _layer_of(weights) -> int:
+    if weights is None:
+        return C.MATCH_LAYER
+    w = torch.as_tensor(weights).reshape(-1).float().cpu()
+    nz = torch.nonzero(w).reshape(-1)
+    if len(nz) != 1 or float(w[nz[0]]) != 1.0:
+        raise NotImplementedError("only one-hot layer weightings are supported (the reference uses layer 6)")
+    return int(nz[0])
+
+
+def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, match_weights=None, synth_weights=None,
+                            topk: int = 4, device="cuda", prioritize_f0=False, ckpt_type="wavlm_only",
+                            src_dataset_path=None, tgt_dataset_path=None, cache_dir=None, required_subset=None,
+                            post_opt="no_post_opt", duration_limit=None):
+    """Same contract as the reference function (ddsp_prematch_dataset.py:1074).  ``topk`` is accepted and
+    ignored (k = 32 -> 4 is hard-coded upstream, :1203,1246,1398); ``cache_dir`` is ignored (the reference
+    force-disables it, :1086-1087)."""
+    assert prioritize_f0, "prioritize_f0=False is unsupported by the reference (ddsp_prematch_dataset.py:1375)"
+    if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type and "mix" not in ckpt_type:
+        raise NotImplementedError(ckpt_type)
+    for wts in (match_weights, synth_weights):
+        if _layer_of(wts) != wavlm.n_layers:
+            raise NotImplementedError("layer weighting does not match the encoder's exit layer")
+    if src_dataset_path is None:
+        assert os.path.isfile(src_wav_file)
+    query_pool, _, _, _, query_f0_pool, _ = get_complete_spk_pool(src_wav_file, wavlm, device=device)
+    if tgt_dataset_path is None:
+        assert os.path.isfile(ref_wav_file)
+    matching_pool, _synth, _audio, _spec, f0_pool, harm_pool = get_complete_spk_pool(
+        ref_wav_file, wavlm, device=device, duration_limit=duration_limit)
+    keys = list(matching_pool)
+    matching_list = torch.cat([matching_pool[k] for k in keys], 0).contiguous()
+    matching_f0 = torch.cat([f0_pool[k] for k in keys], 0).contiguous()
+    harmonics_list = torch.cat([harm_pool[k] for k in keys], 0).contiguous()
+
+    out_c, harm_c, audio_c, f0_c = {}, {}, {}, {}
+    for item in query_pool:
+        if required_subset is not None and \
+                os.path.basename(item).split(".")[0] + "/" + os.path.basename(ref_wav_file) not in required_subset:
+            continue
+        of, hw, sf0 = match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
+                                     harmonics_list, ckpt_type, post_opt)
+        out_c[item] = of; audio_c[item] = None; f0_c[item] = sf0
+        if hw is not None:
+            harm_c[item] = hw
+    if "wavlm_only" in ckpt_type or "no_harm_no_amp" in ckpt_type:
+        return out_c, audio_c, f0_c
+    return out_c, harm_c, audio_c, f0_c

@@ -1,0 +1,166 @@
+"""Host side of the conditioned HiFi-GAN generator ("SynthesizerTrn").
+
+Mirrors ``SynthesizerTrn.forward`` + ``Generator.forward`` of the reference:
+'mix' = hifigan/ddsp_models.py:108-233, 405-493 (additive-synth excitation, doubling
+side channels), 'f0' = hifigan/ddsp_models_f0.py:106-216, 320-381 (sine excitation,
+n_harmonic+2 side channels).  Weight norm is live in the reference at inference
+(ddsp_hubconf.py:100-102); it is folded once here (w = g * v / ||v||).
+
+Everything is channel-last [T, C] fp32.  Skip connections are zero-copy: producers
+write straight into column blocks of the concat buffers (``ldo`` / column offset of
+the conv kernel), so ``torch.cat`` never happens.  The transposed convolutions run as
+one GEMM over K = (k/u)*Cin, N = u*Cout with a row-scatter epilogue.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+LRELU = 0.1
+
+
+def _fold(sd, name):
+    if name + ".weight" in sd:
+        return sd[name + ".weight"].float()
+    return torch._weight_norm(sd[name + ".weight_v"].float(), sd[name + ".weight_g"].float(), 0)
+
+
+class Vocoder:
+    def __init__(self, state: dict, h: dict, kind: str = "mix", device="cuda"):
+        assert kind in ("mix", "f0")
+        self.h, self.kind, self.device = h, kind, torch.device(device)
+        dev = self.device
+        f = lambda t: t.detach().float().contiguous().to(dev)
+        self.rates, self.ksz = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
+        self.n_up = len(self.rates)
+        self.hop = h["hop_size"]
+        self.sr = h["sampling_rate"]
+        nh, uic = h["n_harmonic"], h["upsample_initial_channel"]
+        self.uic = uic
+        self.lin_w, self.lin_b = f(state["dec.lin_pre.weight"]), f(state["dec.lin_pre.bias"])
+        self.pre_w, self.pre_b = f(ops.pack_conv_weight(state["dec.conv_pre.weight"].float())), f(state["dec.conv_pre.bias"])
+        # side (down) path channel counts: res[0] = cond, res[i+1] = output of down stage i
+        if kind == "mix":
+            self.side = [nh * 2 ** i for i in range(self.n_up + 1)]
+        else:
+            self.side = [nh + 2] * (self.n_up + 1)
+        self.downs, self.rbd = [], []
+        for i in range(self.n_up):
+            j = self.n_up - 1 - i
+            self.downs.append(dict(w=f(ops.pack_conv_weight(_fold(state, f"dec.downs.{i}"))), b=f(state[f"dec.downs.{i}.bias"]),
+                                   k=self.ksz[j], u=self.rates[j]))
+            nm = f"dec.resblocks_downs.{i}.convs.0"
+            self.rbd.append(dict(w=f(ops.pack_conv_weight(_fold(state, nm))), b=f(state[nm + ".bias"])))
+        self.cpre_w, self.cpre_b = f(ops.pack_conv_weight(state["dec.concat_pre.weight"].float())), f(state["dec.concat_pre.bias"])
+        self.ups, self.ccv, self.res = [], [], []
+        nk = len(h["resblock_kernel_sizes"])
+        for i in range(self.n_up):
+            u, k = self.rates[i], self.ksz[i]
+            cout = uic // 2 ** (i + 1)
+            self.ups.append(dict(w=f(ops.pack_convT_weight(_fold(state, f"dec.ups.{i}"), u)), b=f(state[f"dec.ups.{i}.bias"]),
+                                 u=u, k=k, cout=cout, cin=uic // 2 ** i))
+            self.ccv.append(f(ops.pack_conv_weight(state[f"dec.concat_conv.{i}.weight"].float())))
+            blocks = []
+            for j, (k_r, dil) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+                nm = f"dec.resblocks.{i * nk + j}"
+                convs = []
+                for m, d in enumerate(dil):
+                    convs.append(dict(w1=f(ops.pack_conv_weight(_fold(state, f"{nm}.convs1.{m}"))), b1=f(state[f"{nm}.convs1.{m}.bias"]),
+                                      w2=f(ops.pack_conv_weight(_fold(state, f"{nm}.convs2.{m}"))), b2=f(state[f"{nm}.convs2.{m}.bias"]),
+                                      d=d))
+                blocks.append(dict(k=k_r, convs=convs))
+            self.res.append(blocks)
+        self.post_w = f(ops.pack_conv_weight(state["dec.conv_post.weight"].float()))
+        self.prenet_w = f(state["sin_prenet.weight"].float().reshape(-1, 3))
+        self.prenet_b = f(state["sin_prenet.bias"])
+
+    # -------------------------------------------------------------------------------------------
+    def _conv(self, x, w, out, *, T_in, cin, cout, k, **kw):
+        return ops.conv_gemm(x, w, out, n=cout, cin=cin, taps=k, t_in=T_in, **kw)
+
+    def forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None) -> torch.Tensor:
+        """c [N, hubert_dim], f0 [N], harm [N, 49] (mix only), all fp32 on the GPU -> waveform [N*hop]."""
+        dev = c.device
+        N = c.shape[0]
+        hop, n_up, uic = self.hop, self.n_up, self.uic
+        L = N * hop
+        new = lambda r, ch: torch.empty(r, ch, device=dev, dtype=torch.float32)
+        # lengths of the time axis at each level of the side path: lens[0] = L ... lens[n_up] = N
+        lens = [L]
+        for i in range(n_up):
+            lens.append(lens[-1] // self.downs[i]["u"])
+        assert lens[-1] == N
+        # concat buffers: up stage i consumes cat[i] = [ups_i output | res[n_up-1-i]]
+        cat = []
+        for i in range(n_up):
+            ch = uic // 2 ** (i + 1)
+            cat.append(new(lens[n_up - 1 - i], ch + self.side[n_up - 1 - i]))
+        cat_pre = new(N, uic + self.side[n_up])
+
+        def res_view(level):
+            """(tensor view, ld, channels) of res[level] inside its concat buffer."""
+            if level == n_up:
+                return cat_pre[:, uic:], cat_pre.shape[1], self.side[level]
+            buf = cat[n_up - 1 - level]
+            ch = uic // 2 ** (n_up - level)
+            return buf[:, ch:], buf.shape[1], self.side[level]
+
+        # ---- excitation + sin_prenet -> res[0] -------------------------------------------------
+        cond, ld0, c0 = res_view(0)
+        ops.additive_synth(f0.contiguous(), harm.contiguous() if self.kind == "mix" else None, self.prenet_w, self.prenet_b,
+                           cond, ld0, hop=hop, sr=self.sr, mode=0 if self.kind == "mix" else 1)
+        # ---- side (down) path ----------------------------------------------------------------------
+        for i in range(n_up):
+            src, ld_s, c_s = res_view(i)
+            dst, ld_d, c_d = res_view(i + 1)
+            dn = self.downs[i]
+            t_in = lens[i]
+            t_mid = t_in // dn["u"] + 1            # the conv yields one more row than the crop keeps; the
+            mid = new(t_mid, c_d)                   # k=3 resblock conv still reads it (ddsp_models.py:189-194)
+            self._conv(src, dn["w"], mid, T_in=t_in, cin=c_s, cout=c_d, k=dn["k"], m=t_mid, stride=dn["u"],
+                       pad=dn["k"] // 2, ldx=ld_s, bias=dn["b"])
+            rb = self.rbd[i]
+            self._conv(mid, rb["w"], dst, T_in=t_mid, cin=c_d, cout=c_d, k=3, m=lens[i + 1], pad=1, bias=rb["b"],
+                       a_slope=LRELU, resid=mid, ldr=c_d, ldo=ld_d)
+        # ---- main path ------------------------------------------------------------------------------
+        x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b)
+        hd = x0.shape[1]
+        self._conv(x0, self.pre_w, cat_pre, T_in=N, cin=hd, cout=uic, k=7, m=N, pad=3, bias=self.pre_b,
+                   ldo=cat_pre.shape[1])
+        x = new(N, uic)
+        self._conv(cat_pre, self.cpre_w, x, T_in=N, cin=cat_pre.shape[1], cout=uic, k=3, m=N, pad=1, bias=self.cpre_b)
+        t_cur = N
+        for i in range(n_up):
+            up = self.ups[i]
+            u, k, cout, cin = up["u"], up["k"], up["cout"], up["cin"]
+            R = k // u
+            t_out = t_cur * u
+            assert t_out == cat[i].shape[0]
+            ld_c = cat[i].shape[1]
+            ops.conv_gemm(x, up["w"], cat[i], m=t_cur + R - 1, n=u * cout, cin=cin, taps=R, stride=1, dil=-1, pad=0,
+                          t_in=t_cur, bias=up["b"], bias_period=cout, a_slope=LRELU, ldo=ld_c,
+                          convt_u=u, convt_cout=cout, convt_pad=(k - u) // 2, t_out=t_out)
+            xc = new(t_out, cout)
+            self._conv(cat[i], self.ccv[i], xc, T_in=t_out, cin=ld_c, cout=cout, k=3, m=t_out, pad=1)
+            xs = new(t_out, cout)
+            t1, ra, rb_ = new(t_out, cout), new(t_out, cout), new(t_out, cout)
+            nblk = len(self.res[i])
+            for j, blk in enumerate(self.res[i]):
+                kr = blk["k"]
+                cur = xc
+                for m, cv in enumerate(blk["convs"]):
+                    d = cv["d"]
+                    self._conv(cur, cv["w1"], t1, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, dil=d,
+                               pad=(kr * d - d) // 2, bias=cv["b1"], a_slope=LRELU, act=ops.ACT_LRELU, act_slope=LRELU)
+                    last = m == len(blk["convs"]) - 1
+                    dst = xs if last else (ra if cur is not ra else rb_)
+                    self._conv(t1, cv["w2"], dst, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, pad=(kr - 1) // 2,
+                               bias=cv["b2"], resid=cur, ldr=cout,
+                               accumulate=(last and j > 0), div=(float(nblk) if (last and j == nblk - 1) else 1.0))
+                    cur = dst
+            x, t_cur = xs, t_out
+        y = new(t_cur, 1)
+        self._conv(x, self.post_w, y, T_in=t_cur, cin=x.shape[1], cout=1, k=7, m=t_cur, pad=3, a_slope=0.01,
+                   act=ops.ACT_TANH)
+        return y.reshape(-1)

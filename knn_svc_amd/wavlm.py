@@ -1,0 +1,192 @@
+"""Host side of the WavLM encoder: weight packing + the kernel schedule.
+
+Mirrors ``WavLM.extract_features`` / ``TransformerEncoder.extract_features`` as the
+kNN-SVC path uses them (wavlm/WavLM.py:323-375, 485-504, 572-612; wavlm/modules.py:
+417-455, 457-564) but only for what the path consumes: the residual stream after
+``n_layers`` layers (default 6 == the one-hot weighting of ddsp_matcher.py:88-89),
+no final LayerNorm, no waveform normalisation, no masks.
+
+Activations are channel-last [B*T, C] fp32 in HBM; every arithmetic step is a call
+into libknnsvc_hip.so (MFMA implicit-GEMM convs/linears, fused LN(+GELU), gated
+rel-pos flash attention).  The T x T bias is never materialised: the bucket
+function (log + integer truncation) is evaluated once on the host, exactly as torch
+does, into a (2T-1)-entry per-head table.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import config as C
+from . import ops
+
+
+def _bucket_lut(T: int, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """rel = key - query in [-(T-1), T-1] -> bucket (wavlm/modules.py:417-442), on the host in torch
+    so that the float log / truncation match the reference bit for bit."""
+    rel = torch.arange(-(T - 1), T, dtype=torch.long)
+    half = num_buckets // 2
+    out = (rel > 0).to(torch.long) * half
+    a = rel.abs()
+    max_exact = half // 2
+    large = max_exact + (torch.log(a.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (half - max_exact)).to(torch.long)
+    large = torch.clamp(large, max=half - 1)
+    return out + torch.where(a < max_exact, a, large)
+
+
+def chunk_plan(n_samples: int, sr: int = C.SAMPLE_RATE, hop: int = C.HOP):
+    """get_full_wavlm_features chunking (ddsp_prematch_dataset.py:275-293): 30 s windows, tails of
+    <= 0.02*sr samples dropped, zero right-pad of hop - len % hop (a full hop when aligned)."""
+    plan, start = [], 0
+    while start < n_samples:
+        ln = min(30 * sr, n_samples - start)
+        if ln <= 0.02 * sr:
+            break
+        plan.append((start, ln, hop - (ln % hop)))
+        start += 30 * sr
+    return plan
+
+
+class WavLMEncoder:
+    """Packed WavLM weights on one GPU + forward schedule."""
+
+    def __init__(self, state: dict, cfg: dict, device="cuda", n_layers: int = C.MATCH_LAYER):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.n_layers = n_layers
+        assert n_layers <= cfg["encoder_layers"]
+        self.E = cfg["encoder_embed_dim"]
+        self.H = cfg["encoder_attention_heads"]
+        if self.E // self.H != 64:
+            raise ValueError("the attention kernel is built for head_dim 64 (WavLM-Large / Base+)")
+        dev = self.device
+        f = lambda t: t.detach().to(torch.float32).contiguous().to(dev)
+        self.conv = []
+        for i, (dim, k, s) in enumerate(C.conv_layers(cfg)):
+            p = f"feature_extractor.conv_layers.{i}."
+            self.conv.append(dict(w=f(ops.pack_conv_weight(state[p + "0.weight"].float())), k=k, s=s, dim=dim,
+                                  cin=state[p + "0.weight"].shape[1],
+                                  g=f(state[p + "2.1.weight"]), b=f(state[p + "2.1.bias"])))
+        self.ln_g, self.ln_b = f(state["layer_norm.weight"]), f(state["layer_norm.bias"])
+        self.proj_w, self.proj_b = f(state["post_extract_proj.weight"]), f(state["post_extract_proj.bias"])
+        # positional conv: fold weight_norm(dim=2) once (wavlm/WavLM.py:526), then pack per group
+        wpc = torch._weight_norm(state["encoder.pos_conv.0.weight_v"].float(), state["encoder.pos_conv.0.weight_g"].float(), 2)
+        self.G = cfg["conv_pos_groups"]
+        self.Kpos = cfg["conv_pos"]
+        self.pos_w = f(ops.pack_grouped_conv_weight(wpc, self.G))
+        self.pos_b = f(state["encoder.pos_conv.0.bias"])
+        self.layers = []
+        for l in range(n_layers):
+            p = f"encoder.layers.{l}."
+            a = p + "self_attn."
+            w8, b8 = state[a + "grep_linear.weight"].float(), state[a + "grep_linear.bias"].float()
+            self.layers.append(dict(
+                ln1_g=f(state[p + "self_attn_layer_norm.weight"]), ln1_b=f(state[p + "self_attn_layer_norm.bias"]),
+                wqkv=f(torch.cat([state[a + "q_proj.weight"], state[a + "k_proj.weight"], state[a + "v_proj.weight"]], 0)),
+                bqkv=f(torch.cat([state[a + "q_proj.bias"], state[a + "k_proj.bias"], state[a + "v_proj.bias"]], 0)),
+                wo=f(state[a + "out_proj.weight"]), bo=f(state[a + "out_proj.bias"]),
+                gate_w=f(torch.stack([w8[:4].sum(0), w8[4:].sum(0)])), gate_b=f(torch.stack([b8[:4].sum(), b8[4:].sum()])),
+                grep_a=f(state[a + "grep_a"].reshape(-1)),
+                ln2_g=f(state[p + "final_layer_norm.weight"]), ln2_b=f(state[p + "final_layer_norm.bias"]),
+                w1=f(state[p + "fc1.weight"]), b1=f(state[p + "fc1.bias"]),
+                w2=f(state[p + "fc2.weight"]), b2=f(state[p + "fc2.bias"]),
+            ))
+        self.rel_emb = state["encoder.layers.0.self_attn.relative_attention_bias.weight"].detach().float().cpu()
+        self._tables = {}
+
+    # -------------------------------------------------------------------------------------------
+    def n_frames(self, n_samples: int) -> int:
+        n = n_samples
+        for c in self.conv:
+            n = (n - c["k"]) // c["s"] + 1
+        return n
+
+    def _table(self, T: int) -> torch.Tensor:
+        if T not in self._tables:
+            lut = _bucket_lut(T, self.cfg["num_buckets"], self.cfg["max_distance"])
+            self._tables[T] = self.rel_emb[lut].T.contiguous().to(self.device)       # [H, 2T-1]
+        return self._tables[T]
+
+    def encode_batch(self, wav: torch.Tensor) -> torch.Tensor:
+        """[B, L] equal-length (already padded) chunks on the GPU -> [B, T, E]."""
+        B, L = wav.shape
+        dev = wav.device
+        x = wav.contiguous()
+        t_in, cin = L, 1
+        for c in self.conv:
+            t_out = (t_in - c["k"]) // c["s"] + 1
+            y = torch.empty(B * t_out, c["dim"], device=dev, dtype=torch.float32)
+            ops.conv_gemm(x, c["w"], y, m=t_out, n=c["dim"], cin=cin, taps=c["k"], stride=c["s"], t_in=t_in,
+                          batches=B, x_bstride=t_in * cin, o_bstride=t_out * c["dim"])
+            ops.layernorm(y, c["g"], c["b"], gelu=True, out=y)
+            x, t_in, cin = y, t_out, c["dim"]
+        T = t_in
+        feats = ops.layernorm(x, self.ln_g, self.ln_b)
+        x = ops.linear(feats, self.proj_w, self.proj_b)                       # [B*T, E]
+        E, H, G, K = self.E, self.H, self.G, self.Kpos
+        cg = E // G
+        x2 = torch.empty_like(x)
+        ops.conv_gemm(x, self.pos_w, x2, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T, ldx=E, ldo=E,
+                      bias=self.pos_b, act=ops.ACT_GELU, resid=x, ldr=E, batches=B, groups=G,
+                      x_bstride=T * E, x_gstride=cg, w_gstride=cg * cg * K, bias_gstride=cg,
+                      o_bstride=T * E, o_gstride=cg, r_bstride=T * E, r_gstride=cg)
+        x = x2
+        table = self._table(T)
+        for ly in self.layers:
+            xn = ops.layernorm(x, ly["ln1_g"], ly["ln1_b"])
+            gate = ops.wavlm_gate(xn, H, ly["gate_w"], ly["gate_b"], ly["grep_a"])
+            qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"])
+            att = ops.wavlm_attention(qkv, gate, table, B, T, H)
+            x = ops.linear(att, ly["wo"], ly["bo"], resid=x)
+            xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"])
+            hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU)
+            x = ops.linear(hmid, ly["w2"], ly["b2"], resid=x)
+        return x.view(B, T, E)
+
+    def full_features(self, wav_1d: torch.Tensor, max_batch: int = 8) -> torch.Tensor:
+        """One utterance [L] on the GPU -> [T_total, E] (get_full_wavlm_features + layer select)."""
+        plan = chunk_plan(wav_1d.numel())
+        outs = []
+        full = [(s, l, p) for (s, l, p) in plan if l == C.CHUNK_SAMPLES]
+        for i in range(0, len(full), max_batch):
+            grp = full[i:i + max_batch]
+            Lp = C.CHUNK_SAMPLES + grp[0][2]
+            buf = torch.zeros(len(grp), Lp, device=wav_1d.device, dtype=torch.float32)
+            for j, (s, l, _p) in enumerate(grp):
+                buf[j, :l] = wav_1d[s:s + l]
+            outs.append((grp[0][0], self.encode_batch(buf).reshape(-1, self.E)))
+        for (s, l, p) in plan:
+            if l != C.CHUNK_SAMPLES:
+                buf = torch.zeros(1, l + p, device=wav_1d.device, dtype=torch.float32)
+                buf[0, :l] = wav_1d[s:s + l]
+                outs.append((s, self.encode_batch(buf)[0]))
+        outs.sort(key=lambda t: t[0])
+        return torch.cat([o for _s, o in outs], 0)
+
+    def encode_many(self, wavs, max_batch: int = 8):
+        """List of utterances -> list of [T_i, E]; 30 s chunks of ALL utterances are batched together
+        (chunks are independent, ddsp_prematch_dataset.py:275-293)."""
+        jobs = []          # (utt, start, len, pad)
+        for u, w in enumerate(wavs):
+            for (s, l, p) in chunk_plan(w.numel()):
+                jobs.append((u, s, l, p))
+        by_len = {}
+        for j in jobs:
+            by_len.setdefault(j[2] + j[3], []).append(j)
+        pieces = {}
+        for Lp, grp in by_len.items():
+            for i in range(0, len(grp), max_batch):
+                sub = grp[i:i + max_batch]
+                buf = torch.zeros(len(sub), Lp, device=self.device, dtype=torch.float32)
+                for r, (u, s, l, _p) in enumerate(sub):
+                    buf[r, :l] = wavs[u][s:s + l]
+                out = self.encode_batch(buf)
+                for r, (u, s, _l, _p) in enumerate(sub):
+                    pieces[(u, s)] = out[r]
+        res = []
+        for u, w in enumerate(wavs):
+            parts = [pieces[(u, s)] for (s, _l, _p) in chunk_plan(w.numel())]
+            res.append(torch.cat(parts, 0) if parts else torch.empty(0, self.E, device=self.device))
+        return res

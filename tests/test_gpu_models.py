@@ -1,0 +1,175 @@
+"""GPU: model-level parity of the HIP path (through the C ABI) against the golden fixtures
+captured from the reference and against the CPU oracle at full model dimensions."""
+import numpy as np
+import pytest
+import torch
+
+from knn_svc_amd import audio_io, config as C, synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _maxdiff(a, b):
+    return float((a.detach().cpu().double() - _t(b).double()).abs().max())
+
+
+def _rms(a, b):
+    d = a.detach().cpu().double() - _t(b).double()
+    return float(d.pow(2).mean().sqrt())
+
+
+def test_wavlm_tiny_golden(golden):
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g1_wavlm_tiny")
+    cfg = C.WAVLM_TINY
+    sd = S.seeded_state(S.wavlm_param_spec(cfg), int(g["seed"]))
+    wav, _ = S.synth_clip(int(g["n_samples"]), int(g["clip_seed"]))
+    x = torch.from_numpy(np.pad(wav, (0, 320)))[None].to(DEV)
+    for nl in (0, 1, 3):
+        enc = WavLMEncoder(sd, cfg, DEV, n_layers=nl)
+        out = enc.encode_batch(x)[0]
+        d = _maxdiff(out, g[f"layer{nl}"])
+        print(f"tiny WavLM layer {nl}: max|d| {d:.2e}")
+        assert d < 1e-4, (nl, d)
+
+
+def test_wavlm_chunked_golden(golden):
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g1b_wavlm_chunked")
+    cfg = C.WAVLM_TINY
+    sd = S.seeded_state(S.wavlm_param_spec(cfg), int(g["seed"]))
+    wav, _ = S.synth_clip(int(g["n_samples"]), int(g["clip_seed"]))
+    enc = WavLMEncoder(sd, cfg, DEV, n_layers=2)
+    f = enc.full_features(torch.from_numpy(wav).to(DEV))
+    assert f.shape[0] == int(g["n_frames"])
+    assert _maxdiff(f[::10], g["rows"]) < 1e-4
+    many = enc.encode_many([torch.from_numpy(wav).to(DEV), torch.from_numpy(wav[:50000]).to(DEV)])
+    assert torch.equal(many[0], f) and many[1].shape[0] == enc.n_frames(50000 + 320 - 50000 % 320)
+
+
+def test_wavlm_large_one_layer_golden(golden):
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g1c_wavlm_large1")
+    cfg = dict(C.WAVLM_LARGE, encoder_layers=1)
+    sd = S.seeded_state(S.wavlm_param_spec(cfg), int(g["seed"]))
+    wav, _ = S.synth_clip(int(g["n_samples"]), int(g["clip_seed"]))
+    x = torch.from_numpy(np.pad(wav, (0, 320)))[None].to(DEV)
+    for nl in (0, 1):
+        out = WavLMEncoder(sd, cfg, DEV, n_layers=nl).encode_batch(x)[0]
+        d = _maxdiff(out, g[f"layer{nl}"])
+        scale = float(np.abs(g[f"layer{nl}"]).max())
+        print(f"large WavLM layer {nl}: max|d| {d:.2e} (|x|max {scale:.2f})")
+        assert d < 2e-4 * max(1.0, scale)
+
+
+def test_wavlm_large_six_layers_vs_oracle():
+    """Full WavLM-Large dimensions, 6 layers, two 2 s chunks in one batch vs the CPU oracle."""
+    from knn_svc_amd.wavlm import WavLMEncoder
+    from oracle import wavlm_ref
+    cfg = C.WAVLM_LARGE
+    sd = S.seeded_state(S.wavlm_param_spec(cfg, 6), seed=1)
+    w0, _ = S.synth_clip(32000, 11); w1, _ = S.synth_clip(32000, 12)
+    x = torch.from_numpy(np.stack([np.pad(w0, (0, 320)), np.pad(w1, (0, 320))]))
+    ref = wavlm_ref.extract_layer(sd, cfg, x, 6)
+    out = WavLMEncoder(sd, cfg, DEV, n_layers=6).encode_batch(x.to(DEV))
+    d = float((out.cpu() - ref).abs().max())
+    rel = d / float(ref.abs().max())
+    print(f"WavLM-Large 6 layers: max|d| {d:.2e}, relative {rel:.2e}")
+    assert rel < 1e-4
+
+
+def test_vocoder_tiny_golden(golden):
+    from knn_svc_amd.vocoder import Vocoder
+    g = golden("g7_vocoder")
+    h = C.HIFIGAN_TINY
+    c, f0, harm = _t(g["c"]).to(DEV), _t(g["f0"]).to(DEV), _t(g["harm"]).to(DEV)
+    for kind, seed in (("mix", 63), ("f0", 64)):
+        sd = S.seeded_state(S.generator_param_spec(h, kind), seed)
+        y = Vocoder(sd, h, kind, DEV).forward(c, f0, harm if kind == "mix" else None)
+        d, r = _maxdiff(y, g["wave_" + kind]), _rms(y, g["wave_" + kind])
+        print(f"tiny generator {kind}: max|d| {d:.2e} rms {r:.2e}")
+        assert r < 1e-5 and d < 1e-4
+
+
+def test_vocoder_full_vs_oracle():
+    """Full-size 'mix' generator (22.9 M parameters), 24 frames, vs the CPU oracle."""
+    from knn_svc_amd.vocoder import Vocoder
+    from oracle import vocoder_ref
+    h = C.HIFIGAN_V1
+    sd = S.seeded_state(S.generator_param_spec(h, "mix"), 2)
+    g = torch.Generator().manual_seed(3)
+    N = 24
+    c = torch.randn(N, 1024, generator=g)
+    _, f0 = S.synth_clip(N * 320, 5); f0 = torch.from_numpy(f0[:N].copy())
+    harm = torch.rand(N, 49, generator=g) * 0.02
+    ref = vocoder_ref.synthesizer(sd, h, "mix", c[None], f0[None, :, None], harm[None])[0, 0]
+    y = Vocoder(sd, h, "mix", DEV).forward(c.to(DEV), f0.to(DEV), harm.to(DEV))
+    r = float((y.cpu() - ref).pow(2).mean().sqrt())
+    print(f"full generator: rms {r:.2e}, ref rms {float(ref.pow(2).mean().sqrt()):.3f}")
+    assert r < 1e-4
+
+
+def _write_tiny_dataset(tmp_path, g):
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    src_wav, src_f0 = S.synth_clip(3 * 16000 + 77, seed=int(g["src_seed"]))
+    audio_io.write_wav_pcm16(str(tmp_path / "a" / "src.wav"), src_wav, 16000)
+    np.save(tmp_path / "a" / "src_f0.npy", src_f0 * float(g["f0_scale"]))
+    for i in range(3):
+        w, f = S.synth_clip(4 * 16000 + 5 * i, seed=int(g["pool_seed0"]) + i)
+        audio_io.write_wav_pcm16(str(tmp_path / "b" / f"u{i}.wav"), w, 16000)
+        np.save(tmp_path / "b" / f"u{i}_f0.npy", f)
+    return str(tmp_path / "a" / "src.wav"), tmp_path / "b"
+
+
+def test_e2e_tiny_golden(golden, tmp_path):
+    """Files -> match_at_inference_time -> vocode, against the waveform the reference produced (g11)."""
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.matching import match_at_inference_time
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g11_e2e")
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    sdw = S.seeded_state(S.wavlm_param_spec(cfg), seed=11)
+    enc = WavLMEncoder(sdw, cfg, DEV, n_layers=2)
+    srcp, poolp = _write_tiny_dataset(tmp_path, g)
+    for kind, ckpt, post_opt, seed in (("mix", "mix", "no_post_opt", 63), ("mix", "mix", "post_opt_0.2", 63),
+                                       ("f0", "wavlm_only", "no_post_opt", 64)):
+        sdg = S.seeded_state(S.generator_param_spec(h, kind), seed)
+        knn = KNeighborsVC(enc, Vocoder(sdg, h, kind, DEV), h, DEV)
+        if kind == "mix":
+            of, hw, _a, sf0 = match_at_inference_time(srcp, poolp, enc, knn.weighting, knn.weighting, prioritize_f0=True,
+                                                      ckpt_type=ckpt, post_opt=post_opt, tgt_dataset_path=tmp_path,
+                                                      duration_limit=int(g["duration_limit"]))
+            y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None], hw[srcp][None]).squeeze()
+        else:
+            of, _a, sf0 = match_at_inference_time(srcp, poolp, enc, knn.weighting, knn.weighting, prioritize_f0=True,
+                                                  ckpt_type=ckpt, tgt_dataset_path=tmp_path,
+                                                  duration_limit=int(g["duration_limit"]))
+            y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None]).squeeze()
+        ref = g[f"{ckpt}__{post_opt}"]
+        r = _rms(y, ref)
+        print(f"e2e {ckpt} {post_opt}: waveform rms error {r:.2e} (signal rms {float(np.sqrt((ref ** 2).mean())):.3f})")
+        assert y.shape[0] == ref.shape[0]
+        assert r < 1e-4, (ckpt, post_opt, r)      # north-star tolerance: waveform within 1e-4 RMS
+
+
+def test_special_match_writes_reference_named_file(golden, tmp_path):
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g11_e2e")
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+    knn = KNeighborsVC(enc, Vocoder(S.seeded_state(S.generator_param_spec(h, "mix"), 63), h, "mix", DEV), h, DEV)
+    srcp, poolp = _write_tiny_dataset(tmp_path, g)
+    y = knn.special_match(srcp, str(poolp / "u0.wav"), ckpt_type="mix", post_opt="post_opt_0.2")
+    out = tmp_path / "a" / "src_to_u0_knn_mix_post_opt_0.2.wav"
+    assert out.is_file()
+    x, sr = audio_io.read_wav(str(out))
+    assert sr == 16000 and x.shape == (1, y.numel())
+    assert np.max(np.abs(x[0] - np.clip(y.cpu().numpy(), -1, 1))) < 1e-6
