@@ -70,6 +70,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must load ITS bundled HIP runtime first: libknnsvc_hip.so then binds to that same
+    # libamdhip64.so.7 (matched by SONAME).  Loaded the other way round the process ends up with two
+    # HIP runtimes and torch's device pointers / streams mean nothing to ours.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise KnnSvcError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

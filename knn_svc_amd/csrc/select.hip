@@ -9,6 +9,13 @@ __device__ __forceinline__ unsigned f2s(float d) {
     unsigned u = __float_as_uint(d);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// f32 log / exp / log2 evaluated in f64 and rounded once: correctly rounded f32 results.  The
+// reference's values come from the host libm (SLEEF, <= 1 ulp); the shifted f0 feeds a phase
+// integrator in the synthesiser, so every ulp here is worth ~1e-4 cycles after 30 s.
+__device__ __forceinline__ float log_rn(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float exp_rn(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float log2_rn(float x) { return (float)log2((double)x); }
+
 __device__ __forceinline__ float s2f(unsigned s) {
     return __uint_as_float((s & 0x80000000u) ? (s & 0x7FFFFFFFu) : ~s);
 }
@@ -24,7 +31,7 @@ __global__ __launch_bounds__(1024) void log_f0_median_kernel(const float* __rest
     unsigned local = 0;
     for (long i = tid; i < n; i += 1024) {
         const float f = f0[i];
-        if (f != 0.f) { ws[i] = logf(f); ++local; } else ws[i] = __builtin_nanf("");
+        if (f != 0.f) { ws[i] = log_rn(f); ++local; } else ws[i] = __builtin_nanf("");
     }
     atomicAdd(&s_count, local);
     __syncthreads();
@@ -62,7 +69,7 @@ __global__ void shift_f0_kernel(const float* __restrict__ f0, long n, const floa
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float f = f0[i];
-    out[i] = f != 0.f ? expf((logf(f) + pmed[0]) - qmed[0]) : f;
+    out[i] = f != 0.f ? exp_rn((log_rn(f) + pmed[0]) - qmed[0]) : f;
 }
 
 // half a wave (32 lanes) per query row; rank by counting gives torch.sort(stable=True) order
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void f0_rerank_kernel(const long* __restrict__
     if (row >= nq) return;
     const bool act = lane < k;
     const long id = act ? nn[row * k + lane] : 0;
-    const float key = act ? fabsf(log2f(pf0[id] + 1e-5f) - log2f(sf0[row] + 1e-5f)) : __builtin_inff();
+    const float key = act ? fabsf(log2_rn(pf0[id] + 1e-5f) - log2_rn(sf0[row] + 1e-5f)) : __builtin_inff();
     int rank = 0;
     for (int j = 0; j < k; ++j) {
         const float kj = __shfl(key, j, 64);
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void concat_reselect_kernel(
                 const float med = fminf(fmaxf(lo01, lo23), fminf(hi01, hi23));
                 total = w * med + s_match[lane];
                 if (use_f0) {
-                    const float lp = log2f(pf0[s_cand[cur][lane]] + 1e-5f), lq = log2f(sf0[i] + 1e-5f);
+                    const float lp = log2_rn(pf0[s_cand[cur][lane]] + 1e-5f), lq = log2_rn(sf0[i] + 1e-5f);
                     total = total + fabsf(lp - lq);
                 }
             }
