@@ -1,0 +1,275 @@
+"""Headline benchmark: end-to-end kNN-SVC conversion throughput (xRT) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One *step* = one cold conversion per rank on synthetic inputs already resident in HBM:
+WavLM-Large (6 layers) encode of a 10-minute target pool shard (20 x 30 s) and a 30 s source,
+STFT + harmonic amplitudes, cosine kNN top-32 (pool sharded over ranks, RCCL all-gather merge),
+f0 shift / re-rank, concat re-selection, two Adam smoothness loops, additive synth, conditioned
+HiFi-GAN generator ('mix', post_opt_0.2).  Weights are seeded random tensors of the real
+architectures (no network for the released checkpoints).  value = source seconds converted by all
+ranks / wall time of the slowest rank.
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel (fp32-MFMA implicit GEMM, 128x128 tile): algorithmic FLOP
+                 (2*M*N*K per launch) / HIP-event time of those launches inside the timed region,
+                 against the 157.3 TFLOP/s dense fp32 matrix peak;
+  cpu_baseline — the CPU oracle (a port of the reference's --device cpu path) timed on this box's
+                 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from knn_svc_amd import config as C, dist as kdist, ops, synthetic as S      # noqa: E402
+from knn_svc_amd.matching import match_features, side_features               # noqa: E402
+from knn_svc_amd.vocoder import Vocoder                                       # noqa: E402
+from knn_svc_amd.wavlm import WavLMEncoder                                    # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
+SRC_SECONDS = 30
+POOL_CLIPS = 20                        # x 30 s = 10 minutes per rank
+
+
+class GemmTimer:
+    """HIP-event timing of every launch of conv_gemm_kernel<GemmTile<128,128,2,2,2,2>, 4> (the
+    dominant kernel) on the stream it is launched on, plus its algorithmic FLOP."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+        self._orig = ops.conv_gemm
+
+    def install(self):
+        orig = self._orig
+
+        def wrapped(x, w, out, **kw):
+            big = kw["n"] > 64 and kw["cin"] % 4 == 0 and (kw.get("ldx") or kw["cin"]) % 4 == 0
+            if not (self.enabled and big):
+                return orig(x, w, out, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(x, w, out, **kw)
+            e1.record()
+            flop = 2.0 * kw["m"] * kw["n"] * kw["cin"] * kw.get("taps", 1) * kw.get("batches", 1) * kw.get("groups", 1)
+            self.records.append((e0, e1, flop))
+            return r
+        ops.conv_gemm = wrapped
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), ms, fl
+
+
+def make_inputs(rank, dev):
+    n = SRC_SECONDS * C.SAMPLE_RATE
+    src, sf0 = S.synth_clip(n, seed=1000 + rank)
+    pool = [S.synth_clip(30 * C.SAMPLE_RATE, seed=2000 + 100 * rank + i) for i in range(POOL_CLIPS)]
+    g = lambda a: torch.from_numpy(a).to(dev)
+    return g(src), sf0 * 1.3, [g(w) for w, _ in pool], [f for _, f in pool]
+
+
+STAGES = {}
+
+
+class stage:
+    """optional per-stage HIP-event timing (--stages), printed to stderr; not part of the contract line"""
+    on = False
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if stage.on:
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e0.record()
+
+    def __exit__(self, *a):
+        if stage.on:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            STAGES.setdefault(self.name, []).append((self.e0, e1))
+
+
+def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
+    with stage("wavlm"):
+        feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
+    qf = feats[-1]
+    with stage("side_features"):
+        qf0, _, _ = side_features(src, sf0, qf.shape[0])
+        f0s, harms = [], []
+        for w, f, ft in zip(pool_w, pool_f0, feats[:-1]):
+            a, b, _ = side_features(w, f, ft.shape[0])
+            f0s.append(a); harms.append(b)
+        P_loc = torch.cat(feats[:-1]).contiguous()
+    with stage("knn"):
+        nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K)
+    with stage("gather"):
+        P = kdist.all_gather_rows(P_loc)
+        Pf0 = kdist.all_gather_rows(torch.cat(f0s).contiguous())
+        Ph = kdist.all_gather_rows(torch.cat(harms).contiguous())
+    with stage("match"):
+        of, hw, s0, dbg = match_features(qf, qf0, P, Pf0, Ph, "mix", "post_opt_0.2", nn32=nn32, return_debug=True)
+    with stage("vocoder"):
+        y = voc.forward(of, s0, hw)
+    step.last = dict(dbg, q=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, of=of, hw=hw, s0=s0)
+    return y
+
+
+def effective_cores() -> int:
+    """CPUs this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(snap):
+    """CPU port of the reference path (the oracle) timed stage by stage on bounded samples of THIS step's
+    data, scaled to the full step: 1 of 21 WavLM chunks, 300 of 1500 kNN query rows, 150 of 1500 frames of
+    each concat re-selection, 25 Adam iterations of each smoothness loop (scaled to the iteration counts the
+    device loop needed on the same inputs), 2 of 30 s of vocoder.  ~10-30 s of host work in total."""
+    from oracle import knn_ref, select_ref, smooth_ref, synth_ref, vocoder_ref, wavlm_ref
+    cores = effective_cores()
+    torch.set_num_threads(cores)
+    cfg, h = C.WAVLM_LARGE, C.HIFIGAN_V1
+    sdw = S.seeded_state(S.wavlm_param_spec(cfg, 6), seed=1)
+    sdg = S.seeded_state(S.generator_param_spec(h, "mix"), seed=2)
+    t = {}
+
+    def timed(name, scale, fn):
+        t0 = time.time(); r = fn(); t[name] = (time.time() - t0) * scale
+        return r
+    wav = snap["src"]
+    timed("wavlm", 21.0, lambda: wavlm_ref.full_features(sdw, cfg, wav, 6))
+    timed("side", 21.0, lambda: synth_ref.harmonic_amps(synth_ref.stft_mag(wav)[:1500], snap["qf0"]))
+    q, P = snap["q"], snap["P"]
+    timed("knn", 5.0, lambda: knn_ref.knn_topk(q[:300], P, 32))
+    nn32 = snap["nn32"]
+    sh = select_ref.shift_query_f0(snap["qf0"], snap["Pf0"])
+    timed("concat_plain", 10.0, lambda: select_ref.concat_reselect(nn32[:150, :4].clone(), q[:150], P, concat_weight=0.2))
+    rk = select_ref.rerank_by_f0(sh, snap["Pf0"], nn32)
+    timed("concat_f0", 10.0, lambda: select_ref.concat_reselect(rk[:150, :4].clone(), q[:150], P, sh[:150], snap["Pf0"], 0.2))
+    it_w, it_h = max(1, snap["iters_wavlm"]), max(1, snap["iters_harm"])
+    timed("adam_wavlm", it_w / 25.0, lambda: smooth_ref.smooth_weights(snap["idx_wavlm"], P, 0.1, max_iter=25))
+    timed("adam_harm", it_h / 25.0, lambda: smooth_ref.smooth_weights(snap["idx_harm"], snap["Ph"], 1000.0, max_iter=25))
+    n = 100
+    timed("vocoder", 15.0, lambda: vocoder_ref.synthesizer(sdg, h, "mix", snap["of"][:n][None], snap["s0"][:n][None, :, None],
+                                                          snap["hw"][:n][None]))
+    total = sum(t.values())
+    return dict(value=round(SRC_SECONDS / total, 4), unit="x real-time", cores=cores, kind="port",
+                sample="oracle stages on this step's data, scaled: 1/21 WavLM chunks, 300/1500 kNN rows, 150/1500 concat "
+                       f"frames x2, 25 Adam iterations x2 (scaled to {it_w}/{it_h} device iterations), 100/1500 vocoder frames; "
+                       "estimated full-step seconds: " + ", ".join(f"{k} {v:.1f}" for k, v in t.items()) +
+                       f"; torch {torch.__version__} CPU")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--max-batch", type=int, default=8, help="30 s chunks per WavLM batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="print per-stage ms to stderr")
+    a = ap.parse_args()
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if ws > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert a.gpus == ws, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(C.WAVLM_LARGE, 6), seed=1), C.WAVLM_LARGE, dev, 6)
+    voc = Vocoder(S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, "mix"), seed=2), C.HIFIGAN_V1, "mix", dev)
+    src, sf0, pool_w, pool_f0 = make_inputs(rank, dev)
+    timer = GemmTimer()
+    timer.install()
+    stage.on = a.stages
+
+    def barrier():
+        if ws > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        for _ in range(a.warmup):
+            y = step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
+        barrier()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            y = step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
+        barrier()
+        dt = time.perf_counter() - t0
+    assert y.numel() == SRC_SECONDS * C.SAMPLE_RATE, y.numel()          # 1500 frames x 320
+    assert bool(torch.isfinite(y).all()), "non-finite waveform"
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if ws > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    n_launch, gemm_ms, gemm_flop = timer.summary()
+    if a.stages and rank == 0:
+        for k, ev in STAGES.items():
+            ms = [x.elapsed_time(y_) for x, y_ in ev[a.warmup:]]
+            print(f"[stage] {k:14s} {sum(ms) / max(1, len(ms)):9.3f} ms/step", file=sys.stderr)
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = ws * SRC_SECONDS * a.steps / dt
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        line = {
+            "metric": "audio-sec converted/sec (xRT) end-to-end, cold target pool",
+            "value": round(value, 3), "unit": "x real-time", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "north-star point per rank: 30 s source vs 10 min target pool (20 x 30 s), "
+                                   "ckpt_type=mix, post_opt_0.2, cold (pool encoded inside the step); seeded random "
+                                   "weights of WavLM-Large (6 layers executed) and the 22.9 M-param generator",
+                       "nq": 1500, "np_per_rank": 30000, "pool_sharding": f"rows over {ws} rank(s), RCCL all-gather merge",
+                       "wavlm_batch_chunks": a.max_batch},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_gemm_kernel<GemmTile<128,128,2,2,2,2>,4> (fp32 MFMA implicit GEMM)",
+                         "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(1, n_launch), 4),
+                         "kernel_ms_per_step": round(gemm_ms / a.steps, 3)},
+        }
+        line["config"]["adam_iterations"] = [int(step.last["iters_wavlm"]), int(step.last["iters_harm"])]
+        if ws == 1 and not a.no_cpu_baseline:
+            L = step.last
+            c = lambda x: x.detach().cpu()
+            snap = dict(src=c(src), q=c(L["q"]), qf0=c(L["qf0"]), P=c(L["P"]), Pf0=c(L["Pf0"]), Ph=c(L["Ph"]), nn32=c(L["nn32"]),
+                        idx_wavlm=c(L["idx_wavlm"]), idx_harm=c(L["idx_harm"]), of=c(L["of"]), hw=c(L["hw"]), s0=c(L["s0"]),
+                        iters_wavlm=int(L["iters_wavlm"]), iters_harm=int(L["iters_harm"]))
+            line["cpu_baseline"] = cpu_baseline(snap)
+        print(json.dumps(line), flush=True)
+    if ws > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""Multi-GPU layer: pool-row sharding with an RCCL all-gather merge.
+
+The reference is single-device.  Here every rank (one process per GPU, ``torch.distributed``
+backend "nccl" == RCCL over xGMI) owns a contiguous range of pool rows:
+
+  1. queries of all ranks are all-gathered (Nq x 4 KB each — small);
+  2. each rank runs the fused distance/top-k kernel against ITS shard only and reports
+     (distance, global row) lists — no pool bytes cross the fabric for the search;
+  3. one all-gather of the [Nq_total, 32] lists (8 B per entry), then an 8-way merge with the
+     same (distance, lower index) ordering as the single-GPU kernel, so results do not depend
+     on the number of devices;
+  4. the rows the later stages read (selected neighbours and their +/-1 neighbours) are served
+     from an all-gathered copy of the pool features / f0 / harmonics (<= ~200 MB per speaker).
+
+xGMI is point to point (7 links per GPU), so the collectives are plain all-gathers whose
+per-peer messages travel on their own link; there is no ring or tree to tune.
+The local top-k and the merge are injectable so that the sharding logic is testable on CPU
+with gloo (tests/test_dist_cpu.py) — the product path always uses the HIP kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
+    """Concatenate equal-shaped [n, ...] tensors of every rank along dim 0 (rank order)."""
+    _r, ws = world()
+    if ws == 1:
+        return t
+    out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def _hip_local_topk(q, pool, k, offset):
+    from . import ops
+    return ops.knn_topk(q, pool, k, idx_offset=offset)
+
+
+def _hip_merge(part_dist, part_idx):
+    from . import ops
+    return ops.knn_merge(part_dist, part_idx)
+
+
+def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, local_topk=_hip_local_topk,
+                merge=_hip_merge):
+    """Top-k of every rank's queries against the union of all ranks' pool shards.
+
+    q_local [nq, D] (same nq on every rank), pool_local [np, D] (same np on every rank; global row of
+    local row j on rank r is r*np + j).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's
+    queries."""
+    rank, ws = world()
+    if ws == 1:
+        return local_topk(q_local, pool_local, k, 0)
+    nq = q_local.shape[0]
+    q_all = all_gather_rows(q_local)                                           # [ws*nq, D]
+    idx, dst = local_topk(q_all, pool_local, k, rank * pool_local.shape[0])    # vs my shard, global ids
+    dist_all = all_gather_rows(dst[None])                                      # [ws, ws*nq, k]
+    idx_all = all_gather_rows(idx[None])
+    mine = slice(rank * nq, (rank + 1) * nq)
+    return merge(dist_all[:, mine].contiguous(), idx_all[:, mine].contiguous())

@@ -103,20 +103,26 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
 
 
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
-                   return_debug=False):
-    """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors."""
+                   return_debug=False, nn32=None):
+    """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors.  ``nn32`` may carry
+    neighbours already found by the pool-sharded search (knn_svc_amd.dist.sharded_knn)."""
     q = query_seq.contiguous()
     P = matching_list
     qn, qs = ops.row_norms(q)
     pn, ps = ops.row_norms(P)
-    nn32, _ = ops.knn_topk(q, P, C.KNN_K, q_stats=(qn, qs), p_stats=(pn, ps))
+    if nn32 is None:
+        nn32, _ = ops.knn_topk(q, P, C.KNN_K, q_stats=(qn, qs), p_stats=(pn, ps))
     qmed, pmed = ops.log_f0_median(query_f0), ops.log_f0_median(matching_f0)
     shifted = ops.shift_f0(query_f0, qmed, pmed)
     cw, run_adam = parse_post_opt(post_opt)
     idx = nn32[:, :C.KNN_USE].contiguous()
     if cw != -1:
         idx = ops.concat_reselect(idx, q, qn, P, pn, concat_weight=cw)
-    w = ops.smooth_weights(idx, P, 0.1) if run_adam else None
+    it1 = it2 = None
+    if run_adam:
+        w, it1 = ops.smooth_weights(idx, P, 0.1, return_iters=True)
+    else:
+        w = None
     out_feats = ops.weighted_gather(idx, w, P)
     ranked = ops.f0_rerank(nn32, shifted, matching_f0)
     idx2 = ranked[:, :C.KNN_USE].contiguous()
@@ -125,10 +131,13 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
     harm_w = None
     w2 = None
     if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type:
-        w2 = ops.smooth_weights(idx2, harmonics_list, 1000.0) if run_adam else None
+        if run_adam:
+            w2, it2 = ops.smooth_weights(idx2, harmonics_list, 1000.0, return_iters=True)
         harm_w = ops.weighted_gather(idx2, w2, harmonics_list)
     if return_debug:
-        return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2)
+        return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2,
+                                                iters_wavlm=it1 if it1 is not None else 0,
+                                                iters_harm=it2 if it2 is not None else 0)
     return out_feats, harm_w, shifted
 
 

@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/knnsvc_hip.h declares
+(no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "knnsvc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(knnsvc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from knn_svc_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.knnsvc_abi_version() == _lib.ABI_VERSION
+    assert lib.knnsvc_knn_workspace_bytes(1500, 30000, 32) > 0
+    assert lib.knnsvc_smooth_workspace_bytes(1500) > 0
+
+
+def test_conv_desc_layout_matches_header():
+    """ctypes.Structure field order/types mirror struct knnsvc_conv_desc (checked by size: 4- and 8-byte
+    members with natural alignment give the same total on both sides)."""
+    from knn_svc_amd._lib import ConvDesc
+    src = open(os.path.join(ROOT, "include", "knnsvc_hip.h")).read()
+    body = re.search(r"typedef struct knnsvc_conv_desc \{(.*?)\} knnsvc_conv_desc;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"(const float\*|float\*|int64_t|int32_t|float)\s+(\w+)$", decl)
+        assert m, decl
+        fields.append((m.group(2), m.group(1)))
+    assert [f for f, _ in fields] == [f for f, _ in ConvDesc._fields_]
+    cmap = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int64_t": ctypes.c_int64,
+            "int32_t": ctypes.c_int32, "float": ctypes.c_float}
+    for (name, ctype), (pname, ptype) in zip(fields, ConvDesc._fields_):
+        assert cmap[ctype] is ptype, (name, ctype, ptype)
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from knn_svc_amd import ops
+    from knn_svc_amd._lib import KnnSvcError
+    with pytest.raises(KnnSvcError):
+        ops.knn_topk(torch.zeros(4, 8), torch.zeros(8, 8), 2)
+
+
+def test_cli_flags_match_reference_surface():
+    from knn_svc_amd.inference import build_parser, output_dir_for
+    a = build_parser().parse_args(["s", "t"])
+    assert (a.ckpt_type, a.post_opt, a.topk, a.device, a.prioritize_f0, a.tgt_loudness_db, a.dur_limit) == \
+        ("mix", "no_post_opt", 4, "cuda", True, -16, None)
+    assert output_dir_for("/d/A", "/d/B", "mix", "post_opt_0.2", None) == "/d/A_to_B_mix_post_opt_post_opt_0.2/"
+    assert output_dir_for("/d/A", "/d/B", "mix", "no_post_opt", 600).startswith("/d/duration_limit_600_A_to_B")
+
+
+def test_packers_roundtrip():
+    import torch
+    import torch.nn.functional as F
+    from knn_svc_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(6, 4, 5, generator=g)
+    x = torch.randn(1, 4, 20, generator=g)
+    ref = F.conv1d(x, w, padding=2)[0].T
+    wp = ops.pack_conv_weight(w)                                  # [6, 5*4]
+    cols = torch.stack([F.pad(x[0].T, (0, 0, 2, 2))[t:t + 5].reshape(-1) for t in range(20)])
+    assert torch.allclose(cols @ wp.T, ref, atol=1e-5)
+    wt = torch.randn(4, 3, 6, generator=g)                        # ConvTranspose1d [Cin, Cout, k], u = 2 -> 3 taps
+    u, pad, R = 2, 2, 3
+    yt = F.conv_transpose1d(x, wt, stride=u, padding=pad)[0].T    # [40, 3]
+    assert yt.shape[0] == 20 * u
+    wpt = ops.pack_convT_weight(wt, u)                            # [u*3, R*4]
+    xz = torch.cat([torch.zeros(R, 4), x[0].T, torch.zeros(R, 4)])           # x[q] lives at row q + R
+    out = torch.zeros(20 * u, 3)
+    for q in range(20 + R - 1):
+        a = torch.cat([xz[q + R - r] for r in range(R)])          # taps r: x[q - r]
+        row = (wpt @ a).reshape(u, 3)
+        for ph in range(u):
+            o = q * u + ph - pad
+            if 0 <= o < 20 * u:
+                out[o] = row[ph]
+    assert torch.allclose(out, yt, atol=1e-5)

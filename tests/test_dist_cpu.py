@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: pool-row sharding + all-gather merge gives the single-process result.
+The local top-k / merge are the oracle here (no GPU in this container); on the GPU box the same
+``sharded_knn`` runs with the HIP kernels (tests/test_gpu_kernels.py::test_knn_shard_merge_equals_single)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cpu_local_topk(q, pool, k, offset):
+    from oracle import knn_ref
+    idx, d = knn_ref.knn_topk(q, pool, k)
+    return idx + offset, d
+
+
+def _cpu_merge(part_dist, part_idx):
+    parts, nq, k = part_dist.shape
+    d = part_dist.permute(1, 0, 2).reshape(nq, parts * k)
+    i = part_idx.permute(1, 0, 2).reshape(nq, parts * k)
+    # (distance, lower index) lexicographic order == the HIP kernels' packed-key order
+    order = torch.argsort(i, dim=1, stable=True)
+    d, i = d.gather(1, order), i.gather(1, order)
+    order = torch.argsort(d, dim=1, stable=True)[:, :k]
+    return i.gather(1, order), d.gather(1, order)
+
+
+def _worker(rank, ws, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from knn_svc_amd import dist as kd, synthetic as S
+    pool = S.clustered_features(600, 64, 7, n_centres=12)
+    npr = 300
+    q = S.clustered_features(40, 64, 100 + rank, n_centres=12)
+    idx, d = kd.sharded_knn(q, pool[rank * npr:(rank + 1) * npr].contiguous(), 8, _cpu_local_topk, _cpu_merge)
+    ref_i, ref_d = _cpu_local_topk(q, pool, 8, 0)
+    ok = bool(torch.equal(d, ref_d)) and bool((idx == ref_i).float().mean() > 0.99)
+    gathered = kd.all_gather_rows(torch.full((2, 3), float(rank)))
+    ok = ok and gathered.shape == (4, 3) and float(gathered[2, 0]) == 1.0
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_sharded_knn_gloo_world2():
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out[0] and out[1]
+
+
+def test_single_process_passthrough():
+    sys.path.insert(0, ROOT)
+    from knn_svc_amd import dist as kd, synthetic as S
+    q = S.clustered_features(10, 64, 1, n_centres=4); p = S.clustered_features(100, 64, 2, n_centres=4)
+    idx, d = kd.sharded_knn(q, p, 8, _cpu_local_topk, _cpu_merge)
+    ref_i, ref_d = _cpu_local_topk(q, p, 8, 0)
+    assert torch.equal(idx, ref_i) and torch.equal(d, ref_d)
