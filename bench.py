@@ -62,13 +62,13 @@ class GemmTimer:
             r = orig(x, w, out, **kw)
             e1.record()
             flop = 2.0 * kw["m"] * kw["n"] * kw["cin"] * kw.get("taps", 1) * kw.get("batches", 1) * kw.get("groups", 1)
-            self.records.append((e0, e1, flop))
+            self.records.append((e0, e1, flop, (kw["m"], kw["n"], kw["cin"] * kw.get("taps", 1), kw.get("batches", 1) * kw.get("groups", 1))))
             return r
         ops.conv_gemm = wrapped
 
     def summary(self):
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
         return len(self.records), ms, fl
 
 
@@ -234,6 +234,12 @@ def main():
     dt = float(tmax.item())
     n_launch, gemm_ms, gemm_flop = timer.summary()
     if a.stages and rank == 0:
+        agg = {}
+        for e0, e1, fl, shp in timer.records:
+            t = agg.setdefault(shp, [0, 0.0, 0.0]); t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
+        for shp, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"[gemm] m={shp[0]:7d} n={shp[1]:5d} k={shp[2]:5d} z={shp[3]:3d}  x{cnt // a.steps:3d}/step  {ms / a.steps:8.3f} ms/step  {fl / ms / 1e9:7.1f} TFLOP/s",
+                  file=sys.stderr)
         for k, ev in STAGES.items():
             ms = [x.elapsed_time(y_) for x, y_ in ev[a.warmup:]]
             print(f"[stage] {k:14s} {sum(ms) / max(1, len(ms)):9.3f} ms/step", file=sys.stderr)

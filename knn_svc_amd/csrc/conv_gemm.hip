@@ -58,6 +58,10 @@ struct ALoader {
                 if (ke < K && row >= 0 && row < t_in) v[e] = x[(long)row * ldx + cc];
             }
         }
+        return v;
+    }
+    // prologue activation, applied when the slab is written to LDS (keeps the global load in flight)
+    __device__ __forceinline__ f32x4 finish(f32x4 v) const {
         if (slope != 1.0f) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], slope);

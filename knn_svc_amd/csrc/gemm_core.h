@@ -29,15 +29,24 @@ struct GemmTile {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 
     // aload(kt, j) -> f32x4 for row (tid>>3) + 32*j, k = kt*32 + (tid&7)*4 ; same for bload.
+    // LDS pointers are kept in address space 3 explicitly: through generic pointers hipcc emits
+    // flat_load/flat_store for the staging buffers and then waits vmcnt(0) in front of every MFMA
+    // group, which also drains the NEXT slab's global prefetch (measured: 82 -> see DESIGN.md).
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+
+    // aload(kt, j) -> f32x4 for row (tid>>3) + 32*j, k = kt*32 + (tid&7)*4 ; same for bload.
+    // aload.finish(v) is applied when the registers are written to LDS (prologue activation), so
+    // that nothing has to wait on the global load right after issuing it.
     template <class ALoad, class BLoad>
-    __device__ __forceinline__ static void mainloop(float* lds, int nk, ALoad& aload, BLoad& bload,
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, BLoad& bload,
                                                     f32x16 (&acc)[TM][TN]) {
+        lds_f* lds = (lds_f*)lds_generic;
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WN, wn = wave % WN;
         const int srow = tid >> 3, skq = (tid & 7) * 4;
-        float* As[2] = {lds, lds + (BM + BN) * LDK};
-        float* Bs[2] = {lds + BM * LDK, lds + (BM + BN) * LDK + BM * LDK};
+        constexpr int BUF = (BM + BN) * LDK;          // floats per staging buffer: [A rows | B rows]
 
         f32x4 ra[A_F4], rb[B_F4];
 #pragma unroll
@@ -45,14 +54,16 @@ struct GemmTile {
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) rb[j] = bload(0, j);
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j) *(f32x4*)&As[0][(srow + 32 * j) * LDK + skq] = ra[j];
+        for (int j = 0; j < A_F4; ++j) *(lds_f4*)&lds[(srow + 32 * j) * LDK + skq] = aload.finish(ra[j]);
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) *(f32x4*)&Bs[0][(srow + 32 * j) * LDK + skq] = rb[j];
+        for (int j = 0; j < B_F4; ++j) *(lds_f4*)&lds[BM * LDK + (srow + 32 * j) * LDK + skq] = rb[j];
         __syncthreads();
 
         const int li = lane & 31, lh = lane >> 5;
+        const int a_frag = (wm * TM * 32 + li) * LDK + lh * 4;
+        const int b_frag = BM * LDK + (wn * TN * 32 + li) * LDK + lh * 4;
         for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
+            const int cur = (kt & 1) * BUF;
             const bool more = (kt + 1 < nk);
             if (more) {
 #pragma unroll
@@ -60,15 +71,13 @@ struct GemmTile {
 #pragma unroll
                 for (int j = 0; j < B_F4; ++j) rb[j] = bload(kt + 1, j);
             }
-            const float* a_base = &As[cur][(wm * TM * 32 + li) * LDK + lh * 4];
-            const float* b_base = &Bs[cur][(wn * TN * 32 + li) * LDK + lh * 4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(a_base + i * 32 * LDK + g * 8);
+                for (int i = 0; i < TM; ++i) fa[i] = *(const lds_f4*)&lds[cur + a_frag + i * 32 * LDK + g * 8];
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[i] = *(const f32x4*)(b_base + i * 32 * LDK + g * 8);
+                for (int i = 0; i < TN; ++i) fb[i] = *(const lds_f4*)&lds[cur + b_frag + i * 32 * LDK + g * 8];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -78,11 +87,11 @@ struct GemmTile {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
             }
             if (more) {
-                const int nxt = cur ^ 1;
+                const int nxt = BUF - cur;
 #pragma unroll
-                for (int j = 0; j < A_F4; ++j) *(f32x4*)&As[nxt][(srow + 32 * j) * LDK + skq] = ra[j];
+                for (int j = 0; j < A_F4; ++j) *(lds_f4*)&lds[nxt + (srow + 32 * j) * LDK + skq] = aload.finish(ra[j]);
 #pragma unroll
-                for (int j = 0; j < B_F4; ++j) *(f32x4*)&Bs[nxt][(srow + 32 * j) * LDK + skq] = rb[j];
+                for (int j = 0; j < B_F4; ++j) *(lds_f4*)&lds[nxt + BM * LDK + (srow + 32 * j) * LDK + skq] = rb[j];
             }
             __syncthreads();
         }

@@ -63,6 +63,7 @@ struct RowLoader {      // rows of a [rows][dim] row-major matrix, 16-byte vecto
         if (r < rows && k < dim) v = *(const f32x4*)(base + r * dim + k);
         return v;
     }
+    __device__ __forceinline__ f32x4 finish(f32x4 v) const { return v; }
 };
 
 constexpr int LDD = 128;                                  // distance tile pitch
