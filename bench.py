@@ -48,28 +48,32 @@ class GemmTimer:
     def __init__(self):
         self.records = []
         self.enabled = False
+        self.all_variants = False
         self._orig = ops.conv_gemm
 
     def install(self):
         orig = self._orig
 
         def wrapped(x, w, out, **kw):
-            big = kw["n"] > 64 and kw["cin"] % 4 == 0 and (kw.get("ldx") or kw["cin"]) % 4 == 0
-            if not (self.enabled and big):
+            vec4 = kw["cin"] % 4 == 0 and (kw.get("ldx") or kw["cin"]) % 4 == 0
+            big = kw["n"] > 64 and vec4
+            if not (self.enabled and (big or self.all_variants)):
                 return orig(x, w, out, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(x, w, out, **kw)
             e1.record()
             flop = 2.0 * kw["m"] * kw["n"] * kw["cin"] * kw.get("taps", 1) * kw.get("batches", 1) * kw.get("groups", 1)
-            self.records.append((e0, e1, flop, (kw["m"], kw["n"], kw["cin"] * kw.get("taps", 1), kw.get("batches", 1) * kw.get("groups", 1))))
+            var = ("G128" if kw["n"] > 64 else "G64" if kw["n"] > 32 else "G32") + ("v4" if vec4 else "v1")
+            self.records.append((e0, e1, flop, (kw["m"], kw["n"], kw["cin"] * kw.get("taps", 1), kw.get("batches", 1) * kw.get("groups", 1)), var))
             return r
         ops.conv_gemm = wrapped
 
     def summary(self):
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        fl = sum(r[2] for r in self.records)
-        return len(self.records), ms, fl
+        dom = [r for r in self.records if r[4] == "G128v4"]
+        ms = sum(r[0].elapsed_time(r[1]) for r in dom)
+        fl = sum(r[2] for r in dom)
+        return len(dom), ms, fl
 
 
 def make_inputs(rank, dev):
@@ -210,6 +214,7 @@ def main():
     timer = GemmTimer()
     timer.install()
     stage.on = a.stages
+    timer.all_variants = a.stages
 
     def barrier():
         if ws > 1:
@@ -235,10 +240,10 @@ def main():
     n_launch, gemm_ms, gemm_flop = timer.summary()
     if a.stages and rank == 0:
         agg = {}
-        for e0, e1, fl, shp in timer.records:
-            t = agg.setdefault(shp, [0, 0.0, 0.0]); t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
+        for e0, e1, fl, shp, var in timer.records:
+            t = agg.setdefault((var,) + shp, [0, 0.0, 0.0]); t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl
         for shp, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print(f"[gemm] m={shp[0]:7d} n={shp[1]:5d} k={shp[2]:5d} z={shp[3]:3d}  x{cnt // a.steps:3d}/step  {ms / a.steps:8.3f} ms/step  {fl / ms / 1e9:7.1f} TFLOP/s",
+            print(f"[gemm] {shp[0]:6s} m={shp[1]:7d} n={shp[2]:5d} k={shp[3]:5d} z={shp[4]:3d}  x{cnt // a.steps:3d}/step  {ms / a.steps:8.3f} ms/step  {fl / ms / 1e9:7.1f} TFLOP/s",
                   file=sys.stderr)
         for k, ev in STAGES.items():
             ms = [x.elapsed_time(y_) for x, y_ in ev[a.warmup:]]

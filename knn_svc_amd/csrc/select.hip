@@ -217,6 +217,200 @@ __global__ __launch_bounds__(256) void concat_reselect_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant (feature dim <= 1024): 8 waves, one per candidate.  Everything frame i needs is
+// already in LDS when the frame starts: its 4 kNN rows and q[i] were prefetched during frame i-1,
+// and the "previous selection + 1" rows come from a speculative prefetch of the successors of ALL
+// eight candidates of frame i-1 (4 of them are used).  The global loads of frame i+1 are issued
+// at the top of frame i and land behind the distance reductions, so no frame waits on HBM/L2.
+//   LDS rows: A[2][4] kNN rows | S[2][8] successor rows | P[4] previous selection | Q[2] queries.
+// ---------------------------------------------------------------------------------------------
+constexpr int CT = 512;
+
+__global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
+    const long* __restrict__ idx_in, const float* __restrict__ q, const float* __restrict__ qn, long nq,
+    const float* __restrict__ pool, const float* __restrict__ pn, long np, int dim,
+    const float* __restrict__ sf0, const float* __restrict__ pf0, int use_f0, float concat_weight,
+    long* __restrict__ idx_out) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    typedef __attribute__((address_space(3))) float lf;
+    typedef __attribute__((address_space(3))) f32x4 lf4;
+    lf* L = (lf*)sm;
+    const int D = dim;
+    const int offA = 0, offS = 8 * D, offP = 24 * D, offQ = 28 * D;      // floats
+    __shared__ long s_idA[2][4], s_idS[2][8], s_idP[4];
+    __shared__ float s_pnA[2][4], s_pnS[2][8], s_pnP[4], s_qn[2], s_f0A[2][4], s_f0S[2][8], s_sf0[2];
+    __shared__ int s_slot[2][4];           // slots (0..7) of the kept candidates of frame i, i&1
+    __shared__ float s_match[NC], s_cc[KC][NC], s_base, s_w;
+    __shared__ long s_cand[NC];
+    __shared__ float s_cpn[NC], s_cf0[NC];
+    __shared__ int s_coff[NC];             // LDS float offset of each candidate row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = (tid & 255) * 4;       // 256 threads cover one 1024-float row with float4
+    const int half = tid >> 8;             // two rows per pass
+    const bool colok = col < D;
+
+    // ---- frame 0 ---------------------------------------------------------------------------------
+    if (tid < 4) {
+        const long id = idx_in[tid];
+        idx_out[tid] = id;
+        s_idP[tid] = id; s_pnP[tid] = pn[id];
+        long sid = id + 1; if (sid >= np) sid = np - 1;
+        s_idS[0][tid] = sid; s_pnS[0][tid] = pn[sid]; s_f0S[0][tid] = use_f0 ? pf0[sid] : 0.f;
+        s_slot[0][tid] = tid;
+        if (nq > 1) { const long a = idx_in[4 + tid]; s_idA[1][tid] = a; s_pnA[1][tid] = pn[a]; s_f0A[1][tid] = use_f0 ? pf0[a] : 0.f; }
+    }
+    if (tid == 0) {
+        s_w = concat_weight; s_qn[0] = qn[0];
+        if (nq > 1) { s_qn[1] = qn[1]; s_sf0[1] = use_f0 ? sf0[1] : 0.f; }
+    }
+    __syncthreads();
+    if (colok) {
+        for (int r = half; r < 4; r += 2) {
+            *(lf4*)&L[offP + r * D + col] = *(const f32x4*)(pool + s_idP[r] * (long)D + col);
+            *(lf4*)&L[offS + r * D + col] = *(const f32x4*)(pool + s_idS[0][r] * (long)D + col);
+            if (nq > 1) *(lf4*)&L[offA + (4 + r) * D + col] = *(const f32x4*)(pool + s_idA[1][r] * (long)D + col);
+        }
+        if (half == 0) *(lf4*)&L[offQ + col] = *(const f32x4*)(q + col);
+        else if (nq > 1) *(lf4*)&L[offQ + D + col] = *(const f32x4*)(q + (long)D + col);
+    }
+    __syncthreads();
+
+    for (long i = 1; i < nq; ++i) {
+        const int cur = (int)(i & 1), prv = cur ^ 1;
+        // candidate table of this frame
+        if (tid < NC) {
+            long id; float nrm, f; int off;
+            if (tid < KC) { id = s_idA[cur][tid]; nrm = s_pnA[cur][tid]; f = s_f0A[cur][tid]; off = offA + (cur * 4 + tid) * D; }
+            else {
+                const int sl = s_slot[prv][tid - KC];
+                id = s_idS[prv][sl]; nrm = s_pnS[prv][sl]; f = s_f0S[prv][sl]; off = offS + (prv * 8 + sl) * D;
+            }
+            s_cand[tid] = id; s_cpn[tid] = nrm; s_cf0[tid] = f; s_coff[tid] = off;
+        }
+        __syncthreads();
+        // ---- (a) prefetch for frame i+1 into registers: 4 kNN rows, q[i+1], 8 successor rows --------
+        const bool more = (i + 1 < nq);
+        f32x4 pre[7];
+        long my_id = 0; float my_pn = 0.f, my_f0 = 0.f; int my_kind = -1;   // per-thread scalar prefetch (tid < 13)
+        {
+            // row list r = 0..12: 0-3 -> A[i+1], 4 -> q[i+1], 5-12 -> successors of cand[0..7]
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int r = 2 * t + half;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (colok && r < 13) {
+                    if (r < 4) { if (more) v = *(const f32x4*)(pool + idx_in[(i + 1) * KC + r] * (long)D + col); }
+                    else if (r == 4) { if (more) v = *(const f32x4*)(q + (i + 1) * (long)D + col); }
+                    else { long sid = s_cand[r - 5] + 1; if (sid >= np) sid = np - 1; v = *(const f32x4*)(pool + sid * (long)D + col); }
+                }
+                pre[t] = v;
+            }
+            if (tid < 13) {
+                if (tid < 4) { if (more) { my_id = idx_in[(i + 1) * KC + tid]; my_pn = pn[my_id]; my_f0 = use_f0 ? pf0[my_id] : 0.f; my_kind = 0; } }
+                else if (tid == 4) { if (more) { my_pn = qn[i + 1]; my_f0 = use_f0 ? sf0[i + 1] : 0.f; my_kind = 1; } }
+                else { long sid = s_cand[tid - 5] + 1; if (sid >= np) sid = np - 1; my_id = sid; my_pn = pn[sid]; my_f0 = use_f0 ? pf0[sid] : 0.f; my_kind = 2; }
+            }
+        }
+        // ---- (b) distances: wave b owns candidate b ---------------------------------------------------
+        {
+            const int coff = s_coff[wave];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
+            for (int c = lane * 4; c < D; c += 256) {
+                const f32x4 cv = *(const lf4*)&L[coff + c];
+                const f32x4 qv = *(const lf4*)&L[offQ + cur * D + c];
+                const f32x4 p0 = *(const lf4*)&L[offP + c], p1 = *(const lf4*)&L[offP + D + c];
+                const f32x4 p2 = *(const lf4*)&L[offP + 2 * D + c], p3 = *(const lf4*)&L[offP + 3 * D + c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d;
+                    d = qv[e] - cv[e]; a0 += d * d;
+                    d = p0[e] - cv[e]; a1 += d * d;
+                    d = p1[e] - cv[e]; a2 += d * d;
+                    d = p2[e] - cv[e]; a3 += d * d;
+                    d = p3[e] - cv[e]; a4 += d * d;
+                }
+                if (wave == 0) {
+                    const f32x4 qp = *(const lf4*)&L[offQ + prv * D + c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = qp[e] - qv[e]; a5 += d * d; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+                a3 += __shfl_xor(a3, o, 64); a4 += __shfl_xor(a4, o, 64);
+                if (wave == 0) a5 += __shfl_xor(a5, o, 64);
+            }
+            if (lane == 0) {
+                const float cn = s_cpn[wave];
+                s_match[wave] = cos_from_cd(a0, s_qn[cur], cn);
+                s_cc[0][wave] = cos_from_cd(a1, s_pnP[0], cn);
+                s_cc[1][wave] = cos_from_cd(a2, s_pnP[1], cn);
+                s_cc[2][wave] = cos_from_cd(a3, s_pnP[2], cn);
+                s_cc[3][wave] = cos_from_cd(a4, s_pnP[3], cn);
+                if (wave == 0) s_base = cos_from_cd(a5, s_qn[prv], s_qn[cur]) * 2.0f;
+            }
+        }
+        __syncthreads();
+        // ---- (c) costs, lower median over the previous selection, 4 smallest -------------------------
+        if (wave == 0) {
+            float total = __builtin_inff();
+            const float base = s_base;
+            float w = s_w;
+            if (use_f0 && !(base < 0.08f)) w = 0.f;
+            if (lane < NC) {
+                float c4[KC];
+#pragma unroll
+                for (int a = 0; a < KC; ++a) {
+                    float c = s_cc[a][lane];
+                    if (use_f0) { if (base < 0.08f && c < 5.0f * base) c = 0.f; }
+                    else if (c > base) c = 1.5f * c - base;
+                    c4[a] = c;
+                }
+                const float lo01 = fminf(c4[0], c4[1]), hi01 = fmaxf(c4[0], c4[1]);
+                const float lo23 = fminf(c4[2], c4[3]), hi23 = fmaxf(c4[2], c4[3]);
+                const float med = fminf(fmaxf(lo01, lo23), fminf(hi01, hi23));
+                total = w * med + s_match[lane];
+                if (use_f0) total = total + fabsf(log2_rn(s_cf0[lane] + 1e-5f) - log2_rn(s_sf0[cur] + 1e-5f));
+            }
+            int rank = 0;
+            for (int j = 0; j < NC; ++j) {
+                const float tj = __shfl(total, j, 64);
+                rank += (tj < total || (tj == total && j < lane)) ? 1 : 0;
+            }
+            if (lane < NC && rank < KC) { s_slot[cur][rank] = lane; idx_out[i * KC + rank] = s_cand[lane]; }
+            if (lane == 0) s_w = w;
+        }
+        __syncthreads();
+        // ---- (d) kept rows -> P, prefetched registers -> A[next], Q[next], S[cur] -----------------------
+        f32x4 keep[2];
+        if (colok) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) keep[t] = *(const lf4*)&L[s_coff[s_slot[cur][2 * t + half]] + col];
+        }
+        if (colok) {                        // P is only read in (b); kept rows live in A[cur] / S[prv], not written here
+#pragma unroll
+            for (int t = 0; t < 2; ++t) *(lf4*)&L[offP + (2 * t + half) * D + col] = keep[t];
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int r = 2 * t + half;
+                if (r < 4) { if (more) *(lf4*)&L[offA + (prv * 4 + r) * D + col] = pre[t]; }
+                else if (r == 4) { if (more) *(lf4*)&L[offQ + prv * D + col] = pre[t]; }
+                else if (r < 13) *(lf4*)&L[offS + (cur * 8 + (r - 5)) * D + col] = pre[t];
+            }
+        }
+        if (tid < 4) { const int sl = s_slot[cur][tid]; s_idP[tid] = s_cand[sl]; s_pnP[tid] = s_cpn[sl]; }
+        if (my_kind == 0) { s_idA[prv][tid] = my_id; s_pnA[prv][tid] = my_pn; s_f0A[prv][tid] = my_f0; }
+        else if (my_kind == 1) { s_qn[prv] = my_pn; s_sf0[prv] = my_f0; }
+        else if (my_kind == 2) { s_idS[cur][tid - 5] = my_id; s_pnS[cur][tid - 5] = my_pn; s_f0S[cur][tid - 5] = my_f0; }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int knnsvc_log_f0_median(const float* f0, int64_t n, float* result, float* workspace, void* stream) {
@@ -250,6 +444,20 @@ extern "C" int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, con
     KN_REQUIRE(nq > 0 && np > 0 && dim > 0 && dim % 4 == 0, "concat_reselect: bad sizes");
     KN_REQUIRE(!use_f0 || (shifted_f0 && pool_f0), "concat_reselect: f0 variant needs both f0 arrays");
     KN_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)pool & 15) == 0, "concat_reselect: 16-byte alignment");
+    if (dim <= 1024) {
+        const size_t pl = (size_t)30 * dim * 4;
+        static size_t pattr = 0;
+        if (pl > pattr) {
+            if (hipFuncSetAttribute((const void*)concat_reselect_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)pl) != hipSuccess)
+                return knnsvc_fail(KNNSVC_EHIP, "concat_reselect: hipFuncSetAttribute failed");
+            pattr = pl;
+        }
+        hipLaunchKernelGGL(concat_reselect_pipe_kernel, dim3(1), dim3(CT), pl, (hipStream_t)stream, (const long*)idx_in, q,
+                           q_norm, (long)nq, pool, p_norm, (long)np, dim, shifted_f0, pool_f0, use_f0, concat_weight,
+                           (long*)idx_out);
+        return knnsvc_check_launch("concat_reselect_pipe");
+    }
     const size_t lds = (size_t)(2 * NC + 2) * dim * 4;
     KN_REQUIRE(lds <= 150 * 1024, "concat_reselect: feature dim too large for LDS");
     static size_t attr = 0;

@@ -102,6 +102,16 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     return matching, synth, audio, specs, f0p, harmp
 
 
+_SIDE = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key)
+    return _SIDE[key]
+
+
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
                    return_debug=False, nn32=None):
     """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors.  ``nn32`` may carry
@@ -112,28 +122,37 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
     pn, ps = ops.row_norms(P)
     if nn32 is None:
         nn32, _ = ops.knn_topk(q, P, C.KNN_K, q_stats=(qn, qs), p_stats=(pn, ps))
-    qmed, pmed = ops.log_f0_median(query_f0), ops.log_f0_median(matching_f0)
-    shifted = ops.shift_f0(query_f0, qmed, pmed)
     cw, run_adam = parse_post_opt(post_opt)
+    with_harm = "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type
+    # The WavLM-feature branch (concat re-selection -> Adam -> weighted sum) and the pitched branch
+    # (f0 shift -> re-rank -> concat re-selection -> Adam on harmonics) only share nn32, and each is a
+    # chain of single-workgroup latency-bound kernels: run them on two HIP streams.
+    main = torch.cuda.current_stream()
+    side = _side_stream(q.device)
+    side.wait_stream(main)
+    it1 = it2 = None
+    w = w2 = harm_w = None
+    with torch.cuda.stream(side):
+        qmed, pmed = ops.log_f0_median(query_f0), ops.log_f0_median(matching_f0)
+        shifted = ops.shift_f0(query_f0, qmed, pmed)
+        ranked = ops.f0_rerank(nn32, shifted, matching_f0)
+        idx2 = ranked[:, :C.KNN_USE].contiguous()
+        if cw != -1:
+            idx2 = ops.concat_reselect(idx2, q, qn, P, pn, shifted, matching_f0, concat_weight=cw)
+        if with_harm:
+            if run_adam:
+                w2, it2 = ops.smooth_weights(idx2, harmonics_list, 1000.0, return_iters=True)
+            harm_w = ops.weighted_gather(idx2, w2, harmonics_list)
     idx = nn32[:, :C.KNN_USE].contiguous()
     if cw != -1:
         idx = ops.concat_reselect(idx, q, qn, P, pn, concat_weight=cw)
-    it1 = it2 = None
     if run_adam:
         w, it1 = ops.smooth_weights(idx, P, 0.1, return_iters=True)
-    else:
-        w = None
     out_feats = ops.weighted_gather(idx, w, P)
-    ranked = ops.f0_rerank(nn32, shifted, matching_f0)
-    idx2 = ranked[:, :C.KNN_USE].contiguous()
-    if cw != -1:
-        idx2 = ops.concat_reselect(idx2, q, qn, P, pn, shifted, matching_f0, concat_weight=cw)
-    harm_w = None
-    w2 = None
-    if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type:
-        if run_adam:
-            w2, it2 = ops.smooth_weights(idx2, harmonics_list, 1000.0, return_iters=True)
-        harm_w = ops.weighted_gather(idx2, w2, harmonics_list)
+    main.wait_stream(side)
+    for t in (shifted, idx2, harm_w, w2):
+        if t is not None:
+            t.record_stream(main)
     if return_debug:
         return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2,
                                                 iters_wavlm=it1 if it1 is not None else 0,
