@@ -60,6 +60,7 @@ struct ALoader {
         }
         return v;
     }
+    __device__ __forceinline__ void begin(int) const {}
     // prologue activation, applied when the slab is written to LDS (keeps the global load in flight)
     __device__ __forceinline__ f32x4 finish(f32x4 v) const {
         if (slope != 1.0f) {
@@ -90,6 +91,64 @@ struct BLoader {
         }
         return v;
     }
+    __device__ __forceinline__ void begin(int) const {}
+};
+
+// ---- fast path (cin % 32 == 0): buffer loads with hardware range checking ---------------------
+// Every slab of 32 k's lies inside ONE tap, so (tap, channel offset) is wave-uniform scalar state and
+// a thread's address is  constant_per_thread + uniform_per_slab.  Rows outside [0, t_in) (conv padding,
+// m >= M) and weight rows n >= N fall outside the buffer resource and read as 0 — no branches, no
+// 64-bit address arithmetic in the K loop.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = 0x40000000;      // pushes an offset out of every resource used here (< 1 GiB each)
+
+template <int NF4>
+struct FastALoader {
+    __amdgpu_buffer_rsrc_t rsrc; int off[NF4]; int cin, step_tap; float slope;
+    int c0, uoff;                     // uniform: channel offset inside the tap, byte offset of (tap, c0)
+    __device__ FastALoader(const ConvArgs& a, const float* xz, int m0, int tid) : cin(a.cin), slope(a.a_slope) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xz, 0, (int)(((long)(a.t_in - 1) * a.ldx + a.cin) * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NF4; ++j) {
+            const int m = m0 + (tid >> 3) + 32 * j;
+            off[j] = (m < a.m) ? ((m * a.stride - a.pad) * a.ldx + (tid & 7) * 4) * 4 : OOB;
+        }
+        step_tap = (a.dil * a.ldx - a.cin) * 4;       // byte step from the end of one tap to the start of the next
+        c0 = 0; uoff = 0;
+    }
+    __device__ __forceinline__ void begin(int kt) {
+        if (kt == 0) return;
+        c0 += 32; uoff += 128;
+        if (c0 == cin) { c0 = 0; uoff += step_tap; }
+    }
+    __device__ __forceinline__ f32x4 operator()(int, int j) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j] + uoff, 0, 0));
+    }
+    __device__ __forceinline__ f32x4 finish(f32x4 v) const {
+        if (slope != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], slope);
+        }
+        return v;
+    }
+};
+
+template <int NF4>
+struct FastBLoader {
+    __amdgpu_buffer_rsrc_t rsrc; int off[NF4]; int uoff;
+    __device__ FastBLoader(const float* wz, int N, int K, int n0, int tid) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wz, 0, (int)((long)N * K * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NF4; ++j) {
+            const int n = n0 + (tid >> 3) + 32 * j;
+            off[j] = (n < N) ? (n * K + (tid & 7) * 4) * 4 : OOB;
+        }
+        uoff = 0;
+    }
+    __device__ __forceinline__ void begin(int kt) { uoff = kt * 128; }
+    __device__ __forceinline__ f32x4 operator()(int, int j) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j] + uoff, 0, 0));
+    }
 };
 
 template <class G, int VEC>
@@ -109,9 +168,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    ALoader<VEC, G::A_F4> al(a, xz, m0, threadIdx.x);
-    BLoader<VEC, G::B_F4> bl(wz, a.n, a.K, n0);
-    G::mainloop(lds, (a.K + 31) / 32, al, bl, acc);
+    if constexpr (VEC == 8) {
+        FastALoader<G::A_F4> al(a, xz, m0, threadIdx.x);
+        FastBLoader<G::B_F4> bl(wz, a.n, a.K, n0, threadIdx.x);
+        G::mainloop(lds, a.K / 32, al, bl, acc);
+    } else {
+        ALoader<VEC, G::A_F4> al(a, xz, m0, threadIdx.x);
+        BLoader<VEC, G::B_F4> bl(wz, a.n, a.K, n0);
+        G::mainloop(lds, (a.K + 31) / 32, al, bl, acc);
+    }
 
     // ---- epilogue -------------------------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,7 +228,12 @@ using G32 = GemmTile<128, 32, 4, 1, 1, 1>;
 
 template <class G>
 int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
-    static bool done4 = false, done1 = false;
+    static bool done4 = false, done1 = false, done8 = false;
+    if (!done8) {
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<G, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess) return 1;
+        done8 = true;
+    }
     if (!done4) {
         if (hipFuncSetAttribute((const void*)conv_gemm_kernel<G, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G::LDS_BYTES) != hipSuccess) return 1;
@@ -216,7 +286,10 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (prepare<G128>() || prepare<G64>() || prepare<G32>())
         return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
-    if (d->n > 64) return vec4 ? launch<G128, 4>(a, d->batches, st) : launch<G128, 1>(a, d->batches, st);
-    if (d->n > 32) return vec4 ? launch<G64, 4>(a, d->batches, st) : launch<G64, 1>(a, d->batches, st);
-    return vec4 ? launch<G32, 4>(a, d->batches, st) : launch<G32, 1>(a, d->batches, st);
+    // buffer-load fast path: every slab inside one tap, resources below 1 GiB
+    const bool fast = vec4 && (d->cin % 32 == 0) && ((long)d->t_in * d->ldx * 4 < (1L << 30)) &&
+                      ((long)d->n * a.K * 4 < (1L << 30)) && ((long)d->m * d->stride * d->ldx * 4 < (1L << 30));
+    if (d->n > 64) return fast ? launch<G128, 8>(a, d->batches, st) : vec4 ? launch<G128, 4>(a, d->batches, st) : launch<G128, 1>(a, d->batches, st);
+    if (d->n > 32) return fast ? launch<G64, 8>(a, d->batches, st) : vec4 ? launch<G64, 4>(a, d->batches, st) : launch<G64, 1>(a, d->batches, st);
+    return fast ? launch<G32, 8>(a, d->batches, st) : vec4 ? launch<G32, 4>(a, d->batches, st) : launch<G32, 1>(a, d->batches, st);
 }

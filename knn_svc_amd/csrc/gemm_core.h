@@ -28,6 +28,7 @@ struct GemmTile {
     static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 
+    // aload.begin(kt) once per slab (uniform bookkeeping), then
     // aload(kt, j) -> f32x4 for row (tid>>3) + 32*j, k = kt*32 + (tid&7)*4 ; same for bload.
     // LDS pointers are kept in address space 3 explicitly: through generic pointers hipcc emits
     // flat_load/flat_store for the staging buffers and then waits vmcnt(0) in front of every MFMA
@@ -35,6 +36,7 @@ struct GemmTile {
     typedef __attribute__((address_space(3))) float lds_f;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
 
+    // aload.begin(kt) once per slab (uniform bookkeeping), then
     // aload(kt, j) -> f32x4 for row (tid>>3) + 32*j, k = kt*32 + (tid&7)*4 ; same for bload.
     // aload.finish(v) is applied when the registers are written to LDS (prologue activation), so
     // that nothing has to wait on the global load right after issuing it.
@@ -49,6 +51,7 @@ struct GemmTile {
         constexpr int BUF = (BM + BN) * LDK;          // floats per staging buffer: [A rows | B rows]
 
         f32x4 ra[A_F4], rb[B_F4];
+        aload.begin(0); bload.begin(0);
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) ra[j] = aload(0, j);
 #pragma unroll
@@ -66,6 +69,7 @@ struct GemmTile {
             const int cur = (kt & 1) * BUF;
             const bool more = (kt + 1 < nk);
             if (more) {
+                aload.begin(kt + 1); bload.begin(kt + 1);
 #pragma unroll
                 for (int j = 0; j < A_F4; ++j) ra[j] = aload(kt + 1, j);
 #pragma unroll

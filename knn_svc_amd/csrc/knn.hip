@@ -64,6 +64,7 @@ struct RowLoader {      // rows of a [rows][dim] row-major matrix, 16-byte vecto
         return v;
     }
     __device__ __forceinline__ f32x4 finish(f32x4 v) const { return v; }
+    __device__ __forceinline__ void begin(int) const {}
 };
 
 constexpr int LDD = 128;                                  // distance tile pitch

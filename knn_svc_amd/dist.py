@@ -41,7 +41,7 @@ def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
 
 def _hip_local_topk(q, pool, k, offset):
     from . import ops
-    return ops.knn_topk(q, pool, k, idx_offset=offset)
+    return ops.knn_topk(q, pool, k, idx_offset=offset, check_nan=False)
 
 
 def _hip_merge(part_dist, part_idx):

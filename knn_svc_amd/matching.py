@@ -120,8 +120,11 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
     P = matching_list
     qn, qs = ops.row_norms(q)
     pn, ps = ops.row_norms(P)
+    nan_flag = None
     if nn32 is None:
-        nn32, _ = ops.knn_topk(q, P, C.KNN_K, q_stats=(qn, qs), p_stats=(pn, ps))
+        # NaN check deferred to the end of the launch sequence (one host sync instead of a split stream)
+        nn32, _, nan_flag = ops.knn_topk(q, P, C.KNN_K, q_stats=(qn, qs), p_stats=(pn, ps), check_nan=False,
+                                         return_flag=True)
     cw, run_adam = parse_post_opt(post_opt)
     with_harm = "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type
     # The WavLM-feature branch (concat re-selection -> Adam -> weighted sum) and the pitched branch
@@ -153,6 +156,8 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
     for t in (shifted, idx2, harm_w, w2):
         if t is not None:
             t.record_stream(main)
+    if nan_flag is not None:
+        ops.raise_if_nan(nan_flag)
     if return_debug:
         return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2,
                                                 iters_wavlm=it1 if it1 is not None else 0,

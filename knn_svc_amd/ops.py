@@ -129,7 +129,7 @@ def row_norms(x2d):
     return norm, sq
 
 
-def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True):
+def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False):
     """Ascending cosine-distance top-k of each q row among pool rows -> (idx int64 [nq,k], dist f32 [nq,k])."""
     _need(q, name="knn.q"); _need(pool, name="knn.pool")
     if not (q.is_contiguous() and pool.is_contiguous()):
@@ -146,9 +146,17 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     flag = torch.zeros(1, device=q.device, dtype=torch.int32)
     check(lib.knnsvc_knn_topk(_p(q), _p(qn), _p(qs), nq, _p(pool), _p(pn), _p(ps), npool, dim, k, idx_offset,
                               _p(idx), _p(dist), _p(ws), ws_bytes, _p(flag), _stream()), "knn_topk")
-    if check_nan and int(flag.item()) != 0:
-        raise KnnSvcError("containing nan")        # the reference prints this and sys.exit()s (lib_ongaku_test.py:166-169)
-    return idx, dist
+    if check_nan:
+        raise_if_nan(flag)
+    return (idx, dist, flag) if return_flag else (idx, dist)
+
+
+def raise_if_nan(flag):
+    """Host check of the device NaN flag (one sync).  The reference prints 'containing nan' and
+    sys.exit()s inside fast_cosine_dist (lib_ongaku_test.py:166-169); callers may defer this check to the
+    end of a launch sequence so that it does not split the stream."""
+    if int(flag.item()) != 0:
+        raise KnnSvcError("containing nan")
 
 
 def knn_merge(part_dist, part_idx):

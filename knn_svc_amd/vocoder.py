@@ -74,13 +74,47 @@ class Vocoder:
         self.post_w = f(ops.pack_conv_weight(state["dec.conv_post.weight"].float()))
         self.prenet_w = f(state["sin_prenet.weight"].float().reshape(-1, 3))
         self.prenet_b = f(state["sin_prenet.bias"])
+        self._graphs = {}          # N -> (hipGraph, static inputs, static output)
+        self.use_graphs = True
 
     # -------------------------------------------------------------------------------------------
     def _conv(self, x, w, out, *, T_in, cin, cout, k, **kw):
         return ops.conv_gemm(x, w, out, n=cout, cin=cin, taps=k, t_in=T_in, **kw)
 
     def forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None) -> torch.Tensor:
-        """c [N, hubert_dim], f0 [N], harm [N, 49] (mix only), all fp32 on the GPU -> waveform [N*hop]."""
+        """c [N, hubert_dim], f0 [N], harm [N, 49] (mix only), all fp32 on the GPU -> waveform [N*hop].
+
+        The generator is ~110 short kernel launches whose host-side launch cost exceeds their device time
+        at 30 s and below, so the schedule for a given frame count N is captured once into a hipGraph
+        (every kernel takes caller-owned buffers and the capture stream, nothing allocates or syncs) and
+        replayed afterwards."""
+        N = c.shape[0]
+        if not self.use_graphs or torch.cuda.is_current_stream_capturing():
+            return self._forward(c, f0, harm)
+        ent = self._graphs.get(N)
+        if ent is None:
+            sc, sf = torch.empty_like(c, memory_format=torch.contiguous_format), torch.empty_like(f0)
+            sh = torch.empty_like(harm) if harm is not None else None
+            sc.copy_(c); sf.copy_(f0)
+            if sh is not None:
+                sh.copy_(harm)
+            self._forward(sc, sf, sh)                      # warm-up: one-time function attributes, allocator pools
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._forward(sc, sf, sh)
+            ent = (g, sc, sf, sh, out)
+            if len(self._graphs) >= 16:                    # bound the private pools kept alive
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[N] = ent
+        g, sc, sf, sh, out = ent
+        sc.copy_(c); sf.copy_(f0)
+        if sh is not None:
+            sh.copy_(harm)
+        g.replay()
+        return out.clone()
+
+    def _forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None) -> torch.Tensor:
         dev = c.device
         N = c.shape[0]
         hop, n_up, uic = self.hop, self.n_up, self.uic

@@ -1,0 +1,18 @@
+"""Micro-benchmark of knnsvc_conv_gemm on one linear shape (M, N, K): prints TFLOP/s (HIP events)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from knn_svc_amd import ops
+M, N, K = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (31500, 4096, 1024)))
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+out = torch.empty(M, N, device="cuda")
+for _ in range(3):
+    ops.linear(x, w, b, out=out)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(iters):
+    ops.linear(x, w, b, out=out)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print(f"M={M} N={N} K={K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
