@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 1
+#define KNNSVC_ABI_VERSION 2
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -64,9 +64,16 @@ typedef struct knnsvc_conv_desc {
     int32_t accumulate; float div;     /* div == 1.0f = off                               */
     int32_t batches; int32_t groups;
     int32_t convt_u; int32_t convt_cout; int32_t convt_pad; int32_t t_out;
+    const void* w_bf16x3;              /* optional: w pre-split by knnsvc_split_weight_bf16x3 (NULL = fp32 MFMA) */
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
+
+/* Split fp32 weights [rows, K] (K % 32 == 0) into three truncated bf16 planes, layout [rows][K/32][3][32]
+ * (6 bytes per weight).  With w_bf16x3 set and cin % 32 == 0, knnsvc_conv_gemm evaluates every fp32
+ * product as six bf16 MFMAs (a0b0+a0b1+a1b0+a0b2+a2b0+a1b1, fp32 accumulate): fp32-level accuracy at
+ * 6/16 of the fp32-MFMA cost.  Activations are split on the fly inside the kernel. */
+int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise layer norm over the last dim (eps 1e-5, affine), optional exact-erf GELU after it.

@@ -2,6 +2,7 @@
 // See include/knnsvc_hip.h (knnsvc_conv_gemm) for the operator definition and the
 // reference call sites it replaces.
 #include "gemm_core.h"
+#include "gemm3_core.h"
 
 namespace {
 
@@ -16,6 +17,7 @@ struct ConvArgs {
     int groups;
     int convt_u, convt_cout, convt_pad, t_out;
     int K;
+    const unsigned short* w3;   // weights pre-split into 3 bf16 planes ([n][K/32][3][32]) or null
 };
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
@@ -26,7 +28,7 @@ struct ALoader {
     const float* x; int ldx, t_in, cin, stride, dil, pad, K; float slope;
     int rowbase[NF4];          // m*stride - pad, or INT_MIN/2 when m is out of range
     int k_cur, tap, c;         // state of the VEC==4 path (k = slab*32 + (tid&7)*4)
-    __device__ ALoader(const ConvArgs& a, const float* xz, int m0, int tid)
+    __device__ __forceinline__ ALoader(const ConvArgs& a, const float* xz, int m0, int tid)
         : x(xz), ldx(a.ldx), t_in(a.t_in), cin(a.cin), stride(a.stride), dil(a.dil), pad(a.pad), K(a.K),
           slope(a.a_slope) {
 #pragma unroll
@@ -38,7 +40,7 @@ struct ALoader {
         tap = k_cur / cin;
         c = k_cur - tap * cin;
     }
-    __device__ __forceinline__ f32x4 operator()(int kt, int j) {
+    __device__ __forceinline__ f32x4 operator()(int kt, int j, int) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int k = kt * 32 + (threadIdx.x & 7) * 4;
         if (VEC == 4) {
@@ -75,8 +77,8 @@ struct ALoader {
 template <int VEC, int NF4>
 struct BLoader {
     const float* w; int N, K, n0;
-    __device__ BLoader(const float* wz, int N_, int K_, int n0_) : w(wz), N(N_), K(K_), n0(n0_) {}
-    __device__ __forceinline__ f32x4 operator()(int kt, int j) {
+    __device__ __forceinline__ BLoader(const float* wz, int N_, int K_, int n0_) : w(wz), N(N_), K(K_), n0(n0_) {}
+    __device__ __forceinline__ f32x4 operator()(int kt, int j, int) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int n = n0 + (threadIdx.x >> 3) + 32 * j;
         const int k = kt * 32 + (threadIdx.x & 7) * 4;
@@ -100,14 +102,26 @@ struct BLoader {
 // m >= M) and weight rows n >= N fall outside the buffer resource and read as 0 — no branches, no
 // 64-bit address arithmetic in the K loop.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int OOB = 0x40000000;      // pushes an offset out of every resource used here (< 1 GiB each)
+constexpr int OOB = 0x40000000;
+
+// descriptor built from readfirstlane'd inputs: provably wave-uniform, so hipcc keeps it in SGPRs and
+// does not wrap every buffer_load in a waterfall loop (cdna_hip_programming.md T20)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    bytes = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}      // pushes an offset out of every resource used here (< 1 GiB each)
 
 template <int NF4>
 struct FastALoader {
-    __amdgpu_buffer_rsrc_t rsrc; int off[NF4]; int cin, step_tap; float slope;
+    int off[NF4]; int cin, step_tap; float slope;
     int c0, uoff;                     // uniform: channel offset inside the tap, byte offset of (tap, c0)
-    __device__ FastALoader(const ConvArgs& a, const float* xz, int m0, int tid) : cin(a.cin), slope(a.a_slope) {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xz, 0, (int)(((long)(a.t_in - 1) * a.ldx + a.cin) * 4), 0x00020000);
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t desc(const ConvArgs& a, const float* xz) {
+        return uniform_rsrc(xz, (int)(((long)(a.t_in - 1) * a.ldx + a.cin) * 4));
+    }
+    __device__ __forceinline__ FastALoader(const ConvArgs& a, int m0, int tid) : cin(a.cin), slope(a.a_slope) {
 #pragma unroll
         for (int j = 0; j < NF4; ++j) {
             const int m = m0 + (tid >> 3) + 32 * j;
@@ -121,7 +135,7 @@ struct FastALoader {
         c0 += 32; uoff += 128;
         if (c0 == cin) { c0 = 0; uoff += step_tap; }
     }
-    __device__ __forceinline__ f32x4 operator()(int, int j) const {
+    __device__ __forceinline__ f32x4 operator()(int, int j, __amdgpu_buffer_rsrc_t rsrc) const {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j] + uoff, 0, 0));
     }
     __device__ __forceinline__ f32x4 finish(f32x4 v) const {
@@ -135,9 +149,9 @@ struct FastALoader {
 
 template <int NF4>
 struct FastBLoader {
-    __amdgpu_buffer_rsrc_t rsrc; int off[NF4]; int uoff;
-    __device__ FastBLoader(const float* wz, int N, int K, int n0, int tid) {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wz, 0, (int)((long)N * K * 4), 0x00020000);
+    int off[NF4]; int uoff;
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t desc(const float* wz, int N, int K) { return uniform_rsrc(wz, (int)((long)N * K * 4)); }
+    __device__ __forceinline__ FastBLoader(int N, int K, int n0, int tid) {
 #pragma unroll
         for (int j = 0; j < NF4; ++j) {
             const int n = n0 + (tid >> 3) + 32 * j;
@@ -146,38 +160,36 @@ struct FastBLoader {
         uoff = 0;
     }
     __device__ __forceinline__ void begin(int kt) { uoff = kt * 128; }
-    __device__ __forceinline__ f32x4 operator()(int, int j) const {
+    __device__ __forceinline__ f32x4 operator()(int, int j, __amdgpu_buffer_rsrc_t rsrc) const {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j] + uoff, 0, 0));
     }
 };
 
-template <class G, int VEC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int z = blockIdx.z;
-    const int b = z / a.groups, g = z - b * a.groups;
-    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
-    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
-    const float* wz = a.w + g * a.w_gstride;
-
-    f32x16 acc[G::TM][G::TN];
-#pragma unroll
-    for (int i = 0; i < G::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < G::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if constexpr (VEC == 8) {
-        FastALoader<G::A_F4> al(a, xz, m0, threadIdx.x);
-        FastBLoader<G::B_F4> bl(wz, a.n, a.K, n0, threadIdx.x);
-        G::mainloop(lds, a.K / 32, al, bl, acc);
-    } else {
-        ALoader<VEC, G::A_F4> al(a, xz, m0, threadIdx.x);
-        BLoader<VEC, G::B_F4> bl(wz, a.n, a.K, n0);
-        G::mainloop(lds, (a.K + 31) / 32, al, bl, acc);
+// split weights [n][K/32][3][32] bf16: thread piece q = tid + 256 j -> row q / 12, 16-byte piece q % 12
+template <int NP, int NPIECES>
+struct Split3BLoader {
+    int off[NP]; int uoff;
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t desc(const unsigned short* w3, int N, int K) {
+        return uniform_rsrc(w3, (int)((long)N * (K / 32) * 192));
     }
+    __device__ __forceinline__ Split3BLoader(int N, int K, int n0, int tid) {
+        const int row_bytes = (K / 32) * 192;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int q = tid + 256 * j;
+            const int n = n0 + q / 12;
+            off[j] = (q < NPIECES && n < N) ? n * row_bytes + (q % 12) * 16 : OOB;
+        }
+        uoff = 0;
+    }
+    __device__ __forceinline__ void begin(int kt) { uoff = kt * 192; }
+    __device__ __forceinline__ u32x4_t operator()(int, int j, __amdgpu_buffer_rsrc_t rsrc) const {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j] + uoff, 0, 0);
+    }
+};
 
+template <class G>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G::TM][G::TN], int m0, int n0, int b, int g) {
     // ---- epilogue -------------------------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
@@ -216,6 +228,92 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 }
 
 template <class G, int VEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const float* wz = a.w + g * a.w_gstride;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if constexpr (VEC == 8) {
+        FastALoader<G::A_F4> al(a, m0, threadIdx.x);
+        FastBLoader<G::B_F4> bl(a.n, a.K, n0, threadIdx.x);
+        G::mainloop(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), FastBLoader<G::B_F4>::desc(wz, a.n, a.K));
+    } else {
+        ALoader<VEC, G::A_F4> al(a, xz, m0, threadIdx.x);
+        BLoader<VEC, G::B_F4> bl(wz, a.n, a.K, n0);
+        G::mainloop(lds, (a.K + 31) / 32, al, bl, acc, 0, 0);
+    }
+
+    conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void conv_gemm3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const unsigned short* wz = a.w3 + (long)g * a.n * (a.K / 32) * 96;      // 96 ushorts = 192 B per (row, slab)
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    FastALoader<G::A_F4> al(a, m0, threadIdx.x);
+    Split3BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
+    G::mainloop(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split3BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K));
+    conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G>
+int launch3(const ConvArgs& a, int batches, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm3_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    dim3 grid((unsigned)cdiv64(a.m, G::BM), (unsigned)cdiv64(a.n, G::BN), (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm3_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm3");
+}
+
+// one thread per 4 consecutive k of one weight row: fp32 -> three truncated bf16 planes
+__global__ void split_weight_kernel(const float* __restrict__ w, long n, int K, unsigned short* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // index of a group of 4 floats
+    const long groups_per_row = K / 4;
+    if (i >= n * groups_per_row) return;
+    const long row = i / groups_per_row; const int k = (int)(i - row * groups_per_row) * 4;
+    const f32x4 v = *(const f32x4*)(w + row * K + k);
+    unsigned short* o = out + row * (long)(K / 32) * 96 + (k / 32) * 96 + (k % 32);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned x = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(x & 0xFFFF0000u);
+        const unsigned y = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(y & 0xFFFF0000u);
+        o[e] = (unsigned short)(x >> 16);
+        o[32 + e] = (unsigned short)(y >> 16);
+        o[64 + e] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+}
+
+template <class G, int VEC>
 int launch(const ConvArgs& a, int batches, hipStream_t st) {
     dim3 grid((unsigned)cdiv64(a.m, G::BM), (unsigned)cdiv64(a.n, G::BN), (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm_kernel<G, VEC>), grid, dim3(256), G::LDS_BYTES, st, a);
@@ -225,6 +323,9 @@ int launch(const ConvArgs& a, int batches, hipStream_t st) {
 using G128 = GemmTile<128, 128, 2, 2, 2, 2>;
 using G64 = GemmTile<128, 64, 4, 1, 1, 2>;
 using G32 = GemmTile<128, 32, 4, 1, 1, 1>;
+using H128 = Gemm3Tile<128, 128, 2, 2, 2, 2>;
+using H64 = Gemm3Tile<128, 64, 4, 1, 1, 2>;
+using H32 = Gemm3Tile<128, 32, 4, 1, 1, 1>;
 
 template <class G>
 int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
@@ -278,6 +379,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.groups = d->groups;
     a.convt_u = d->convt_u; a.convt_cout = d->convt_cout; a.convt_pad = d->convt_pad; a.t_out = d->t_out;
     a.K = d->cin * d->taps;
+    a.w3 = (const unsigned short*)d->w_bf16x3;
 
     // 16-byte vector path needs every float4 of A and W to be aligned and inside one tap
     const bool vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
@@ -289,7 +391,21 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     // buffer-load fast path: every slab inside one tap, resources below 1 GiB
     const bool fast = vec4 && (d->cin % 32 == 0) && ((long)d->t_in * d->ldx * 4 < (1L << 30)) &&
                       ((long)d->n * a.K * 4 < (1L << 30)) && ((long)d->m * d->stride * d->ldx * 4 < (1L << 30));
+    if (fast && a.w3) {        // fp32 emulated on the bf16 matrix cores (gemm3_core.h)
+        if (d->n > 64) return launch3<H128>(a, d->batches, st);
+        if (d->n > 32) return launch3<H64>(a, d->batches, st);
+        return launch3<H32>(a, d->batches, st);
+    }
     if (d->n > 64) return fast ? launch<G128, 8>(a, d->batches, st) : vec4 ? launch<G128, 4>(a, d->batches, st) : launch<G128, 1>(a, d->batches, st);
     if (d->n > 32) return fast ? launch<G64, 8>(a, d->batches, st) : vec4 ? launch<G64, 4>(a, d->batches, st) : launch<G64, 1>(a, d->batches, st);
     return fast ? launch<G32, 8>(a, d->batches, st) : vec4 ? launch<G32, 4>(a, d->batches, st) : launch<G32, 1>(a, d->batches, st);
+}
+
+extern "C" int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* out, void* stream) {
+    KN_REQUIRE(w && out && rows > 0 && K > 0 && K % 32 == 0, "split_weight: K must be a positive multiple of 32");
+    KN_REQUIRE(((uintptr_t)w & 15) == 0, "split_weight: 16-byte alignment");
+    const long groups = rows * (K / 4);
+    hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)cdiv64(groups, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, (long)rows, K, (unsigned short*)out);
+    return knnsvc_check_launch("split_weight");
 }

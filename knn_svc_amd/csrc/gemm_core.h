@@ -40,9 +40,12 @@ struct GemmTile {
     // aload(kt, j) -> f32x4 for row (tid>>3) + 32*j, k = kt*32 + (tid&7)*4 ; same for bload.
     // aload.finish(v) is applied when the registers are written to LDS (prologue activation), so
     // that nothing has to wait on the global load right after issuing it.
-    template <class ALoad, class BLoad>
+    // ra_desc / rb_desc: opaque per-operand values handed to every aload()/bload() call BY VALUE (buffer
+    // resource descriptors must not live inside the loader structs: SROA cannot split a struct holding an
+    // address-space-8 pointer, the struct lands in scratch and every buffer_load becomes a waterfall loop).
+    template <class ALoad, class BLoad, class RA, class RB>
     __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, BLoad& bload,
-                                                    f32x16 (&acc)[TM][TN]) {
+                                                    f32x16 (&acc)[TM][TN], RA ra_desc, RB rb_desc) {
         lds_f* lds = (lds_f*)lds_generic;
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
@@ -53,9 +56,9 @@ struct GemmTile {
         f32x4 ra[A_F4], rb[B_F4];
         aload.begin(0); bload.begin(0);
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j) ra[j] = aload(0, j);
+        for (int j = 0; j < A_F4; ++j) ra[j] = aload(0, j, ra_desc);
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) rb[j] = bload(0, j);
+        for (int j = 0; j < B_F4; ++j) rb[j] = bload(0, j, rb_desc);
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) *(lds_f4*)&lds[(srow + 32 * j) * LDK + skq] = aload.finish(ra[j]);
 #pragma unroll
@@ -71,9 +74,9 @@ struct GemmTile {
             if (more) {
                 aload.begin(kt + 1); bload.begin(kt + 1);
 #pragma unroll
-                for (int j = 0; j < A_F4; ++j) ra[j] = aload(kt + 1, j);
+                for (int j = 0; j < A_F4; ++j) ra[j] = aload(kt + 1, j, ra_desc);
 #pragma unroll
-                for (int j = 0; j < B_F4; ++j) rb[j] = bload(kt + 1, j);
+                for (int j = 0; j < B_F4; ++j) rb[j] = bload(kt + 1, j, rb_desc);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

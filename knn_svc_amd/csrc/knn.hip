@@ -56,7 +56,7 @@ __device__ __forceinline__ float ref_distance(float dot, float qsq, float psq, f
 
 struct RowLoader {      // rows of a [rows][dim] row-major matrix, 16-byte vectors
     const float* base; long rows; int dim; long r0;
-    __device__ __forceinline__ f32x4 operator()(int kt, int j) const {
+    __device__ __forceinline__ f32x4 operator()(int kt, int j, int) const {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const long r = r0 + (threadIdx.x >> 3) + 32 * j;
         const int k = kt * 32 + (threadIdx.x & 7) * 4;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         RowLoader al{q, nq, dim, q0};
         RowLoader bl{pool, p_end, dim, p0};
-        G::mainloop(lds, nk, al, bl, acc);            // ends with __syncthreads(): staging LDS is free
+        G::mainloop(lds, nk, al, bl, acc, 0, 0);            // ends with __syncthreads(): staging LDS is free
 
         // distances -> LDS tile [query][pool]
 #pragma unroll

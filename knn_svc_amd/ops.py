@@ -55,6 +55,23 @@ def pack_convT_weight(w: torch.Tensor, u: int) -> torch.Tensor:
     return w.reshape(cin, cout, r, u).permute(3, 1, 2, 0).reshape(u * cout, r * cin).contiguous()
 
 
+def attach_split(w: torch.Tensor) -> torch.Tensor:
+    """Pre-split a packed weight matrix [..., K] (K % 32 == 0) into three bf16 planes and hang the result on
+    the tensor (``w._w3``).  conv_gemm then runs the bf16x3 kernel for it (fp32-level accuracy, ~2.7x the
+    fp32-MFMA rate).  No-op when the shape does not qualify or KNNSVC_GEMM=fp32 is set."""
+    import os
+    if os.environ.get("KNNSVC_GEMM", "") == "fp32" or not w.is_cuda or w.dtype != torch.float32:
+        return w
+    K = w.shape[-1]
+    if K % 32 != 0 or not w.is_contiguous():
+        return w
+    rows = w.numel() // K
+    out = torch.empty(rows * (K // 32) * 96, device=w.device, dtype=torch.int16)
+    check(_lib.load().knnsvc_split_weight_bf16x3(_p(w), rows, K, _p(out), _stream()), "split_weight")
+    w._w3 = out
+    return w
+
+
 # ------------------------------------------------------------------ implicit-GEMM convolution
 def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None, ldx=None, ldo=None,
               bias=None, bias_period=0, act=ACT_NONE, act_slope=0.0, a_slope=1.0, resid=None, ldr=None,
@@ -78,6 +95,8 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.accumulate = 1 if accumulate else 0; d.div = div
     d.batches = batches; d.groups = groups
     d.convt_u = convt_u; d.convt_cout = convt_cout; d.convt_pad = convt_pad; d.t_out = t_out
+    w3 = getattr(w, "_w3", None)
+    d.w_bf16x3 = w3.data_ptr() if w3 is not None else None
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
     return out
 

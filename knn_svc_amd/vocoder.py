@@ -31,7 +31,8 @@ class Vocoder:
         assert kind in ("mix", "f0")
         self.h, self.kind, self.device = h, kind, torch.device(device)
         dev = self.device
-        f = lambda t: t.detach().float().contiguous().to(dev)
+        f0_ = lambda t: t.detach().float().contiguous().to(dev)
+        f = lambda t: ops.attach_split(f0_(t)) if t.dim() == 2 else f0_(t)     # 2-D = packed GEMM weights
         self.rates, self.ksz = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
         self.n_up = len(self.rates)
         self.hop = h["hop_size"]

@@ -63,19 +63,20 @@ class WavLMEncoder:
             raise ValueError("the attention kernel is built for head_dim 64 (WavLM-Large / Base+)")
         dev = self.device
         f = lambda t: t.detach().to(torch.float32).contiguous().to(dev)
+        fw = lambda t: ops.attach_split(f(t))       # GEMM weights: also keep the bf16x3 split (ops.attach_split)
         self.conv = []
         for i, (dim, k, s) in enumerate(C.conv_layers(cfg)):
             p = f"feature_extractor.conv_layers.{i}."
-            self.conv.append(dict(w=f(ops.pack_conv_weight(state[p + "0.weight"].float())), k=k, s=s, dim=dim,
+            self.conv.append(dict(w=fw(ops.pack_conv_weight(state[p + "0.weight"].float())), k=k, s=s, dim=dim,
                                   cin=state[p + "0.weight"].shape[1],
                                   g=f(state[p + "2.1.weight"]), b=f(state[p + "2.1.bias"])))
         self.ln_g, self.ln_b = f(state["layer_norm.weight"]), f(state["layer_norm.bias"])
-        self.proj_w, self.proj_b = f(state["post_extract_proj.weight"]), f(state["post_extract_proj.bias"])
+        self.proj_w, self.proj_b = fw(state["post_extract_proj.weight"]), f(state["post_extract_proj.bias"])
         # positional conv: fold weight_norm(dim=2) once (wavlm/WavLM.py:526), then pack per group
         wpc = torch._weight_norm(state["encoder.pos_conv.0.weight_v"].float(), state["encoder.pos_conv.0.weight_g"].float(), 2)
         self.G = cfg["conv_pos_groups"]
         self.Kpos = cfg["conv_pos"]
-        self.pos_w = f(ops.pack_grouped_conv_weight(wpc, self.G))
+        self.pos_w = fw(ops.pack_grouped_conv_weight(wpc, self.G))
         self.pos_b = f(state["encoder.pos_conv.0.bias"])
         self.layers = []
         for l in range(n_layers):
@@ -84,14 +85,14 @@ class WavLMEncoder:
             w8, b8 = state[a + "grep_linear.weight"].float(), state[a + "grep_linear.bias"].float()
             self.layers.append(dict(
                 ln1_g=f(state[p + "self_attn_layer_norm.weight"]), ln1_b=f(state[p + "self_attn_layer_norm.bias"]),
-                wqkv=f(torch.cat([state[a + "q_proj.weight"], state[a + "k_proj.weight"], state[a + "v_proj.weight"]], 0)),
+                wqkv=fw(torch.cat([state[a + "q_proj.weight"], state[a + "k_proj.weight"], state[a + "v_proj.weight"]], 0)),
                 bqkv=f(torch.cat([state[a + "q_proj.bias"], state[a + "k_proj.bias"], state[a + "v_proj.bias"]], 0)),
-                wo=f(state[a + "out_proj.weight"]), bo=f(state[a + "out_proj.bias"]),
+                wo=fw(state[a + "out_proj.weight"]), bo=f(state[a + "out_proj.bias"]),
                 gate_w=f(torch.stack([w8[:4].sum(0), w8[4:].sum(0)])), gate_b=f(torch.stack([b8[:4].sum(), b8[4:].sum()])),
                 grep_a=f(state[a + "grep_a"].reshape(-1)),
                 ln2_g=f(state[p + "final_layer_norm.weight"]), ln2_b=f(state[p + "final_layer_norm.bias"]),
-                w1=f(state[p + "fc1.weight"]), b1=f(state[p + "fc1.bias"]),
-                w2=f(state[p + "fc2.weight"]), b2=f(state[p + "fc2.bias"]),
+                w1=fw(state[p + "fc1.weight"]), b1=f(state[p + "fc1.bias"]),
+                w2=fw(state[p + "fc2.weight"]), b2=f(state[p + "fc2.bias"]),
             ))
         self.rel_emb = state["encoder.layers.0.self_attn.relative_attention_bias.weight"].detach().float().cpu()
         self._tables = {}

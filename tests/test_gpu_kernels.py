@@ -37,6 +37,23 @@ def test_linear(M, K, N):
     assert _err(out, ref)[0] < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 1024, 1024), (1500, 4096, 1024), (129, 64, 130), (500, 96, 40), (77, 32, 20)])
+def test_linear_bf16x3(M, K, N):
+    """fp32 emulated with six bf16 MFMAs per product: must be as accurate as the fp32 path (vs fp64)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * 3; w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().T + b.double()
+    wd = w.to(DEV)
+    o32 = ops.linear(x.to(DEV), wd, b.to(DEV))
+    ops.attach_split(wd)
+    assert hasattr(wd, "_w3")
+    o3 = ops.linear(x.to(DEV), wd, b.to(DEV))
+    e32, e3 = float((o32.cpu().double() - ref).abs().max()), float((o3.cpu().double() - ref).abs().max())
+    print(f"fp32 MFMA err {e32:.2e}, bf16x3 err {e3:.2e}")
+    assert e3 <= 2.0 * e32 + 1e-6 and e3 < 1e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("cin,cout,k,s,d,T", [(1, 64, 10, 5, 1, 1000), (64, 64, 3, 2, 1, 199), (32, 32, 11, 1, 5, 700),
                                              (512, 512, 3, 2, 1, 301), (8, 16, 4, 2, 1, 640), (34, 34, 16, 8, 1, 800),
                                              (32, 1, 7, 1, 1, 500)])
@@ -55,6 +72,12 @@ def test_conv1d(cin, cout, k, s, d, T):
     ops.conv_gemm(xcl, ops.pack_conv_weight(w).to(DEV), out, m=To, n=cout, cin=cin, taps=k, stride=s, dil=d, pad=pad,
                   t_in=T, bias=b.to(DEV), a_slope=0.1, batches=B, x_bstride=T * cin, o_bstride=To * cout)
     assert _err(out.transpose(1, 2), ref)[0] < 2e-5
+    if cin % 32 == 0:                      # same conv through the bf16x3 kernel
+        wp = ops.attach_split(ops.pack_conv_weight(w).to(DEV))
+        out2 = torch.empty(B, To, cout, device=DEV)
+        ops.conv_gemm(xcl, wp, out2, m=To, n=cout, cin=cin, taps=k, stride=s, dil=d, pad=pad, t_in=T, bias=b.to(DEV),
+                      a_slope=0.1, batches=B, x_bstride=T * cin, o_bstride=To * cout)
+        assert _err(out2.transpose(1, 2), ref)[0] < 2e-5
 
 
 def test_conv_epilogue_chain():
@@ -89,7 +112,7 @@ def test_conv_transpose(cin, cout, k, u, T):
     xcl = x[0].T.contiguous().to(DEV)
     out = torch.zeros(To, cout, device=DEV)
     R = k // u
-    ops.conv_gemm(xcl, ops.pack_convT_weight(w, u).to(DEV), out, m=T + R - 1, n=u * cout, cin=cin, taps=R, stride=1,
+    ops.conv_gemm(xcl, ops.attach_split(ops.pack_convT_weight(w, u).to(DEV)), out, m=T + R - 1, n=u * cout, cin=cin, taps=R, stride=1,
                   dil=-1, pad=0, t_in=T, bias=b.to(DEV), bias_period=cout, a_slope=0.1, ldo=cout,
                   convt_u=u, convt_cout=cout, convt_pad=pad, t_out=To)
     assert _err(out, ref)[0] < 2e-5
@@ -107,7 +130,7 @@ def test_grouped_pos_conv():
     xd = x.to(DEV)
     out = torch.empty_like(xd)
     cg = E // G
-    ops.conv_gemm(xd, ops.pack_grouped_conv_weight(w, G).to(DEV), out, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T,
+    ops.conv_gemm(xd, ops.attach_split(ops.pack_grouped_conv_weight(w, G).to(DEV)), out, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T,
                   ldx=E, ldo=E, bias=b.to(DEV), act=ops.ACT_GELU, resid=xd, ldr=E, batches=B, groups=G,
                   x_bstride=T * E, x_gstride=cg, w_gstride=cg * cg * K, bias_gstride=cg, o_bstride=T * E, o_gstride=cg,
                   r_bstride=T * E, r_gstride=cg)

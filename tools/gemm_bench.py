@@ -7,6 +7,9 @@ M, N, K = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (31500, 409
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
 out = torch.empty(M, N, device="cuda")
+if os.environ.get("SPLIT", "1") == "1":
+    ops.attach_split(w)
+    print("bf16x3 path", hasattr(w, "_w3"))
 for _ in range(3):
     ops.linear(x, w, b, out=out)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -16,3 +19,7 @@ for _ in range(iters):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 print(f"M={M} N={N} K={K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+
+ref = (x[:256].double().cpu() @ w.double().cpu().T + b.double().cpu())
+err = (out[:256].double().cpu() - ref).abs().max().item()
+print(f"max |err| vs fp64 on 256 rows: {err:.3e}  (|ref| max {ref.abs().max().item():.2f})")
