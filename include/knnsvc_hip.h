@@ -82,6 +82,12 @@ int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* ou
 int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32_t ldx, const float* gamma,
                      const float* beta, int32_t gelu, float* out, int32_t ldo, void* stream);
 
+/* Layer 0 of the conv feature extractor fused: Conv1d(1->C, k, stride, no bias) -> LayerNorm(C) -> GELU
+ * (wavlm/WavLM.py:401-419 with in_d = 1).  x [batches, L] -> out [batches * T, C], T = (L-k)/stride + 1,
+ * w [C, k].  C in {64,128,256,512}, k <= 16, stride <= 8. */
+int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, const float* w, int32_t channels, int32_t k,
+                       int32_t stride, const float* gamma, const float* beta, float* out, void* stream);
+
 /* Gated relative-position multiplier, wavlm/modules.py:523-533:
  *   gate[row, h] = ga*(gb*grep_a[h] - 1) + 2, (ga, gb) = sigmoid(W2 @ xn[row, h*hd:(h+1)*hd] + b2)
  * where W2 [2, hd] / b2 [2] are grep_linear's weight rows / bias summed in groups of four. */

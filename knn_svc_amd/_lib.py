@@ -41,6 +41,7 @@ SIGNATURES = {
     "knnsvc_conv_gemm": (i32, [C.POINTER(ConvDesc), vp]),
     "knnsvc_split_weight_bf16x3": (i32, [vp, i64, i32, vp, vp]),
     "knnsvc_layernorm": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "knnsvc_wavlm_conv0": (i32, [vp, i32, i64, vp, i32, i32, i32, vp, vp, vp, vp]),
     "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
     "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp]),

@@ -6,48 +6,125 @@ namespace {
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-// one wave per row; row kept in registers (dim <= 2048), two-pass mean / variance
+// one wave per R rows, rows kept in registers (R * dim <= 2048 floats per wave), two-pass mean / variance.
+// The R rows are independent chains (loads, reductions, stores), interleaved for memory-level parallelism.
+template <int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long rows, int dim, int ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int gelu, float* __restrict__ out, int ldo) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + row * (long)ldx;
-    float* orow = out + row * (long)ldo;
-    constexpr int MAXV = 8;
-    f32x4 v[MAXV];
-    float s = 0.f;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    f32x4 v[R][MAXV];
+    float s[R];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane * 4 + 256 * i;
-        if (c < dim) { v[i] = *(const f32x4*)(xr + c); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
-        else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const float mean = wave_sum(s) / (float)dim;
-    float q = 0.f;
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+        const bool ok = row0 + r < rows;
+        const float* xr = x + (row0 + r) * (long)ldx;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane * 4 + 256 * i;
-        if (c < dim) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (ok && c < dim) { v[r][i] = *(const f32x4*)(xr + c); s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]); }
+            else v[r][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    const float var = wave_sum(q) / (float)dim;
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float mean[R], q[R];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane * 4 + 256 * i;
-        if (c < dim) {
-            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-            f32x4 y;
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) / (float)dim;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = (v[i][e] - mean) * rstd * g[e] + b[e];
-                y[e] = gelu ? gelu_erf(t) : t;
+    for (int r = 0; r < R; ++r) {
+        q[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < dim) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mean[r]; q[r] += d * d; }
             }
-            *(f32x4*)(orow + c) = y;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float var = wave_sum(q[r]) / (float)dim;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        if (row0 + r >= rows) continue;
+        float* orow = out + (row0 + r) * (long)ldo;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < dim) {
+                const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = (v[r][i][e] - mean[r]) * rstd * g[e] + b[e];
+                    y[e] = gelu ? gelu_erf(t) : t;
+                }
+                *(f32x4*)(orow + c) = y;
+            }
+        }
+    }
+}
+
+// First layer of the WavLM feature extractor fused end to end (wavlm/WavLM.py:401-419, layer 0):
+// Conv1d(1 -> C, k, stride, no bias) -> LayerNorm over channels -> GELU, written once.
+// A lane owns CPL = C/64 consecutive channels and keeps their k taps in registers; a block stages the
+// input span of its 64 output rows in LDS; each wave walks 16 rows (LN statistics by wave reduction).
+// The unfused route wrote, re-read and re-wrote the [T, C] tensor (4.1 GB per 10 min of audio at C = 512).
+template <int CPL, int KMAXT>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ x, long L, long T, int k, int stride,
+                                                           const float* __restrict__ w, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ out) {
+    __shared__ float xs[64 * 8 + 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = CPL * 64;
+    const long b = blockIdx.y;
+    const long m0 = (long)blockIdx.x * 64;
+    const float* xb = x + b * L;
+    const int span = 63 * stride + k;
+    for (int i = threadIdx.x; i < span; i += 256) {
+        const long p = m0 * stride + i;
+        xs[i] = p < L ? xb[p] : 0.f;
+    }
+    float wr[CPL][KMAXT], g[CPL], be[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = lane * CPL + c;
+        g[c] = gamma[ch]; be[c] = beta[ch];
+#pragma unroll
+        for (int t = 0; t < KMAXT; ++t) wr[c][t] = t < k ? w[ch * k + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = 0; r < 16; ++r) {
+        const int lm = wave * 16 + r;
+        const long m = m0 + lm;
+        if (m >= T) break;
+        float xv[KMAXT];
+#pragma unroll
+        for (int t = 0; t < KMAXT; ++t) xv[t] = t < k ? xs[lm * stride + t] : 0.f;
+        float y[CPL], s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < KMAXT; ++t) a += wr[c][t] * xv[t];
+            y[c] = a; s += a;
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { const float d = y[c] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+        float* o = out + (b * T + m) * C + lane * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) y[c] = gelu_erf((y[c] - mean) * rstd * g[c] + be[c]);
+        if (CPL % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < CPL; c += 4) *(f32x4*)(o + c) = (f32x4){y[c], y[c + 1], y[c + 2], y[c + 3]};
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) o[c] = y[c];
         }
     }
 }
@@ -154,8 +231,16 @@ extern "C" int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32
     KN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
                ((uintptr_t)beta & 15) == 0, "layernorm: pointers must be 16-byte aligned");
     if (rows <= 0) return KNNSVC_OK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       x, (long)rows, dim, ldx, gamma, beta, gelu, out, ldo);
+    hipStream_t st = (hipStream_t)stream;
+    if (dim <= 512)
+        hipLaunchKernelGGL((layernorm_kernel<2, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, st, x, (long)rows, dim, ldx,
+                           gamma, beta, gelu, out, ldo);
+    else if (dim <= 1024)
+        hipLaunchKernelGGL((layernorm_kernel<4, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, st, x, (long)rows, dim, ldx,
+                           gamma, beta, gelu, out, ldo);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<8, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st, x, (long)rows, dim, ldx,
+                           gamma, beta, gelu, out, ldo);
     return knnsvc_check_launch("layernorm");
 }
 
@@ -205,4 +290,19 @@ extern "C" int knnsvc_harmonic_amps(const float* spec, const float* f0, int64_t 
     hipLaunchKernelGGL(harmonic_amps_kernel, dim3((unsigned)cdiv64(T * n_harm, 256)), dim3(256), 0,
                        (hipStream_t)stream, spec, f0, (long)T, bins, n_harm, harm);
     return knnsvc_check_launch("harmonic_amps");
+}
+
+extern "C" int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, const float* w, int32_t channels, int32_t k,
+                                  int32_t stride, const float* gamma, const float* beta, float* out, void* stream) {
+    KN_REQUIRE(x && w && gamma && beta && out, "wavlm_conv0: null pointer");
+    KN_REQUIRE(batches > 0 && batches <= 65535 && L >= k && k >= 1 && k <= 16 && stride >= 1 && stride <= 8,
+               "wavlm_conv0: needs 1 <= k <= 16, 1 <= stride <= 8");
+    KN_REQUIRE(channels == 64 || channels == 128 || channels == 256 || channels == 512, "wavlm_conv0: channels must be 64/128/256/512");
+    const long T = (L - k) / stride + 1;
+    dim3 grid((unsigned)cdiv64(T, 64), (unsigned)batches);
+    hipStream_t st = (hipStream_t)stream;
+#define KN_C0(CPL) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, 16>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out)
+    if (channels == 512) KN_C0(8); else if (channels == 256) KN_C0(4); else if (channels == 128) KN_C0(2); else KN_C0(1);
+#undef KN_C0
+    return knnsvc_check_launch("wavlm_conv0");
 }

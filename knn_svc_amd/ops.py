@@ -122,6 +122,17 @@ def layernorm(x2d, gamma, beta, gelu=False, out=None):
     return out
 
 
+def wavlm_conv0(x, w, gamma, beta, k, stride):
+    """[B, L] waveform -> [B*T, C] = GELU(LN(conv1d(x))) of the first feature-extractor layer, one kernel."""
+    B, L = x.shape
+    C_ = gamma.numel()
+    T = (L - k) // stride + 1
+    out = torch.empty(B * T, C_, device=x.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_wavlm_conv0(_p(x), B, L, _p(w), C_, k, stride, _p(gamma), _p(beta), _p(out), _stream()),
+          "wavlm_conv0")
+    return out
+
+
 def wavlm_gate(xn2d, heads, w2, b2, grep_a):
     rows = xn2d.shape[0]
     gate = torch.empty(rows, heads, device=xn2d.device, dtype=torch.float32)

@@ -116,8 +116,12 @@ class WavLMEncoder:
         dev = wav.device
         x = wav.contiguous()
         t_in, cin = L, 1
-        for c in self.conv:
+        for li, c in enumerate(self.conv):
             t_out = (t_in - c["k"]) // c["s"] + 1
+            if li == 0 and cin == 1 and c["dim"] in (64, 128, 256, 512) and c["k"] <= 16 and c["s"] <= 8:
+                x = ops.wavlm_conv0(x, c["w"], c["g"], c["b"], c["k"], c["s"])       # conv + LN + GELU in one pass
+                t_in, cin = t_out, c["dim"]
+                continue
             y = torch.empty(B * t_out, c["dim"], device=dev, dtype=torch.float32)
             ops.conv_gemm(x, c["w"], y, m=t_out, n=c["dim"], cin=cin, taps=c["k"], stride=c["s"], t_in=t_in,
                           batches=B, x_bstride=t_in * cin, o_bstride=t_out * c["dim"])
