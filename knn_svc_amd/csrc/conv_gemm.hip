@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 }
 
 template <class G>
-__global__ __launch_bounds__(256) void conv_gemm3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_gemm3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
@@ -324,8 +324,8 @@ using G128 = GemmTile<128, 128, 2, 2, 2, 2>;
 using G64 = GemmTile<128, 64, 4, 1, 1, 2>;
 using G32 = GemmTile<128, 32, 4, 1, 1, 1>;
 using H128 = Gemm3Tile<128, 128, 2, 2, 2, 2>;
-using H64 = Gemm3Tile<128, 64, 4, 1, 1, 2>;
-using H32 = Gemm3Tile<128, 32, 4, 1, 1, 1>;
+using H64 = Gemm3Tile<256, 64, 4, 1, 2, 2>;     // small-N layers: taller tiles so that a wave still issues 48 / 24
+using H32 = Gemm3Tile<256, 32, 4, 1, 2, 1>;     // MFMAs between the two barriers of a slab
 
 template <class G>
 int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
