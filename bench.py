@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from knn_svc_amd import config as C, dist as kdist, ops, synthetic as S      # noqa: E402
-from knn_svc_amd.matching import match_features, side_features               # noqa: E402
+from knn_svc_amd.matching import _side_stream, match_features, side_features               # noqa: E402
 from knn_svc_amd.vocoder import Vocoder                                       # noqa: E402
 from knn_svc_amd.wavlm import WavLMEncoder                                    # noqa: E402
 
@@ -117,22 +117,32 @@ class stage:
 
 
 def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
+    # STFT / harmonic amplitudes only need the raw audio: run them on a second stream next to the encoder
+    main = torch.cuda.current_stream()
+    side = _side_stream(src.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        with stage("side_features"):
+            qf0, _, _ = side_features(src, sf0, 1500)
+            f0s, harms = [], []
+            for w, f in zip(pool_w, pool_f0):
+                a, b, _ = side_features(w, f, 1500)
+                f0s.append(a); harms.append(b)
+            Pf0_loc, Ph_loc = torch.cat(f0s).contiguous(), torch.cat(harms).contiguous()
     with stage("wavlm"):
         feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
     qf = feats[-1]
-    with stage("side_features"):
-        qf0, _, _ = side_features(src, sf0, qf.shape[0])
-        f0s, harms = [], []
-        for w, f, ft in zip(pool_w, pool_f0, feats[:-1]):
-            a, b, _ = side_features(w, f, ft.shape[0])
-            f0s.append(a); harms.append(b)
-        P_loc = torch.cat(feats[:-1]).contiguous()
+    assert qf.shape[0] == 1500
+    P_loc = torch.cat(feats[:-1]).contiguous()
+    main.wait_stream(side)
+    for t in (qf0, Pf0_loc, Ph_loc):
+        t.record_stream(main)
     with stage("knn"):
         nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K)
     with stage("gather"):
         P = kdist.all_gather_rows(P_loc)
-        Pf0 = kdist.all_gather_rows(torch.cat(f0s).contiguous())
-        Ph = kdist.all_gather_rows(torch.cat(harms).contiguous())
+        Pf0 = kdist.all_gather_rows(Pf0_loc)
+        Ph = kdist.all_gather_rows(Ph_loc)
     with stage("match"):
         of, hw, s0, dbg = match_features(qf, qf0, P, Pf0, Ph, "mix", "post_opt_0.2", nn32=nn32, return_debug=True)
     with stage("vocoder"):

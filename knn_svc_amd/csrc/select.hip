@@ -242,11 +242,13 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
     const int offA = 0, offS = 8 * D, offP = 24 * D, offQ = 28 * D;      // floats
     __shared__ long s_idA[2][4], s_idS[2][8], s_idP[4];
     __shared__ float s_pnA[2][4], s_pnS[2][8], s_pnP[4], s_qn[2], s_f0A[2][4], s_f0S[2][8], s_sf0[2];
+    __shared__ long s_idNext[2][4];        // kNN ids of frame f live in s_idNext[f & 1], loaded two frames ahead
     __shared__ int s_slot[2][4];           // slots (0..7) of the kept candidates of frame i, i&1
-    __shared__ float s_match[NC], s_cc[KC][NC], s_base, s_w;
-    __shared__ long s_cand[NC];
-    __shared__ float s_cpn[NC], s_cf0[NC];
-    __shared__ int s_coff[NC];             // LDS float offset of each candidate row
+    __shared__ float s_match[NC], s_cc[KC][NC], s_base, s_wv[2];
+    // candidate table, double buffered by frame parity: frame i reads [i&1] while wave 0 fills [(i+1)&1]
+    __shared__ long s_candT[2][NC];
+    __shared__ float s_cpnT[2][NC], s_cf0T[2][NC];
+    __shared__ int s_coffT[2][NC];         // LDS float offset of each candidate row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = (tid & 255) * 4;       // 256 threads cover one 1024-float row with float4
@@ -259,15 +261,20 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
         idx_out[tid] = id;
         s_idP[tid] = id; s_pnP[tid] = pn[id];
         long sid = id + 1; if (sid >= np) sid = np - 1;
-        s_idS[0][tid] = sid; s_pnS[0][tid] = pn[sid]; s_f0S[0][tid] = use_f0 ? pf0[sid] : 0.f;
+        s_idS[0][tid] = sid; s_pnS[0][tid] = pn[sid]; s_f0S[0][tid] = use_f0 ? log2_rn(pf0[sid] + 1e-5f) : 0.f;
         s_slot[0][tid] = tid;
-        if (nq > 1) { const long a = idx_in[4 + tid]; s_idA[1][tid] = a; s_pnA[1][tid] = pn[a]; s_f0A[1][tid] = use_f0 ? pf0[a] : 0.f; }
+        if (nq > 2) s_idNext[0][tid] = idx_in[8 + tid];
+        if (nq > 1) { const long a = idx_in[4 + tid]; s_idA[1][tid] = a; s_pnA[1][tid] = pn[a]; s_f0A[1][tid] = use_f0 ? log2_rn(pf0[a] + 1e-5f) : 0.f; }
     }
     if (tid == 0) {
-        s_w = concat_weight; s_qn[0] = qn[0];
-        if (nq > 1) { s_qn[1] = qn[1]; s_sf0[1] = use_f0 ? sf0[1] : 0.f; }
+        s_wv[1] = concat_weight; s_qn[0] = qn[0];
+        if (nq > 1) { s_qn[1] = qn[1]; s_sf0[1] = use_f0 ? log2_rn(sf0[1] + 1e-5f) : 0.f; }
     }
     __syncthreads();
+    if (tid < NC && nq > 1) {                // candidate table of frame 1
+        if (tid < KC) { s_candT[1][tid] = s_idA[1][tid]; s_cpnT[1][tid] = s_pnA[1][tid]; s_cf0T[1][tid] = s_f0A[1][tid]; s_coffT[1][tid] = offA + (4 + tid) * D; }
+        else { const int sl = tid - KC; s_candT[1][tid] = s_idS[0][sl]; s_cpnT[1][tid] = s_pnS[0][sl]; s_cf0T[1][tid] = s_f0S[0][sl]; s_coffT[1][tid] = offS + sl * D; }
+    }
     if (colok) {
         for (int r = half; r < 4; r += 2) {
             *(lf4*)&L[offP + r * D + col] = *(const f32x4*)(pool + s_idP[r] * (long)D + col);
@@ -281,21 +288,12 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
 
     for (long i = 1; i < nq; ++i) {
         const int cur = (int)(i & 1), prv = cur ^ 1;
-        // candidate table of this frame
-        if (tid < NC) {
-            long id; float nrm, f; int off;
-            if (tid < KC) { id = s_idA[cur][tid]; nrm = s_pnA[cur][tid]; f = s_f0A[cur][tid]; off = offA + (cur * 4 + tid) * D; }
-            else {
-                const int sl = s_slot[prv][tid - KC];
-                id = s_idS[prv][sl]; nrm = s_pnS[prv][sl]; f = s_f0S[prv][sl]; off = offS + (prv * 8 + sl) * D;
-            }
-            s_cand[tid] = id; s_cpn[tid] = nrm; s_cf0[tid] = f; s_coff[tid] = off;
-        }
-        __syncthreads();
+        const long* s_cand = s_candT[cur]; const float* s_cpn = s_cpnT[cur]; const float* s_cf0 = s_cf0T[cur];
+        const int* s_coff = s_coffT[cur];
         // ---- (a) prefetch for frame i+1 into registers: 4 kNN rows, q[i+1], 8 successor rows --------
         const bool more = (i + 1 < nq);
         f32x4 pre[7];
-        long my_id = 0; float my_pn = 0.f, my_f0 = 0.f; int my_kind = -1;   // per-thread scalar prefetch (tid < 13)
+        long my_id = 0, nn_id = 0; float my_pn = 0.f, my_f0 = 0.f; int my_kind = -1;   // per-thread scalar prefetch (tid < 13)
         {
             // row list r = 0..12: 0-3 -> A[i+1], 4 -> q[i+1], 5-12 -> successors of cand[0..7]
 #pragma unroll
@@ -303,14 +301,15 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 const int r = 2 * t + half;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (colok && r < 13) {
-                    if (r < 4) { if (more) v = *(const f32x4*)(pool + idx_in[(i + 1) * KC + r] * (long)D + col); }
+                    if (r < 4) { if (more) v = *(const f32x4*)(pool + (i == 1 ? idx_in[2 * KC + r] : s_idNext[prv][r]) * (long)D + col); }
                     else if (r == 4) { if (more) v = *(const f32x4*)(q + (i + 1) * (long)D + col); }
                     else { long sid = s_cand[r - 5] + 1; if (sid >= np) sid = np - 1; v = *(const f32x4*)(pool + sid * (long)D + col); }
                 }
                 pre[t] = v;
             }
             if (tid < 13) {
-                if (tid < 4) { if (more) { my_id = idx_in[(i + 1) * KC + tid]; my_pn = pn[my_id]; my_f0 = use_f0 ? pf0[my_id] : 0.f; my_kind = 0; } }
+                if (tid < 4) { if (i + 2 < nq) nn_id = idx_in[(i + 2) * KC + tid];
+                               if (more) { my_id = (i == 1 ? idx_in[2 * KC + tid] : s_idNext[prv][tid]); my_pn = pn[my_id]; my_f0 = use_f0 ? pf0[my_id] : 0.f; my_kind = 0; } }
                 else if (tid == 4) { if (more) { my_pn = qn[i + 1]; my_f0 = use_f0 ? sf0[i + 1] : 0.f; my_kind = 1; } }
                 else { long sid = s_cand[tid - 5] + 1; if (sid >= np) sid = np - 1; my_id = sid; my_pn = pn[sid]; my_f0 = use_f0 ? pf0[sid] : 0.f; my_kind = 2; }
             }
@@ -356,11 +355,13 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
             }
         }
         __syncthreads();
-        // ---- (c) costs, lower median over the previous selection, 4 smallest -------------------------
-        if (wave == 0) {
+        // ---- (c) costs, lower median over the previous selection, 4 smallest.  Every wave evaluates the
+        // same 8-lane decision redundantly (it only reads LDS), so no barrier is needed before (d). ------
+        int my_slot = -1;                       // lane < 8: rank of candidate `lane` if kept
+        {
             float total = __builtin_inff();
             const float base = s_base;
-            float w = s_w;
+            float w = s_wv[cur];
             if (use_f0 && !(base < 0.08f)) w = 0.f;
             if (lane < NC) {
                 float c4[KC];
@@ -375,22 +376,31 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 const float lo23 = fminf(c4[2], c4[3]), hi23 = fmaxf(c4[2], c4[3]);
                 const float med = fminf(fmaxf(lo01, lo23), fminf(hi01, hi23));
                 total = w * med + s_match[lane];
-                if (use_f0) total = total + fabsf(log2_rn(s_cf0[lane] + 1e-5f) - log2_rn(s_sf0[cur] + 1e-5f));
+                if (use_f0) total = total + fabsf(s_cf0[lane] - s_sf0[cur]);      // both already log2(f0 + 1e-5)
             }
             int rank = 0;
             for (int j = 0; j < NC; ++j) {
                 const float tj = __shfl(total, j, 64);
                 rank += (tj < total || (tj == total && j < lane)) ? 1 : 0;
             }
-            if (lane < NC && rank < KC) { s_slot[cur][rank] = lane; idx_out[i * KC + rank] = s_cand[lane]; }
-            if (lane == 0) s_w = w;
+            if (lane < NC && rank < KC) my_slot = rank;
+            if (wave == 0) {
+                if (my_slot >= 0) { s_slot[cur][my_slot] = lane; idx_out[i * KC + my_slot] = s_cand[lane]; }
+                if (lane == 0) s_wv[prv] = w;
+            }
         }
-        __syncthreads();
+        // slot kept at rank r, broadcast inside the wave: lane holding rank r
+        int kept[KC];
+#pragma unroll
+        for (int r = 0; r < KC; ++r) {
+            const unsigned long long bal = __ballot(my_slot == r);
+            kept[r] = (int)__builtin_ctzll(bal);
+        }
         // ---- (d) kept rows -> P, prefetched registers -> A[next], Q[next], S[cur] -----------------------
         f32x4 keep[2];
         if (colok) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) keep[t] = *(const lf4*)&L[s_coff[s_slot[cur][2 * t + half]] + col];
+            for (int t = 0; t < 2; ++t) keep[t] = *(const lf4*)&L[s_coff[kept[2 * t + half]] + col];
         }
         if (colok) {                        // P is only read in (b); kept rows live in A[cur] / S[prv], not written here
 #pragma unroll
@@ -403,7 +413,31 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 else if (r < 13) *(lf4*)&L[offS + (cur * 8 + (r - 5)) * D + col] = pre[t];
             }
         }
-        if (tid < 4) { const int sl = s_slot[cur][tid]; s_idP[tid] = s_cand[sl]; s_pnP[tid] = s_cpn[sl]; }
+        if (use_f0 && my_kind >= 0) my_f0 = log2_rn(my_f0 + 1e-5f);      // one evaluation per new row, 13 lanes of wave 0
+        // next frame's candidate table, straight from the prefetch registers of wave 0 (lanes 0..12):
+        // slots 0-3 = its kNN rows, slots 4-7 = successors of the rows kept now
+        {
+            long nid = my_id; float npn = my_pn, nf0 = my_f0;
+            int ksl = 0;
+            if (tid >= KC && tid < NC) {
+#pragma unroll
+                for (int r = 0; r < KC; ++r) if (tid - KC == r) ksl = kept[r];
+            }
+            const int src = 5 + ksl;
+            const long sid = __shfl(my_id, src, 64); const float spn = __shfl(my_pn, src, 64), sf = __shfl(my_f0, src, 64);
+            long pid = 0; float ppn = 0.f;
+            if (tid < KC) {
+#pragma unroll
+                for (int r = 0; r < KC; ++r) if (tid == r) { pid = s_cand[kept[r]]; ppn = s_cpn[kept[r]]; }
+            }
+            if (wave == 0) {
+                // every lane of wave 0 has read the old table above; LDS ops of one wave execute in order
+                if (tid < KC) { s_idP[tid] = pid; s_pnP[tid] = ppn; }
+                if (tid < KC) { s_candT[prv][tid] = nid; s_cpnT[prv][tid] = npn; s_cf0T[prv][tid] = nf0; s_coffT[prv][tid] = offA + (prv * 4 + tid) * D; }
+                else if (tid < NC) { s_candT[prv][tid] = sid; s_cpnT[prv][tid] = spn; s_cf0T[prv][tid] = sf; s_coffT[prv][tid] = offS + (cur * 8 + ksl) * D; }
+            }
+        }
+        if (tid < 4 && i + 2 < nq) s_idNext[cur][tid] = nn_id;
         if (my_kind == 0) { s_idA[prv][tid] = my_id; s_pnA[prv][tid] = my_pn; s_f0A[prv][tid] = my_f0; }
         else if (my_kind == 1) { s_qn[prv] = my_pn; s_sf0[prv] = my_f0; }
         else if (my_kind == 2) { s_idS[cur][tid - 5] = my_id; s_pnS[cur][tid - 5] = my_pn; s_f0S[cur][tid - 5] = my_f0; }
