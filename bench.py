@@ -52,6 +52,7 @@ class GemmTimer:
         self.enabled = False
         self.all_variants = False
         self.dominant = "H128"
+        self.dom_bytes = 0
         self._orig = ops.conv_gemm
 
     def install(self):
@@ -78,6 +79,9 @@ class GemmTimer:
             else:
                 var = "G" + tile + ("v8" if fast else "v4" if vec4 else "v1")
             self.records.append((e0, e1, flop, (kw["m"], kw["n"], kw["cin"] * kw.get("taps", 1), kw.get("batches", 1) * kw.get("groups", 1)), var))
+            if var == self.dominant:      # algorithmic floats moved: A read once (not im2col-expanded) + W + output
+                z = kw.get("batches", 1) * kw.get("groups", 1)
+                self.dom_bytes += z * (t_in * kw["cin"] + kw["n"] * K + kw["m"] * kw["n"])
             return r
         ops.conv_gemm = wrapped
 
@@ -93,7 +97,7 @@ def make_inputs(rank, dev):
     src, sf0 = S.synth_clip(n, seed=1000 + rank)
     pool = [S.synth_clip(30 * C.SAMPLE_RATE, seed=2000 + 100 * rank + i) for i in range(POOL_CLIPS)]
     g = lambda a: torch.from_numpy(a).to(dev)
-    return g(src), sf0 * 1.3, [g(w) for w, _ in pool], [f for _, f in pool]
+    return g(src), g(sf0 * 1.3), [g(w) for w, _ in pool], [g(f) for _, f in pool]      # audio AND f0 tracks resident in HBM
 
 
 STAGES = {}
@@ -117,10 +121,13 @@ class stage:
 
 
 def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
-    # STFT / harmonic amplitudes only need the raw audio: run them on a second stream next to the encoder
+    # The encoder is enqueued first (its first kernels are long, so the host runs ahead); STFT / harmonic
+    # amplitudes only need the raw audio and run on a second stream next to it.
     main = torch.cuda.current_stream()
     side = _side_stream(src.device)
     side.wait_stream(main)
+    with stage("wavlm"):
+        feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
     with torch.cuda.stream(side):
         with stage("side_features"):
             qf0, _, _ = side_features(src, sf0, 1500)
@@ -129,8 +136,6 @@ def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
                 a, b, _ = side_features(w, f, 1500)
                 f0s.append(a); harms.append(b)
             Pf0_loc, Ph_loc = torch.cat(f0s).contiguous(), torch.cat(harms).contiguous()
-    with stage("wavlm"):
-        feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
     qf = feats[-1]
     assert qf.shape[0] == 1500
     P_loc = torch.cat(feats[:-1]).contiguous()
@@ -214,7 +219,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--max-batch", type=int, default=8, help="30 s chunks per WavLM batch")
+    ap.add_argument("--max-batch", type=int, default=32, help="30 s chunks per WavLM batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print per-stage ms to stderr")
     a = ap.parse_args()
@@ -235,7 +240,6 @@ def main():
     src, sf0, pool_w, pool_f0 = make_inputs(rank, dev)
     timer = GemmTimer()
     timer.install()
-    stage.on = a.stages
     timer.all_variants = a.stages
 
     def barrier():
@@ -247,12 +251,22 @@ def main():
         for _ in range(a.warmup):
             y = step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
         barrier()
-        timer.enabled = True
         t0 = time.perf_counter()
         for _ in range(a.steps):
             y = step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
         barrier()
         dt = time.perf_counter() - t0
+        # Roofline pass: the timed region replays hipGraphs (encoder, vocoder), and HIP events cannot be
+        # recorded around individual launches inside a replayed graph.  The same K steps are therefore run
+        # once more eagerly with an event pair around every launch of the dominant kernel, on its own stream.
+        enc.use_graphs = voc.use_graphs = False
+        timer.enabled = True
+        stage.on = a.stages
+        for _ in range(a.steps):
+            step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
+        barrier()
+        timer.enabled = False
+        enc.use_graphs = voc.use_graphs = True
     assert y.numel() == SRC_SECONDS * C.SAMPLE_RATE, y.numel()          # 1500 frames x 320
     assert bool(torch.isfinite(y).all()), "non-finite waveform"
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -268,7 +282,7 @@ def main():
             print(f"[gemm] {shp[0]:6s} m={shp[1]:7d} n={shp[2]:5d} k={shp[3]:5d} z={shp[4]:3d}  x{cnt // a.steps:3d}/step  {ms / a.steps:8.3f} ms/step  {fl / ms / 1e9:7.1f} TFLOP/s",
                   file=sys.stderr)
         for k, ev in STAGES.items():
-            ms = [x.elapsed_time(y_) for x, y_ in ev[a.warmup:]]
+            ms = [x.elapsed_time(y_) for x, y_ in ev]
             print(f"[stage] {k:14s} {sum(ms) / max(1, len(ms)):9.3f} ms/step", file=sys.stderr)
 
     if rank == 0:
@@ -291,10 +305,18 @@ def main():
                          "note": "achieved = algorithmic fp32 FLOP (2*M*N*K per launch) / HIP-event time; peak = dense bf16 "
                                  "MFMA peak 2500 TFLOP/s / 6 MFMAs per product; executed bf16 MFMA rate = 6 x achieved",
                          "frac_of_fp32_mfma_peak_157.3": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "timing": "HIP events around each launch in an eager re-run of the same K steps right after the "
+                                   "timed region (which replays hipGraphs)",
                          "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(1, n_launch), 4),
                          "kernel_ms_per_step": round(gemm_ms / a.steps, 3)},
         }
         line["config"]["adam_iterations"] = [int(step.last["iters_wavlm"]), int(step.last["iters_harm"])]
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(pmc):      # measured offline with rocprofv3 --pmc (tools/pmc_traffic.py); bench.py cannot read PMCs itself
+            t = json.load(open(pmc))
+            line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes"
+            line["roofline"]["algorithmic_bytes_per_launch"] = int(4 * timer.dom_bytes / max(1, n_launch))
         if ws == 1 and not a.no_cpu_baseline:
             L = step.last
             c = lambda x: x.detach().cpu()

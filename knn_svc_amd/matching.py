@@ -71,7 +71,10 @@ def side_features(wav_gpu: torch.Tensor, f0_host: np.ndarray, T: int):
     assert spec.shape[0] >= T
     spec = spec[:T].contiguous()
     assert abs(len(f0_host) - T) <= 1 and len(f0_host) >= T, [len(f0_host), T]
-    f0 = torch.from_numpy(np.ascontiguousarray(f0_host[:T])).to(wav_gpu.device)
+    if isinstance(f0_host, torch.Tensor):           # already resident on the device
+        f0 = f0_host[:T].contiguous()
+    else:
+        f0 = torch.from_numpy(np.ascontiguousarray(f0_host[:T])).to(wav_gpu.device)
     harm = ops.harmonic_amps(spec, f0, C.N_HARM)
     return f0, harm, spec
 

@@ -96,6 +96,8 @@ class WavLMEncoder:
             ))
         self.rel_emb = state["encoder.layers.0.self_attn.relative_attention_bias.weight"].detach().float().cpu()
         self._tables = {}
+        self._graphs = {}          # (B, L) -> (hipGraph, static input, static output)
+        self.use_graphs = True
 
     # -------------------------------------------------------------------------------------------
     def n_frames(self, n_samples: int) -> int:
@@ -111,7 +113,31 @@ class WavLMEncoder:
         return self._tables[T]
 
     def encode_batch(self, wav: torch.Tensor) -> torch.Tensor:
-        """[B, L] equal-length (already padded) chunks on the GPU -> [B, T, E]."""
+        """[B, L] equal-length (already padded) chunks on the GPU -> [B, T, E].
+
+        The ~70 launches of one batch are captured into a hipGraph per (B, L) and replayed: the schedule is
+        fixed-shape (30 s chunks), every kernel takes caller-owned buffers, and replay keeps the GPU fed even
+        when the host is slow or shared."""
+        key = tuple(wav.shape)
+        if not self.use_graphs or torch.cuda.is_current_stream_capturing():
+            return self._encode_batch(wav)
+        ent = self._graphs.get(key)
+        if ent is None:
+            sin = wav.clone()
+            self._encode_batch(sin)                        # warm-up: bias table upload, function attributes, pools
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._encode_batch(sin)
+            if len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = (g, sin, out)
+        g, sin, out = ent
+        sin.copy_(wav)
+        g.replay()
+        return out.clone()
+
+    def _encode_batch(self, wav: torch.Tensor) -> torch.Tensor:
         B, L = wav.shape
         dev = wav.device
         x = wav.contiguous()
