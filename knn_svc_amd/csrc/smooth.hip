@@ -16,16 +16,23 @@
 namespace {
 
 constexpr int KW = 4;           // neighbours per frame
-constexpr int GE = 36;          // unique entries of a symmetric 8x8
+constexpr int GE = 28;          // strict upper triangle of the symmetric 8x8 Gram matrix; the eight centred vectors sum
+                                // to zero, so every row of G sums to zero and the diagonal is implied:
+                                // (G c)_i = sum_{j != i} G_ij (c_j - c_i)
 
-__device__ __forceinline__ int tri(int i, int j) { return i <= j ? i * 8 - i * (i - 1) / 2 + (j - i) : j * 8 - j * (j - 1) / 2 + (i - j); }
+__device__ __forceinline__ int tri(int i, int j) { return i < j ? i * 7 - i * (i - 1) / 2 + (j - i - 1) : j * 7 - j * (j - 1) / 2 + (i - j - 1); }   // i != j
 
-// block per frame pair t: rows of term a: F[idx[t+1,k]-1] (k<4), F[idx[t,k]] ; term b: F[idx[t+1,k]], F[idx[t,k]+1]
+// block per frame pair t.  Both cost terms are quadratic forms in the SAME coefficient vector
+// c = [w[t+1,:], -w[t,:]] (term a over rows F[idx[t+1,k]-1], F[idx[t,k]]; term b over F[idx[t+1,k]], F[idx[t,k]+1]),
+// so only the sum of the two centred 8x8 Gram matrices is kept: its 28 off-diagonal entries per pair.
 __global__ __launch_bounds__(256) void gram_kernel(const long* __restrict__ idx, long nq, const float* __restrict__ pool,
                                                   long np, int dim, int ld, float* __restrict__ gram) {
     extern __shared__ float sm[];           // [8][dim] centred vectors of the current term
     const long t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[GE / 4];
+#pragma unroll
+    for (int q = 0; q < GE / 4; ++q) acc[q] = 0.0;
     for (int term = 0; term < 2; ++term) {
         __syncthreads();
         for (int c = tid; c < dim; c += 256) {
@@ -44,15 +51,20 @@ __global__ __launch_bounds__(256) void gram_kernel(const long* __restrict__ idx,
             for (int r = 0; r < 8; ++r) sm[r * dim + c] = v[r] - mean;
         }
         __syncthreads();
-        for (int e = wave; e < GE; e += 4) {
-            int i = 0, rem = e;                       // unpack e -> (i <= j)
-            while (rem >= 8 - i) { rem -= 8 - i; ++i; }
-            const int j = i + rem;
+#pragma unroll
+        for (int q = 0; q < GE / 4; ++q) {
+            const int e = wave + 4 * q;
+            int i = 0, rem = e;                       // unpack e -> (i < j)
+            while (rem >= 7 - i) { rem -= 7 - i; ++i; }
+            const int j = i + 1 + rem;
             double s = 0.0;
             for (int c = lane; c < dim; c += 64) s += (double)sm[i * dim + c] * (double)sm[j * dim + c];
-            s = wave_sum_d(s);
-            if (lane == 0) gram[((long)(term * GE + e)) * nq + t] = (float)s;
+            acc[q] += wave_sum_d(s);
         }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < GE / 4; ++q) gram[((long)(wave + 4 * q)) * nq + t] = (float)acc[q];
     }
 }
 
@@ -96,16 +108,15 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
             const f32x4 w1 = *(const f32x4*)&xw[(t + 1) * KW], w0 = *(const f32x4*)&xw[t * KW];
             const float c[8] = {w1[0], w1[1], w1[2], w1[3], -w0[0], -w0[1], -w0[2], -w0[3]};
             float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int term = 0; term < 2; ++term) {
+            {
                 float g[GE];
 #pragma unroll
-                for (int e = 0; e < GE; ++e) g[e] = gram[((long)(term * GE + e)) * nq + t];
+                for (int e = 0; e < GE; ++e) g[e] = gram[((long)e) * nq + t];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float s = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) s += g[tri(i, j)] * c[j];
+                    for (int j = 0; j < 8; ++j) if (j != i) s += g[tri(i, j)] * (c[j] - c[i]);
                     y[i] += s;
                 }
             }
@@ -175,12 +186,136 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
     if (tid == 0 && out_iters) out_iters[0] = it;
 }
 
+// Same loop with everything a thread needs for its (up to FPT) frames in registers: the 36-entry Gram of
+// each frame pair, theta, Adam moments, amsgrad maximum and the best iterate.  Only the softmax weights and
+// the gradient contribution of the left neighbour travel through LDS; an iteration costs three barriers and
+// no global memory traffic (the global-state variant streams ~150 KB of Gram data per iteration through one CU).
+template <int FPT>
+__global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float scale, int max_iter,
+                                                      const float* __restrict__ gram, float* __restrict__ out_w,
+                                                      int* __restrict__ out_iters) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double red[8];
+    __shared__ float s_loss;
+    float* xw = sm;                       // [nq][4]
+    float* xg = sm + nq * KW;             // [nq][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double S = (double)scale / ((double)dim * (double)(nq - 1));
+    const float twoS = (float)(2.0 * S);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float g[FPT][GE];
+    f32x4 th[FPT], mm[FPT], vv[FPT], vm[FPT], best[FPT], gs[FPT];
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+        const long t = tid + 512L * f;
+        th[f] = mm[f] = vv[f] = vm[f] = best[f] = gs[f] = zero;
+#pragma unroll
+        for (int e = 0; e < GE; ++e) g[f][e] = (t < nq - 1) ? gram[(long)e * nq + t] : 0.f;
+    }
+    double min_loss = 20000.0, conv_min = 20000.0;
+    int since = 0, it = 0;
+    const float b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
+    double pb1 = 1.0, pb2 = 1.0;
+    for (it = 0; it < max_iter; ++it) {
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) {
+            const long t = tid + 512L * f;
+            if (t < nq) {
+                const float mx = fmaxf(fmaxf(th[f][0], th[f][1]), fmaxf(th[f][2], th[f][3]));
+                f32x4 e = {expf(th[f][0] - mx), expf(th[f][1] - mx), expf(th[f][2] - mx), expf(th[f][3] - mx)};
+                const float den = (e[0] + e[1]) + (e[2] + e[3]);
+                *(f32x4*)&xw[t * KW] = e / den;
+            }
+        }
+        __syncthreads();
+        double lsum = 0.0;
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) {
+            const long t = tid + 512L * f;
+            if (t < nq - 1) {
+                const f32x4 w1 = *(const f32x4*)&xw[(t + 1) * KW], w0 = *(const f32x4*)&xw[t * KW];
+                const float c[8] = {w1[0], w1[1], w1[2], w1[3], -w0[0], -w0[1], -w0[2], -w0[3]};
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j != i) s += g[f][tri(i, j)] * (c[j] - c[i]);
+                    y[i] = s;
+                }
+                float qf = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qf += c[i] * y[i];
+                lsum += (double)qf;
+                *(f32x4*)&xg[(t + 1) * KW] = (f32x4){twoS * y[0], twoS * y[1], twoS * y[2], twoS * y[3]};
+                gs[f] = (f32x4){-twoS * y[4], -twoS * y[5], -twoS * y[6], -twoS * y[7]};
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one frame at a time: keeps the matvec temporaries of different frames from coexisting
+        }
+        lsum = wave_sum_d(lsum);
+        if (lane == 0) red[wave] = lsum;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < 8; ++i) tot += red[i];
+            s_loss = (float)(S * tot);
+        }
+        __syncthreads();
+        const float loss = s_loss;
+        if (it % 100 == 1) {
+            if (fabs(min_loss - conv_min) < 1e-5) break;
+            conv_min = min_loss;
+        }
+        const bool improved = loss < (float)min_loss;
+        if (improved) { min_loss = (double)loss; since = 0; } else ++since;
+        if (since >= 1000) break;
+        pb1 *= 0.9; pb2 *= 0.999;
+        const float step_size = (float)(-(0.1 / (1.0 - pb1)));
+        const float bc2_sqrt = (float)sqrt(1.0 - pb2);
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) {
+            const long t = tid + 512L * f;
+            if (t < nq) {
+                const f32x4 w = *(const f32x4*)&xw[t * KW];
+                f32x4 gg = zero;
+                if (t >= 1) gg = *(const f32x4*)&xg[t * KW];
+                if (t < nq - 1) gg += gs[f];
+                const float dotwg = (w[0] * gg[0] + w[1] * gg[1]) + (w[2] * gg[2] + w[3] * gg[3]);
+                const f32x4 gt = w * (gg - dotwg);
+                if (improved) best[f] = th[f];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    mm[f][k] = mm[f][k] + (gt[k] - mm[f][k]) * omb1;
+                    vv[f][k] = vv[f][k] * b2 + (omb2 * gt[k]) * gt[k];
+                    vm[f][k] = fmaxf(vm[f][k], vv[f][k]);
+                    const float denom = sqrtf(vm[f][k]) / bc2_sqrt + eps;
+                    th[f][k] = th[f][k] + step_size * (mm[f][k] / denom);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();            // xw / xg are rewritten by the next iteration
+    }
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+        const long t = tid + 512L * f;
+        if (t < nq) {
+            const f32x4 b = best[f];
+            const float mx = fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]));
+            f32x4 e = {expf(b[0] - mx), expf(b[1] - mx), expf(b[2] - mx), expf(b[3] - mx)};
+            const float den = (e[0] + e[1]) + (e[2] + e[3]);
+            *(f32x4*)&out_w[t * KW] = e / den;
+        }
+    }
+    if (tid == 0 && out_iters) out_iters[0] = it;
+}
+
 __global__ void fill_quarter_kernel(float* w, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] = 0.25f;
 }
 
-inline size_t ws_floats(long nq) { return (size_t)(2 * GE) * nq + (size_t)6 * 4 * nq + (size_t)2 * 4 * nq; }
+inline size_t ws_floats(long nq) { return (size_t)GE * nq + (size_t)6 * 4 * nq + (size_t)2 * 4 * nq; }
 
 }  // namespace
 
@@ -202,8 +337,8 @@ extern "C" int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float
         return knnsvc_check_launch("smooth_weights(fill)");
     }
     float* base = (float*)(((uintptr_t)workspace + 63) & ~(uintptr_t)63);
-    float* gram = base;                                 // [72][nq]
-    float* state = gram + (size_t)(2 * GE) * nq;        // theta, m, v, vmax, best, scratch : 6 x [nq] float4
+    float* gram = base;                                 // [36][nq]
+    float* state = gram + (size_t)GE * nq;        // theta, m, v, vmax, best, scratch : 6 x [nq] float4
     float* xch = state + (size_t)6 * 4 * nq;            // [2][nq][4] when LDS is too small
     const size_t gl = (size_t)8 * dim * 4;
     KN_REQUIRE(gl <= 150 * 1024, "smooth_weights: feature dim too large for LDS");
@@ -217,6 +352,25 @@ extern "C" int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float
                        dim, ld, gram);
     int rc = knnsvc_check_launch("gram");
     if (rc) return rc;
+    if (nq <= 1536) {            // register-resident loop
+        const size_t rl = (size_t)nq * 2 * KW * 4;
+        static size_t rattr = 0;
+#define KN_ADAM(F)                                                                                                     \
+    {                                                                                                                  \
+        if (rl > rattr) {                                                                                              \
+            if (hipFuncSetAttribute((const void*)adam_reg_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess || \
+                hipFuncSetAttribute((const void*)adam_reg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess || \
+                hipFuncSetAttribute((const void*)adam_reg_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess)   \
+                return knnsvc_fail(KNNSVC_EHIP, "smooth_weights: hipFuncSetAttribute failed");                         \
+            rattr = 65536;                                                                                             \
+        }                                                                                                              \
+        hipLaunchKernelGGL(adam_reg_kernel<F>, dim3(1), dim3(512), rl, st, (long)nq, dim, scale, max_iter,              \
+                           (const float*)gram, out_w, out_iters);                                                      \
+    }
+        if (nq <= 512) KN_ADAM(1) else if (nq <= 1024) KN_ADAM(2) else KN_ADAM(3)
+#undef KN_ADAM
+        return knnsvc_check_launch("adam_reg");
+    }
     size_t al = (size_t)nq * 2 * KW * 4;
     int use_lds = al <= 144 * 1024;
     if (!use_lds) al = 0;
