@@ -10,6 +10,7 @@
 // trip for P.  The bias is gate[query] * table[key - query + T - 1], read from a per-head LDS
 // copy of the (2T-1)-entry table; nothing T x T ever reaches HBM.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -146,6 +147,223 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16x3 variant: the same transposed flash schedule, but every fp32 product of S^T = K.Q^T and
+// O^T += V^T.P^T is evaluated as six v_mfma_f32_32x32x16_bf16 on truncation-split operands
+// (x = hi + mid + lo, see gemm3_core.h): fp32-level accuracy at 6/16 of the fp32-MFMA cycles.
+//   K tile  : LDS [64 keys][3 planes][64 d] bf16, row pitch 400 B  (A operand of K.Q^T, ds_read_b128)
+//   V tile  : LDS [64 d][3 planes][64 keys] bf16, row pitch 392 B  (transposed while staged; A operand of
+//             V^T.P^T needs 8 keys per lane: two runs of 4 keys, in the order the S^T accumulator
+//             registers hold them -> two ds_read_b64)
+//   Q       : split once into registers (B operand of K.Q^T)
+//   P       : exp() results are split in registers and used directly as the B operand of V^T.P^T
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned au32x2 __attribute__((ext_vector_type(2)));
+constexpr int KP3 = 400;      // K row pitch (bytes)
+constexpr int VP3 = 392;      // V^T row pitch (bytes)
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(h & 0xFFFF0000u);
+    m = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = __float_as_uint(r2);
+}
+__device__ __forceinline__ unsigned pack_hi(unsigned b, unsigned a) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
+                                                           const float* __restrict__ table, int T, int heads,
+                                                           float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) char lc;
+    typedef __attribute__((address_space(3))) au32x4 l_u4;
+    typedef __attribute__((address_space(3))) au32x2 l_u2;
+    typedef __attribute__((address_space(3))) unsigned short l_u16;
+    typedef __attribute__((address_space(3))) float l_f;
+    lc* Ks = (lc*)lds;                       // 64 * 400
+    lc* Vs = Ks + KT * KP3;                  // 64 * 392
+    l_f* tb = (l_f*)(Vs + HD * VP3);         // [2T-1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int E = heads * HD;
+    const long ld = 3L * E;
+    const float* base = qkv + (long)b * T * ld;
+    const int qi = blockIdx.x * 128 + wave * 32 + li;
+    const bool qvalid = qi < T;
+
+    for (int i = tid; i < 2 * T - 1; i += 256) tb[i] = table[(long)head * (2 * T - 1) + i];
+
+    // Q (scaled) split into three planes: qf[s][p] = 8 bf16 of d = 16 s + 8 h + 0..7
+    au32x4 qf[4][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (qvalid) {
+            const float* p = base + (long)qi * ld + head * HD + s * 16 + lh * 8;
+            v0 = *(const f32x4*)p; v1 = *(const f32x4*)(p + 4);
+        }
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { split3(v0[e] * 0.125f, h[e], m[e], l[e]); split3(v1[e] * 0.125f, h[4 + e], m[4 + e], l[4 + e]); }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            qf[s][0][w] = pack_hi(h[2 * w + 1], h[2 * w]);
+            qf[s][1][w] = pack_hi(m[2 * w + 1], m[2 * w]);
+            qf[s][2][w] = pack_hi(l[2 * w + 1], l[2 * w]);
+        }
+    }
+    const float g_i = qvalid ? gate[((long)b * T + qi) * heads + head] : 0.f;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    const int srow = tid >> 4, scol = (tid & 15) * 4;       // staging: rows (keys) srow + 16 j, d = scol..scol+3
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = k0 + srow + 16 * j;
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < T) {
+                const float* p = base + (long)key * ld + head * HD + scol;
+                kk = *(const f32x4*)(p + E);
+                vv = *(const f32x4*)(p + 2 * E);
+            }
+            rk[j] = kk; rv[j] = vv;
+        }
+    };
+    gload(0);
+    const int ntiles = (T + KT - 1) / KT;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = srow + 16 * j;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(rk[j][e], h[e], m[e], l[e]);
+            lc* kd = Ks + key * KP3 + scol * 2;
+            *(l_u2*)(kd) = (au32x2){pack_hi(h[1], h[0]), pack_hi(h[3], h[2])};
+            *(l_u2*)(kd + 128) = (au32x2){pack_hi(m[1], m[0]), pack_hi(m[3], m[2])};
+            *(l_u2*)(kd + 256) = (au32x2){pack_hi(l[1], l[0]), pack_hi(l[3], l[2])};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split3(rv[j][e], h[e], m[e], l[e]);
+                lc* vd = Vs + (scol + e) * VP3 + key * 2;              // transposed: row = d, column = key
+                *(l_u16*)(vd) = (unsigned short)(h[e] >> 16);
+                *(l_u16*)(vd + 128) = (unsigned short)(m[e] >> 16);
+                *(l_u16*)(vd + 256) = (unsigned short)(l[e] >> 16);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) gload((t + 1) * KT);
+
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kbase = t * KT + sub * 32;
+            if (kbase >= T) break;
+            // ---- S^T = K . Q^T : 4 d-steps x 6 products -----------------------------------------------
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const lc* kp = Ks + (sub * 32 + li) * KP3 + lh * 16;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bf16x8_t k0 = __builtin_bit_cast(bf16x8_t, *(const l_u4*)(kp + st * 32));
+                const bf16x8_t k1 = __builtin_bit_cast(bf16x8_t, *(const l_u4*)(kp + 128 + st * 32));
+                const bf16x8_t k2 = __builtin_bit_cast(bf16x8_t, *(const l_u4*)(kp + 256 + st * 32));
+                const bf16x8_t q0 = __builtin_bit_cast(bf16x8_t, qf[st][0]), q1 = __builtin_bit_cast(bf16x8_t, qf[st][1]),
+                               q2 = __builtin_bit_cast(bf16x8_t, qf[st][2]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q2, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, s, 0, 0, 0);
+            }
+            // ---- bias, mask, online softmax --------------------------------------------------------------
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = -__builtin_inff();
+                if (key < T && qvalid) v = s[r] + g_i * tb[key - qi + T - 1];
+                s[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = qvalid ? m_new : 0.f;
+            const float alpha = qvalid ? expf(m_run - m_use) : 1.f;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_use); ps += s[r]; }
+            ps += __shfl_xor(ps, 32, 64);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            // ---- O^T += V^T . P^T : 2 key-steps x 2 d-tiles x 6 products ---------------------------------------
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                unsigned h[8], m[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split3(s[8 * st + e], h[e], m[e], l[e]);
+                au32x4 p0, p1, p2;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    p0[w] = pack_hi(h[2 * w + 1], h[2 * w]); p1[w] = pack_hi(m[2 * w + 1], m[2 * w]); p2[w] = pack_hi(l[2 * w + 1], l[2 * w]);
+                }
+                const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, p0), b1 = __builtin_bit_cast(bf16x8_t, p1), b2 = __builtin_bit_cast(bf16x8_t, p2);
+                // element e of this lane's fragment is key sub*32 + 16 st + 8 (e>>2) + 4 h + (e&3): two runs of four keys
+                const int kcol = (sub * 32 + 16 * st + 4 * lh) * 2;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const lc* vp = Vs + (dt * 32 + li) * VP3 + kcol;
+                    au32x4 a0, a1, a2;
+                    const au32x2 x0 = *(const l_u2*)(vp), x1 = *(const l_u2*)(vp + 16);
+                    const au32x2 y0 = *(const l_u2*)(vp + 128), y1 = *(const l_u2*)(vp + 128 + 16);
+                    const au32x2 z0 = *(const l_u2*)(vp + 256), z1 = *(const l_u2*)(vp + 256 + 16);
+                    a0 = (au32x4){x0[0], x0[1], x1[0], x1[1]};
+                    a1 = (au32x4){y0[0], y0[1], y1[0], y1[1]};
+                    a2 = (au32x4){z0[0], z0[1], z1[0], z1[1]};
+                    const bf16x8_t v0 = __builtin_bit_cast(bf16x8_t, a0), v1 = __builtin_bit_cast(bf16x8_t, a1), v2 = __builtin_bit_cast(bf16x8_t, a2);
+                    f32x16 c = o[dt];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, b2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, b0, c, 0, 0, 0);
+                    o[dt] = c;
+                }
+            }
+        }
+    }
+    if (qvalid) {
+        const float inv = 1.0f / l_run;
+        float* op = out + ((long)b * T + qi) * E + head * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {o[d][r4 * 4 + 0] * inv, o[d][r4 * 4 + 1] * inv, o[d][r4 * 4 + 2] * inv, o[d][r4 * 4 + 3] * inv};
+                *(f32x4*)(op + d * 32 + r4 * 8 + lh * 4) = v;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
@@ -153,6 +371,21 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
     KN_REQUIRE(qkv && gate && table && out, "wavlm_attention: null pointer");
     KN_REQUIRE(batches > 0 && T > 0 && heads > 0 && heads <= 65535 && batches <= 65535, "wavlm_attention: bad sizes");
     KN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "wavlm_attention: 16-byte alignment");
+    static int use3 = -1;
+    if (use3 < 0) { const char* e = getenv("KNNSVC_ATTENTION"); use3 = (e && e[0] == 'f') ? 0 : 1; }   // "fp32" = exact-f32 MFMA kernel
+    if (use3) {
+        const size_t l3 = (size_t)KT * KP3 + (size_t)HD * VP3 + (size_t)(2 * T - 1) * 4;
+        KN_REQUIRE(l3 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~13000)");
+        static size_t attr3 = 0;
+        if (l3 > attr3) {
+            if (hipFuncSetAttribute((const void*)attention3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3) != hipSuccess)
+                return knnsvc_fail(KNNSVC_EHIP, "wavlm_attention: hipFuncSetAttribute failed");
+            attr3 = l3;
+        }
+        dim3 grid3((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batches);
+        hipLaunchKernelGGL(attention3_kernel, grid3, dim3(256), l3, (hipStream_t)stream, qkv, gate, table, T, heads, out);
+        return knnsvc_check_launch("wavlm_attention3");
+    }
     const size_t lds = (size_t)(KT * LDKK + KT * LDV + 2 * T - 1) * 4;
     KN_REQUIRE(lds <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~16000)");
     static size_t attr = 0;
