@@ -4,7 +4,10 @@
 
 namespace {
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float v) {
+#pragma clang fp contract(off)
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
 
 // one wave per R rows, rows kept in registers (R * dim <= 2048 floats per wave), two-pass mean / variance.
 // The R rows are independent chains (loads, reductions, stores), interleaved for memory-level parallelism.
@@ -12,6 +15,8 @@ template <int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long rows, int dim, int ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int gelu, float* __restrict__ out, int ldo) {
+#pragma clang fp contract(off)      // explicit fmaf only: every row slot runs the same roundings, so results do not
+                                    // depend on a row's position in the batch (bitwise batch invariance)
     const int lane = threadIdx.x & 63;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const int c = lane * 4 + 256 * i;
             if (c < dim) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mean[r]; q[r] += d * d; }
+                for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mean[r]; q[r] = fmaf(d, d, q[r]); }
             }
         }
     }
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = (v[r][i][e] - mean[r]) * rstd * g[e] + b[e];
+                    float t = fmaf((v[r][i][e] - mean[r]) * rstd, g[e], b[e]);
                     y[e] = gelu ? gelu_erf(t) : t;
                 }
                 *(f32x4*)(orow + c) = y;

@@ -1,0 +1,152 @@
+"""GPU: BASELINE-size runs checked through size-independent properties and sampled oracle rows, plus the
+edge cases of the path (ragged chunks, tiny pools, unvoiced tracks, single frames)."""
+import numpy as np
+import pytest
+import torch
+
+from knn_svc_amd import config as C, synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _smooth(x):
+    return (x + torch.roll(x, 1, 0) + torch.roll(x, 2, 0)) / 3
+
+
+@pytest.fixture(scope="module")
+def north_star_features():
+    """1500 query / 30000 pool rows of 1024-d features (BASELINE north-star point), temporally smooth."""
+    q = _smooth(S.clustered_features(1500, 1024, 1, n_centres=80))
+    p = _smooth(S.clustered_features(30000, 1024, 2, n_centres=80))
+    _, f0 = S.synth_clip(30000 * 320, 3); pf0 = torch.from_numpy(f0[:30000].copy())
+    _, f0 = S.synth_clip(1500 * 320, 4); qf0 = torch.from_numpy(f0[:1500].copy() * 1.2)
+    harm = torch.rand(30000, 49, generator=torch.Generator().manual_seed(5)) * 0.05
+    return q, p, qf0, pf0, harm
+
+
+def test_knn_full_size_properties(north_star_features):
+    from knn_svc_amd import ops
+    from oracle import knn_ref
+    q, p, *_ = north_star_features
+    qd, pd = q.to(DEV), p.to(DEV)
+    idx, dist = ops.knn_topk(qd, pd, 32)
+    idx_c, dist_c = idx.cpu(), dist.cpu()
+    # sortedness, range, uniqueness
+    assert bool((dist_c[:, 1:] >= dist_c[:, :-1]).all())
+    assert int(idx_c.min()) >= 0 and int(idx_c.max()) < 30000
+    assert all(len(set(r.tolist())) == 32 for r in idx_c[::50])
+    # sampled rows against the oracle (the reference's own formula)
+    rows = torch.arange(0, 1500, 47)
+    ref_i, ref_d = knn_ref.knn_topk(q[rows], p, 32)
+    st = knn_ref.topk_agreement(ref_i, idx_c[rows], knn_ref.cosine_dist_f64(q[rows], p), tau=5e-7)
+    print("full-size kNN, 32 sampled rows:", st)
+    assert st["unexplained"] == 0 and st["top4"] >= 0.9 and st["sets"] >= 0.9
+    assert float((dist_c[rows] - ref_d).abs().max()) < 5e-6
+    # determinism: the same launch twice is bit-identical
+    idx2, dist2 = ops.knn_topk(qd, pd, 32)
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+    # shard invariance at full size: 8 unequal shards merged == single search (device-count invariance)
+    cuts = [0, 3000, 7000, 11111, 15000, 19999, 24000, 27000, 30000]
+    pi, pdists = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        i, d = ops.knn_topk(qd, pd[a:b].contiguous(), 32, idx_offset=a)
+        pi.append(i); pdists.append(d)
+    mi, md = ops.knn_merge(torch.stack(pdists), torch.stack(pi))
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
+    # idempotence: pool rows queried against the pool find themselves first, at distance ~0
+    self_i, self_d = ops.knn_topk(pd[:256].contiguous(), pd, 4)
+    assert bool((self_i[:, 0].cpu() == torch.arange(256)).all()) and float(self_d[:, 0].abs().max()) < 1e-5
+
+
+def test_match_full_size_against_oracle_pieces(north_star_features):
+    """Whole match stage at 1500 x 30000: index stages vs the oracle, Adam by its objective."""
+    from knn_svc_amd.matching import match_features
+    from oracle import select_ref
+    q, p, qf0, pf0, harm = north_star_features
+    of, hw, sf0, dbg = match_features(q.to(DEV), qf0.to(DEV), p.to(DEV), pf0.to(DEV), harm.to(DEV), "mix", "post_opt_0.2",
+                                      return_debug=True)
+    nn32 = dbg["nn32"].cpu()
+    sh = select_ref.shift_query_f0(qf0, pf0)
+    assert float(((sf0.cpu() - sh).abs() / (sh.abs() + 1e-9)).max()) < 5e-6
+    ranked = select_ref.rerank_by_f0(sf0.cpu(), pf0, nn32)       # same shifted f0 -> same keys
+    sel = select_ref.concat_reselect(nn32[:300, :4].clone(), q[:300], p, concat_weight=0.2)
+    match = float((dbg["idx_wavlm"].cpu()[:300] == sel).all(1).float().mean())
+    sel2 = select_ref.concat_reselect(ranked[:300, :4].clone(), q[:300], p, sf0.cpu()[:300], pf0, concat_weight=0.2)
+    match2 = float((dbg["idx_harm"].cpu()[:300] == sel2).all(1).float().mean())
+    print(f"concat re-selection, first 300 of 1500 frames: plain {match:.3f}, pitched {match2:.3f}")
+    assert match >= 0.97 and match2 >= 0.97
+    for w, idx, pool, scale in ((dbg["w_wavlm"], dbg["idx_wavlm"], p, 0.1), (dbg["w_harm"], dbg["idx_harm"], harm, 1000.0)):
+        w, idx = w.cpu(), idx.cpu()
+        assert float((w.sum(1) - 1).abs().max()) < 1e-5 and float(w.min()) >= 0
+
+        def loss(wt):
+            g = {s: pool[torch.clamp(idx + s, 0, len(pool) - 1)] for s in (-1, 0, 1)}
+            e = {s: (g[s] * wt[..., None]).sum(1) for s in g}
+            return float(scale * ((e[-1][1:] - e[0][:-1]) ** 2).mean(-1).mean() + scale * ((e[0][1:] - e[1][:-1]) ** 2).mean(-1).mean())
+        l_opt, l_uniform = loss(w), loss(torch.full_like(w, 0.25))
+        print(f"smoothness loss: optimised {l_opt:.5f} vs uniform {l_uniform:.5f}")
+        assert l_opt < l_uniform
+    # weighted sums are what the weights say
+    ref = (p[dbg["idx_wavlm"].cpu().reshape(-1)].reshape(1500, 4, 1024) * dbg["w_wavlm"].cpu()[..., None]).sum(1)
+    assert float((of.cpu() - ref).abs().max()) < 1e-4
+
+
+def test_vocoder_30s_deterministic_and_graph_equals_eager():
+    from knn_svc_amd.vocoder import Vocoder
+    voc = Vocoder(S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, "mix"), 2), C.HIFIGAN_V1, "mix", DEV)
+    g = torch.Generator().manual_seed(0)
+    N = 1500
+    c = torch.randn(N, 1024, generator=g).to(DEV); harm = (torch.rand(N, 49, generator=g) * 0.02).to(DEV)
+    _, f0 = S.synth_clip(N * 320, 5); f0 = torch.from_numpy(f0[:N].copy()).to(DEV)
+    y1 = voc.forward(c, f0, harm)            # captures the hipGraph
+    y2 = voc.forward(c, f0, harm)            # replay
+    voc.use_graphs = False
+    y3 = voc.forward(c, f0, harm)            # eager
+    assert y1.numel() == N * 320 and bool(torch.isfinite(y1).all()) and float(y1.abs().max()) <= 1.0
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
+
+
+def test_wavlm_large_chunk_independence_and_ragged_tail():
+    """A 30 s chunk encodes to the same 1500 frames alone, in a batch, and in front of a ragged tail;
+    tails of <= 320 samples are dropped (ddsp_prematch_dataset.py:277-285)."""
+    from knn_svc_amd.wavlm import WavLMEncoder, chunk_plan
+    cfg = C.WAVLM_LARGE
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg, 2), seed=1), cfg, DEV, n_layers=2)
+    w, _ = S.synth_clip(30 * 16000 + 5000, 21)
+    wg = torch.from_numpy(w).to(DEV)
+    full = enc.full_features(wg)
+    assert full.shape == (1500 + enc.n_frames(5000 + 320 - 5000 % 320), 1024)
+    alone = enc.full_features(wg[:480000])
+    assert alone.shape[0] == 1500 and torch.equal(alone, full[:1500])
+    many = enc.encode_many([wg, wg[:480000], wg[:480000 + 300]])
+    assert torch.equal(many[0], full) and torch.equal(many[1], alone)
+    assert many[2].shape[0] == 1500                       # 300-sample tail dropped
+    assert [l for (_s, l, _p) in chunk_plan(480000 + 300)] == [480000]
+    assert [l for (_s, l, _p) in chunk_plan(480000 + 321)] == [480000, 321]
+
+
+def test_edge_cases():
+    from knn_svc_amd import ops
+    from knn_svc_amd._lib import KnnSvcError
+    from knn_svc_amd.matching import match_features
+    # pool smaller than k: the reference's topk(k=32) raises; so do we
+    q = torch.randn(5, 64, device=DEV); p = torch.randn(20, 64, device=DEV)
+    with pytest.raises(KnnSvcError):
+        ops.knn_topk(q, p, 32)
+    # single query frame, smallest legal pool, every frame unvoiced except two
+    q = S.clustered_features(1, 64, 1, n_centres=3).to(DEV); p = S.clustered_features(32, 64, 2, n_centres=3).to(DEV)
+    qf0 = torch.tensor([220.0], device=DEV); pf0 = torch.zeros(32, device=DEV); pf0[3] = 200.0; pf0[9] = 180.0
+    harm = torch.rand(32, 49, device=DEV)
+    of, hw, sf0 = match_features(q, qf0, p, pf0, harm, "mix", "post_opt_0.2")
+    assert of.shape == (1, 64) and hw.shape == (1, 49) and bool(torch.isfinite(of).all()) and bool(torch.isfinite(hw).all())
+    assert abs(float(sf0[0]) - 180.0) < 1e-3              # lower median of {180, 200} in the log domain
+    # two frames: one adjacent pair for the smoothness loop
+    q2 = S.clustered_features(2, 64, 3, n_centres=3).to(DEV)
+    of, hw, sf0 = match_features(q2, torch.tensor([0.0, 150.0], device=DEV), p, pf0, harm, "mix", "post_opt_0.2")
+    assert float(sf0[0]) == 0.0 and bool(torch.isfinite(of).all())
+    # additive synth: all-unvoiced track gives the 1e-7 mask floor, not NaN
+    cond = torch.empty(4 * 320, 32, device=DEV)
+    exc = ops.additive_synth(torch.zeros(4, device=DEV), torch.rand(4, 49, device=DEV), torch.randn(32, 3, device=DEV),
+                             torch.zeros(32, device=DEV), cond, 32, want_exc=True)
+    assert bool(torch.isfinite(exc).all()) and float(exc.abs().max()) < 1e-3
