@@ -17,14 +17,15 @@
 #pragma once
 #include "common.h"
 
-template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
+template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_, int NT_ = 256>
 struct GemmTile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
-    static constexpr int BK = 32, LDK = 36, THREADS = 256;
-    static_assert(WM * WN == 4, "4 waves per block");
+    static constexpr int BK = 32, LDK = 36, THREADS = NT_;
+    static constexpr int RP = THREADS / 8;        // rows staged per pass (8 float4 per 32-float row)
+    static_assert(WM * WN * 64 == THREADS, "one wave per (wm, wn)");
     static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    static constexpr int A_F4 = BM / 32;      // float4 per thread per slab (256 thr x 8 f4/row)
-    static constexpr int B_F4 = BN / 32;
+    static constexpr int A_F4 = BM / RP;      // float4 per thread per slab
+    static constexpr int B_F4 = BN / RP;
     static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 
@@ -60,9 +61,9 @@ struct GemmTile {
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) rb[j] = bload(0, j, rb_desc);
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j) *(lds_f4*)&lds[(srow + 32 * j) * LDK + skq] = aload.finish(ra[j]);
+        for (int j = 0; j < A_F4; ++j) *(lds_f4*)&lds[(srow + RP * j) * LDK + skq] = aload.finish(ra[j]);
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) *(lds_f4*)&lds[BM * LDK + (srow + 32 * j) * LDK + skq] = rb[j];
+        for (int j = 0; j < B_F4; ++j) *(lds_f4*)&lds[BM * LDK + (srow + RP * j) * LDK + skq] = rb[j];
         __syncthreads();
 
         const int li = lane & 31, lh = lane >> 5;
@@ -96,9 +97,9 @@ struct GemmTile {
             if (more) {
                 const int nxt = BUF - cur;
 #pragma unroll
-                for (int j = 0; j < A_F4; ++j) *(lds_f4*)&lds[nxt + (srow + 32 * j) * LDK + skq] = aload.finish(ra[j]);
+                for (int j = 0; j < A_F4; ++j) *(lds_f4*)&lds[nxt + (srow + RP * j) * LDK + skq] = aload.finish(ra[j]);
 #pragma unroll
-                for (int j = 0; j < B_F4; ++j) *(lds_f4*)&lds[nxt + BM * LDK + (srow + 32 * j) * LDK + skq] = rb[j];
+                for (int j = 0; j < B_F4; ++j) *(lds_f4*)&lds[nxt + BM * LDK + (srow + RP * j) * LDK + skq] = rb[j];
             }
             __syncthreads();
         }

@@ -12,7 +12,8 @@
 
 namespace {
 
-using G = GemmTile<128, 128, 2, 2, 2, 2>;
+using G = GemmTile<128, 128, 4, 2, 1, 2, 512>;      // 8 waves (two per SIMD inside the one block a CU can hold)
+constexpr int NT = 512;
 constexpr int KMAX = 32;
 constexpr unsigned long long KEY_INF = 0xFFFFFFFFFFFFFFFFull;
 
@@ -58,7 +59,7 @@ struct RowLoader {      // rows of a [rows][dim] row-major matrix, 16-byte vecto
     const float* base; long rows; int dim; long r0;
     __device__ __forceinline__ f32x4 operator()(int kt, int j, int) const {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const long r = r0 + (threadIdx.x >> 3) + 32 * j;
+        const long r = r0 + (threadIdx.x >> 3) + G::RP * j;
         const int k = kt * 32 + (threadIdx.x & 7) * 4;
         if (r < rows && k < dim) v = *(const f32x4*)(base + r * dim + k);
         return v;
@@ -69,17 +70,17 @@ struct RowLoader {      // rows of a [rows][dim] row-major matrix, 16-byte vecto
 
 constexpr int LDD = 128;                                  // distance tile pitch
 constexpr int LDS_STAGE = G::LDS_FLOATS;                  // 18432 floats (>= 128*128)
-constexpr int KNN_LDS_BYTES = LDS_STAGE * 4 + 128 * KMAX * 8 /*lists*/ + 4 * 128 * 8 /*scratch*/ + 128 * 4 * 2;
+constexpr int KNN_LDS_BYTES = LDS_STAGE * 4 + 128 * KMAX * 8 /*lists*/ + 8 * 128 * 8 /*scratch*/ + 128 * 4 * 2;
 
-__global__ __launch_bounds__(256) void knn_tile_kernel(
+__global__ __launch_bounds__(512) void knn_tile_kernel(
     const float* __restrict__ q, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
     const float* __restrict__ pool, const float* __restrict__ pn, const float* __restrict__ psq, long np,
     int dim, int k, long rows_per_split, unsigned long long* __restrict__ part, int* nan_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dist = lds;                                                       // [128][LDD] (aliases staging)
     unsigned long long* lists = (unsigned long long*)(lds + LDS_STAGE);      // [128][32]
-    unsigned long long* scratch = lists + 128 * KMAX;                        // [4 waves][128]
-    float* s_qn = (float*)(scratch + 4 * 128);
+    unsigned long long* scratch = lists + 128 * KMAX;                        // [8 waves][128]
+    float* s_qn = (float*)(scratch + 8 * 128);
     float* s_qsq = s_qn + 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(
     const long p_begin = (long)blockIdx.y * rows_per_split;
     const long p_end = p_begin + rows_per_split < np ? p_begin + rows_per_split : np;
 
-    for (int i = tid; i < 128 * KMAX; i += 256) lists[i] = KEY_INF;
+    for (int i = tid; i < 128 * KMAX; i += NT) lists[i] = KEY_INF;
     if (tid < 128) {
         const long r = q0 + tid;
         s_qn[tid] = r < nq ? qn[r] : 1.f;
@@ -98,11 +99,11 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(
     const int nk = (dim + 31) / 32;
     bool saw_nan = false;
     for (long p0 = p_begin; p0 < p_end; p0 += 128) {
-        f32x16 acc[2][2];
+        f32x16 acc[G::TM][G::TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < G::TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         RowLoader al{q, nq, dim, q0};
@@ -111,13 +112,13 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(
 
         // distances -> LDS tile [query][pool]
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < G::TN; ++j) {
             const int c = G::acc_col(wave, lane, j);
             const long p = p0 + c;
             const bool pv = p < p_end;
             const float v_pn = pv ? pn[p] : 1.f, v_psq = pv ? psq[p] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < G::TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = G::acc_row(wave, lane, i, r);
@@ -128,10 +129,10 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(
         }
         __syncthreads();
 
-        // selection: wave w owns query rows 32w .. 32w+31
+        // selection: wave w owns query rows 16w .. 16w+15
         unsigned long long* my_scratch = scratch + wave * 128;
-        for (int rr = 0; rr < 32; ++rr) {
-            const int row = wave * 32 + rr;
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = wave * 16 + rr;
             if (q0 + row >= nq) break;
             unsigned long long* lst = lists + row * KMAX;
             unsigned long long thr = lst[k - 1];
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(
     if (saw_nan) atomicOr(nan_flag, 1);
 
     // per-split lists -> workspace  part[split][q][k]
-    for (int i = tid; i < 128 * k; i += 256) {
+    for (int i = tid; i < 128 * k; i += NT) {
         const int row = i / k, e = i - row * k;
         if (q0 + row < nq) part[((long)blockIdx.y * nq + q0 + row) * k + e] = lists[row * KMAX + e];
     }
@@ -231,10 +232,13 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
 }
 
 int split_count(long nq, long np) {
+    // The kernel needs 109 KB of LDS, so one block is resident per CU: aim for ONE wave of <= 256 blocks and let
+    // every block walk as many 128-row pool tiles as possible — the first tile of a block pays a full top-32
+    // build for each of its 128 query rows (about as long as the tile's MFMA work), later tiles only filter.
     const long qtiles = cdiv64(nq, 128), ptiles = cdiv64(np, 128);
-    long s = cdiv64(768, qtiles);           // aim for ~3 waves of blocks over 256 CUs
-    if (s > ptiles) s = ptiles;
+    long s = 256 / qtiles;
     if (s < 1) s = 1;
+    if (s > ptiles) s = ptiles;
     if (s > 4096) s = 4096;
     return (int)s;
 }
@@ -281,7 +285,7 @@ extern "C" int knnsvc_knn_topk(const float* q, const float* q_norm, const float*
     const long rows_per_split = cdiv64(ptiles, S) * 128;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv64(nq, 128), (unsigned)S);
-    hipLaunchKernelGGL(knn_tile_kernel, grid, dim3(256), KNN_LDS_BYTES, st, q, q_norm, q_sq, (long)nq, pool, p_norm,
+    hipLaunchKernelGGL(knn_tile_kernel, grid, dim3(NT), KNN_LDS_BYTES, st, q, q_norm, q_sq, (long)nq, pool, p_norm,
                        p_sq, (long)np, dim, k, rows_per_split, (unsigned long long*)workspace, nan_flag);
     int rc = knnsvc_check_launch("knn_tile");
     if (rc) return rc;
