@@ -231,7 +231,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if ws > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ          # started by torch.distributed.run
+    if ws > 1 or launched:
         dist.init_process_group("nccl", device_id=dev)
     assert a.gpus == ws, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
 
@@ -243,7 +244,7 @@ def main():
     timer.all_variants = a.stages
 
     def barrier():
-        if ws > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -270,7 +271,7 @@ def main():
     assert y.numel() == SRC_SECONDS * C.SAMPLE_RATE, y.numel()          # 1500 frames x 320
     assert bool(torch.isfinite(y).all()), "non-finite waveform"
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if ws > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     n_launch, gemm_ms, gemm_flop = timer.summary()
@@ -325,7 +326,7 @@ def main():
                         iters_wavlm=int(L["iters_wavlm"]), iters_harm=int(L["iters_harm"]))
             line["cpu_baseline"] = cpu_baseline(snap)
         print(json.dumps(line), flush=True)
-    if ws > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

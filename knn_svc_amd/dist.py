@@ -32,8 +32,8 @@ def world():
 def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
     """Concatenate equal-shaped [n, ...] tensors of every rank along dim 0 (rank order)."""
     _r, ws = world()
-    if ws == 1:
-        return t
+    if not (dist.is_available() and dist.is_initialized()):
+        return t                      # single process without a process group
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous())
     return out
@@ -57,9 +57,9 @@ def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, lo
     local row j on rank r is r*np + j).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's
     queries."""
     rank, ws = world()
-    if ws == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_topk(q_local, pool_local, k, 0)
-    nq = q_local.shape[0]
+    nq = q_local.shape[0]                 # (a 1-rank group still walks the collective path: it is the same code)
     q_all = all_gather_rows(q_local)                                           # [ws*nq, D]
     idx, dst = local_topk(q_all, pool_local, k, rank * pool_local.shape[0])    # vs my shard, global ids
     dist_all = all_gather_rows(dst[None])                                      # [ws, ws*nq, k]
