@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import audio_io, config as C, features, ops
+from . import audio_io, config as C, features, ops, pool_cache
 from .wavlm import WavLMEncoder, chunk_plan
 
 AUDIO_EXT = {".flac", ".wav", ".mp3"}
@@ -84,25 +84,51 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     """Per-file dicts (matching_pool, synth_pool, audio_synth_pool, spec_synth_pool, f0_pool, harmonics_pool),
     like the reference.  matching == synth features (both weightings are the same one-hot on the live path);
     ``audio_synth_pool`` is kept as None values: the live path never reads it (audio_out_feats_weighted = None,
-    ddsp_prematch_dataset.py:1368)."""
+    ddsp_prematch_dataset.py:1368).  Per-file results are kept in the device-resident pool store
+    (knn_svc_amd/pool_cache.py) so that dataset mode encodes every file once instead of once per speaker pair."""
     dev = wavlm.device
     files = list_audio(path)
-    kept, wavs, f0s, Ts = [], [], [], []
+    cache = _pool_cache()
+    tag = (wavlm.uid, wavlm.n_layers)
+    kept, keys, Ts = [], [], []
+    loaded = {}                       # index -> (wav on device, f0 host) for files that miss the cache
     dur = 0.0
-    for pth in files:
-        w, f0 = load_utterance(pth)
-        T = frames_of(len(w), wavlm)
-        kept.append(str(pth)); wavs.append(torch.from_numpy(w).to(dev)); f0s.append(f0); Ts.append(T)
+    for i, pth in enumerate(files):
+        key = pool_cache.file_key(pth, tag)
+        ent = cache.get(key)
+        if ent is not None:
+            T = ent["feats"].shape[0]
+        else:
+            w, f0 = load_utterance(pth)
+            T = frames_of(len(w), wavlm)
+            loaded[i] = (torch.from_numpy(w).to(dev), f0)
+        kept.append(str(pth)); keys.append(key); Ts.append(T)
         dur += T * C.HOP / C.SAMPLE_RATE
         if duration_limit is not None and dur >= duration_limit:
             break
-    feats = wavlm.encode_many(wavs)
+    miss = sorted(loaded)
+    feats = wavlm.encode_many([loaded[i][0] for i in miss]) if miss else []
+    for i, ft in zip(miss, feats):
+        assert ft.shape[0] == Ts[i]
+        f0, harm, spec = side_features(loaded[i][0], loaded[i][1], Ts[i])
+        cache.put(keys[i], dict(feats=ft, f0=f0, harm=harm, spec=spec))
+        loaded[i] = dict(feats=ft, f0=f0, harm=harm, spec=spec)
     matching, synth, audio, specs, f0p, harmp = {}, {}, {}, {}, {}, {}
-    for key, w, f0h, T, ft in zip(kept, wavs, f0s, Ts, feats):
-        assert ft.shape[0] == T
-        f0, harm, spec = side_features(w, f0h, T)
-        matching[key] = ft; synth[key] = ft; audio[key] = None; specs[key] = spec; f0p[key] = f0; harmp[key] = harm
+    for i, key in enumerate(kept):
+        ent = loaded[i] if i in loaded else cache.get(keys[i])
+        matching[key] = ent["feats"]; synth[key] = ent["feats"]; audio[key] = None
+        specs[key] = ent["spec"]; f0p[key] = ent["f0"]; harmp[key] = ent["harm"]
     return matching, synth, audio, specs, f0p, harmp
+
+
+_POOL_CACHE = None
+
+
+def _pool_cache():
+    global _POOL_CACHE
+    if _POOL_CACHE is None:
+        _POOL_CACHE = pool_cache.PoolCache()
+    return _POOL_CACHE
 
 
 _SIDE = {}

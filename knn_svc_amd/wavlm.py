@@ -51,11 +51,14 @@ def chunk_plan(n_samples: int, sr: int = C.SAMPLE_RATE, hop: int = C.HOP):
 
 class WavLMEncoder:
     """Packed WavLM weights on one GPU + forward schedule."""
+    _uids = 0
 
     def __init__(self, state: dict, cfg: dict, device="cuda", n_layers: int = C.MATCH_LAYER):
         self.cfg = cfg
         self.device = torch.device(device)
         self.n_layers = n_layers
+        WavLMEncoder._uids += 1
+        self.uid = WavLMEncoder._uids          # identity of this weight set in the pool-feature store
         assert n_layers <= cfg["encoder_layers"]
         self.E = cfg["encoder_embed_dim"]
         self.H = cfg["encoder_attention_heads"]

@@ -94,3 +94,25 @@ def test_packers_roundtrip():
             if 0 <= o < 20 * u:
                 out[o] = row[ph]
     assert torch.allclose(out, yt, atol=1e-5)
+
+
+def test_pool_cache_lru_and_keys(tmp_path):
+    import numpy as np
+    import torch
+    from knn_svc_amd import pool_cache
+    a = tmp_path / "a.wav"; a.write_bytes(b"x" * 10); np.save(tmp_path / "a_f0.npy", np.zeros(3))
+    k1 = pool_cache.file_key(a, ("enc", 6))
+    assert k1 == pool_cache.file_key(a, ("enc", 6)) and k1 != pool_cache.file_key(a, ("enc", 2))
+    a.write_bytes(b"x" * 11)
+    assert pool_cache.file_key(a, ("enc", 6)) != k1                       # content change -> new identity
+    c = pool_cache.PoolCache(budget_bytes=3 * 400)
+    ent = lambda v: dict(feats=torch.full((100,), float(v)), f0=None)      # 400 bytes each
+    for i in range(3):
+        c.put(("f", i), ent(i))
+    assert c.get(("f", 0)) is not None                                    # refresh 0 -> 1 is now the oldest
+    c.put(("f", 3), ent(3))
+    assert c.get(("f", 1)) is None and c.get(("f", 0)) is not None and c.get(("f", 3)) is not None
+    assert c.used == 3 * 400 and c.hits == 3 and c.misses == 1
+    off = pool_cache.PoolCache(budget_bytes=0)
+    off.put(("f", 0), ent(0))
+    assert off.get(("f", 0)) is None

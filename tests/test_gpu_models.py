@@ -173,3 +173,54 @@ def test_special_match_writes_reference_named_file(golden, tmp_path):
     x, sr = audio_io.read_wav(str(out))
     assert sr == 16000 and x.shape == (1, y.numel())
     assert np.max(np.abs(x[0] - np.clip(y.cpu().numpy(), -1, 1))) < 1e-6
+
+
+def test_bulk_match_dataset_mode_uses_pool_store(tmp_path):
+    """Folder -> folder conversion (ddsp_matcher.py:1027-1155): output tree, subset file, duration-limit prefix,
+    and the device-resident pool store (every file encoded once, identical waveforms with the store off)."""
+    from knn_svc_amd import matching, pool_cache
+    from knn_svc_amd.inference import output_dir_for
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+    knn = KNeighborsVC(enc, Vocoder(S.seeded_state(S.generator_param_spec(h, "mix"), 63), h, "mix", DEV), h, DEV)
+    root = tmp_path / "data"
+    for s, spk in enumerate(("spkA", "spkB", "spkC")):
+        (root / spk).mkdir(parents=True)
+        for u in range(2):
+            w, f = S.synth_clip(16000 + 320 * (s + u), seed=300 + 10 * s + u)
+            audio_io.write_wav_pcm16(str(root / spk / f"u{u}.wav"), w, 16000)
+            np.save(root / spk / f"u{u}_f0.npy", f)
+    csvp = tmp_path / "subset.csv"
+    csvp.write_text("src,tgt,key,x,label\n" + "".join(f"a,b,u0/{t},x,0\n" for t in ("spkA", "spkB", "spkC")) + "a,b,u1/spkB,x,1\n")
+
+    def run(out_dir):
+        calls = {"n": 0}
+        orig = enc.encode_many
+        def counted(wavs, **kw):
+            calls["n"] += len(wavs)
+            return orig(wavs, **kw)
+        enc.encode_many = counted
+        try:
+            written = knn.bulk_match(str(root), str(root), str(out_dir), ckpt_type="mix", post_opt="post_opt_0.2",
+                                     required_subset_file=str(csvp), duration_limit=100)
+        finally:
+            enc.encode_many = orig
+        return written, calls["n"]
+    matching._POOL_CACHE = pool_cache.PoolCache()
+    out1 = output_dir_for(str(root), str(root), "mix", "post_opt_0.2", 100)
+    assert "duration_limit_100_data_to_data_mix_post_opt_post_opt_0.2" in out1
+    w1, n1 = run(tmp_path / "o1")
+    # 3 x 2 ordered speaker pairs, only utterance u0 is in the subset (label 0), one output per pair
+    assert len(w1) == 6 and all(p.endswith(".wav") and "/u0/" in p for p in w1)
+    assert (tmp_path / "o1" / "spkA" / "u0" / "spkB.wav").is_file()
+    assert n1 == 6                                         # six files, each encoded exactly once
+    matching._POOL_CACHE = pool_cache.PoolCache(budget_bytes=0)
+    w2, n2 = run(tmp_path / "o2")
+    assert n2 == 24                                        # the reference's behaviour: both pools per pair
+    for a, b in zip(sorted(w1), sorted(w2)):
+        xa, _ = audio_io.read_wav(a); xb, _ = audio_io.read_wav(b)
+        assert np.array_equal(xa, xb)
+    matching._POOL_CACHE = None
