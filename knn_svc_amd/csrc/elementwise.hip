@@ -306,8 +306,12 @@ extern "C" int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, co
     const long T = (L - k) / stride + 1;
     dim3 grid((unsigned)cdiv64(T, 64), (unsigned)batches);
     hipStream_t st = (hipStream_t)stream;
-#define KN_C0(CPL) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, 16>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out)
-    if (channels == 512) KN_C0(8); else if (channels == 256) KN_C0(4); else if (channels == 128) KN_C0(2); else KN_C0(1);
+#define KN_C0(CPL, KM) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, KM>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out)
+    if (k <= 10) {        // WavLM's k = 10: no padded taps in the unrolled FIR
+        if (channels == 512) KN_C0(8, 10); else if (channels == 256) KN_C0(4, 10); else if (channels == 128) KN_C0(2, 10); else KN_C0(1, 10);
+    } else {
+        if (channels == 512) KN_C0(8, 16); else if (channels == 256) KN_C0(4, 16); else if (channels == 128) KN_C0(2, 16); else KN_C0(1, 16);
+    }
 #undef KN_C0
     return knnsvc_check_launch("wavlm_conv0");
 }
