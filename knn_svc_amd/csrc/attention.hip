@@ -196,8 +196,12 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
     const int qi = blockIdx.x * 128 + wave * 32 + li;
     const bool qvalid = qi < T;
 
-    for (int i = tid; i < 2 * T - 1; i += 256) tb[i] = table[(long)head * (2 * T - 1) + i];
+    // bias table + 64 zero floats: the last key tile indexes past 2T-2 before it is masked
+    for (int i = tid; i < 2 * T - 1 + 64; i += 256) tb[i] = i < 2 * T - 1 ? table[(long)head * (2 * T - 1) + i] : 0.f;
 
+    // scores live in the log2 domain (softmax via v_exp_f32): Q carries 1/8 * log2(e)
+    const float L2E = 1.44269504088896341f;
+    const float qscale = 0.125f * L2E;
     // Q (scaled) split into three planes: qf[s][p] = 8 bf16 of d = 16 s + 8 h + 0..7
     au32x4 qf[4][3];
 #pragma unroll
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
         }
         unsigned h[8], m[8], l[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { split3(v0[e] * 0.125f, h[e], m[e], l[e]); split3(v1[e] * 0.125f, h[4 + e], m[4 + e], l[4 + e]); }
+        for (int e = 0; e < 4; ++e) { split3(v0[e] * qscale, h[e], m[e], l[e]); split3(v1[e] * qscale, h[4 + e], m[4 + e], l[4 + e]); }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             qf[s][0][w] = pack_hi(h[2 * w + 1], h[2 * w]);
@@ -217,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
             qf[s][2][w] = pack_hi(l[2 * w + 1], l[2 * w]);
         }
     }
-    const float g_i = qvalid ? gate[((long)b * T + qi) * heads + head] : 0.f;
+    const float g_i = qvalid ? gate[((long)b * T + qi) * heads + head] * L2E : 0.f;
+    const l_f* tbq = tb + (T - 1 - (qvalid ? qi : T - 1)) + 4 * lh;     // tbq[key] = table[key - qi + T - 1]
 
     f32x16 o[2];
 #pragma unroll
@@ -291,29 +296,33 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, s, 0, 0, 0);
             }
             // ---- bias, mask, online softmax --------------------------------------------------------------
-            float mx = -__builtin_inff();
+            // rows past T hold zero Q (and zero gate): their scores are finite, nothing is written for them
+            const l_f* tp = tbq + kbase;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = -__builtin_inff();
-                if (key < T && qvalid) v = s[r] + g_i * tb[key - qi + T - 1];
-                s[r] = v;
-                mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(g_i, tp[(r & 3) + 8 * (r >> 2)], s[r]);
+            if (kbase + 32 > T) {                                    // wave-uniform: only the last key tile masks
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= T) s[r] = -__builtin_inff();
             }
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+            for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = qvalid ? m_new : 0.f;
-            const float alpha = qvalid ? expf(m_run - m_use) : 1.f;
+            const float m_new = fmaxf(m_run, mx);                    // key 0 is always valid: finite from the first tile on
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_use); ps += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ps += s[r]; }
             ps += __shfl_xor(ps, 32, 64);
             l_run = l_run * alpha + ps;
             m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
             // ---- O^T += V^T . P^T : 2 key-steps x 2 d-tiles x 6 products ---------------------------------------
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -374,7 +383,7 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
     static int use3 = -1;
     if (use3 < 0) { const char* e = getenv("KNNSVC_ATTENTION"); use3 = (e && e[0] == 'f') ? 0 : 1; }   // "fp32" = exact-f32 MFMA kernel
     if (use3) {
-        const size_t l3 = (size_t)KT * KP3 + (size_t)HD * VP3 + (size_t)(2 * T - 1) * 4;
+        const size_t l3 = (size_t)KT * KP3 + (size_t)HD * VP3 + (size_t)(2 * T - 1 + 64) * 4;
         KN_REQUIRE(l3 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~13000)");
         static size_t attr3 = 0;
         if (l3 > attr3) {
