@@ -11,9 +11,9 @@ architectures (no network for the released checkpoints).  value = source seconds
 ranks / wall time of the slowest rank.
 
 Extra objects on the JSON line:
-  roofline     — the dominant kernel (fp32-MFMA implicit GEMM, 128x128 tile): algorithmic FLOP
-                 (2*M*N*K per launch) / HIP-event time of those launches inside the timed region,
-                 against the 157.3 TFLOP/s dense fp32 matrix peak;
+  roofline     — the dominant kernel (implicit GEMM, 128x128 tile, fp32 emulated as three fp16 MFMAs per
+                 product): algorithmic fp32 FLOP (2*M*N*K per launch) / HIP-event time of those launches,
+                 against the dense fp16 matrix peak / 3 (and, for reference, the 157.3 TFLOP/s fp32 peak);
   cpu_baseline — the CPU oracle (a port of the reference's --device cpu path) timed on this box's
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -38,7 +38,8 @@ from knn_svc_amd.wavlm import WavLMEncoder                                    # 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
-BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # six bf16 MFMAs per fp32-accurate product
+BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # six bf16 MFMAs per fp32-accurate product (KNNSVC_GEMM=bf16x3)
+F16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0    # three fp16 MFMAs per fp32-accurate product (default; fp16 rate = bf16 rate)
 SRC_SECONDS = 30
 POOL_CLIPS = 20                        # x 30 s = 10 minutes per rank
 
@@ -51,7 +52,7 @@ class GemmTimer:
         self.records = []
         self.enabled = False
         self.all_variants = False
-        self.dominant = "H128"
+        self.dominant = {"f16x2": "F128", "bf16x3": "H128", "fp32": "G128v8"}[ops.gemm_mode()]
         self.dom_bytes = 0
         self._orig = ops.conv_gemm
 
@@ -74,7 +75,9 @@ class GemmTimer:
             fast = vec4 and kw["cin"] % 32 == 0 and t_in * ldx * 4 < 2 ** 30 and kw["n"] * K * 4 < 2 ** 30 \
                 and kw["m"] * kw.get("stride", 1) * ldx * 4 < 2 ** 30
             tile = "128" if kw["n"] > 64 else "64" if kw["n"] > 32 else "32"
-            if fast and getattr(w, "_w3", None) is not None:
+            if fast and getattr(w, "_w2", None) is not None:
+                var = "F" + tile                      # conv_gemm2_kernel: fp32 emulated with three fp16 MFMAs
+            elif fast and getattr(w, "_w3", None) is not None:
                 var = "H" + tile                      # conv_gemm3_kernel: fp32 emulated with six bf16 MFMAs
             else:
                 var = "G" + tile + ("v8" if fast else "v4" if vec4 else "v1")
@@ -290,6 +293,11 @@ def main():
         ms_step = dt / a.steps * 1e3
         value = ws * SRC_SECONDS * a.steps / dt
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        peak, mfmas, kernel_name = {
+            "F128": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2_kernel<Gemm2Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 3 fp16 MFMAs)"),
+            "H128": (BF16X3_PEAK_TFLOPS, 6, "conv_gemm3_kernel<Gemm3Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 6 bf16 MFMAs)"),
+            "G128v8": (FP32_MFMA_PEAK_TFLOPS, 1, "conv_gemm_kernel<GemmTile<128,128,2,2,2,2>, 8> (implicit GEMM on v_mfma_f32_32x32x2_f32)"),
+        }[timer.dominant]
         line = {
             "metric": "audio-sec converted/sec (xRT) end-to-end, cold target pool",
             "value": round(value, 3), "unit": "x real-time", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
@@ -300,11 +308,11 @@ def main():
                                    "weights of WavLM-Large (6 layers executed) and the 22.9 M-param generator",
                        "nq": 1500, "np_per_rank": 30000, "pool_sharding": f"rows over {ws} rank(s), RCCL all-gather merge",
                        "wavlm_batch_chunks": a.max_batch},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(BF16X3_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16X3_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_gemm3_kernel<Gemm3Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 6 bf16 MFMAs)",
-                         "note": "achieved = algorithmic fp32 FLOP (2*M*N*K per launch) / HIP-event time; peak = dense bf16 "
-                                 "MFMA peak 2500 TFLOP/s / 6 MFMAs per product; executed bf16 MFMA rate = 6 x achieved",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel": kernel_name,
+                         "note": f"achieved = algorithmic fp32 FLOP (2*M*N*K per launch) / HIP-event time; peak = dense 16-bit "
+                                 f"MFMA peak 2500 TFLOP/s / {mfmas} MFMAs per product; executed MFMA rate = {mfmas} x achieved",
                          "frac_of_fp32_mfma_peak_157.3": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "timing": "HIP events around each launch in an eager re-run of the same K steps right after the "
                                    "timed region (which replays hipGraphs)",

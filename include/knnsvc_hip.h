@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 2
+#define KNNSVC_ABI_VERSION 3
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -65,6 +65,9 @@ typedef struct knnsvc_conv_desc {
     int32_t batches; int32_t groups;
     int32_t convt_u; int32_t convt_cout; int32_t convt_pad; int32_t t_out;
     const void* w_bf16x3;              /* optional: w pre-split by knnsvc_split_weight_bf16x3 (NULL = fp32 MFMA) */
+    const void* w_f16x2;               /* optional: w pre-split by knnsvc_split_weight_f16x2; wins over w_bf16x3 */
+    float w_f16x2_scale;               /* the power-of-two scale w_f16x2 was split with                         */
+    float a_f16x2_scale;               /* power-of-two activation pre-scale of the f16x2 path; 0 = default 16    */
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
@@ -74,6 +77,15 @@ int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
  * product as six bf16 MFMAs (a0b0+a0b1+a1b0+a0b2+a2b0+a1b1, fp32 accumulate): fp32-level accuracy at
  * 6/16 of the fp32-MFMA cost.  Activations are split on the fly inside the kernel. */
 int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* out, void* stream);
+
+/* Split scale*w (scale = a power of two that puts max|w| in [2^13, 2^14)) into two round-to-nearest fp16
+ * planes, layout [rows][K/32][2][32] (4 bytes per weight).  With w_f16x2 set and cin % 32 == 0,
+ * knnsvc_conv_gemm evaluates every fp32 product as three fp16 MFMAs (lo*hi + hi*lo + hi*hi, fp32
+ * accumulate; activations are scaled by 16 and split on the fly, the epilogue undoes both scales exactly):
+ * fp32-GEMM accuracy at 3/16 of the fp32-MFMA cost.  a_f16x2_scale * |activation| must stay below 65504
+ * (default scale 16: |x| < 4094) or the output turns NaN (never silently wrong); activations whose rms is
+ * below ~0.2 / a_f16x2_scale lose relative accuracy (absolute floor 3e-8 / a_f16x2_scale per element). */
+int knnsvc_split_weight_f16x2(const float* w, int64_t rows, int32_t K, float scale, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise layer norm over the last dim (eps 1e-5, affine), optional exact-erf GELU after it.

@@ -10,6 +10,7 @@
 // trip for P.  The bias is gate[query] * table[key - query + T - 1], read from a per-head LDS
 // copy of the (2T-1)-entry table; nothing T x T ever reaches HBM.
 #include "common.h"
+#include "gemm2_core.h"
 #include <stdlib.h>
 
 namespace {
@@ -373,6 +374,193 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f16x2 variant (default): the schedule of attention3_kernel with every fp32 product evaluated as
+// three v_mfma_f32_32x32x16_f16 on (hi, lo) fp16 splits of power-of-two-scaled operands
+// (gemm2_core.h): half the matrix-core work of bf16x3 at the same accuracy class.
+//   K tile : LDS [64 keys][2 planes][64 d] fp16, row pitch 272 B;  V tile : LDS [64 d][2 planes][64 keys], pitch 264 B
+//   scales : Q' = 16 (log2 e / 8) Q, K' = 16 K  (scores x 256, undone inside the exp2 argument);
+//            P' = 2^14 P (folded into the exp2 argument, cancels in O / l);  V' = 16 V (undone at the end)
+// ---------------------------------------------------------------------------------------------
+constexpr int KP2 = 272;
+constexpr int VP2 = 264;
+
+__global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
+                                                           const float* __restrict__ table, int T, int heads,
+                                                           float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) char lc;
+    typedef __attribute__((address_space(3))) au32x4 l_u4;
+    typedef __attribute__((address_space(3))) au32x2 l_u2;
+    typedef __attribute__((address_space(3))) unsigned short l_u16;
+    typedef __attribute__((address_space(3))) float l_f;
+    lc* Ks = (lc*)lds;                       // 64 keys * 272 B
+    lc* Vs = Ks + KT * KP2;                  // 64 d * 264 B
+    l_f* tb = (l_f*)(Vs + HD * VP2);         // [2T-1+64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int E = heads * HD;
+    const long ld = 3L * E;
+    const float* base = qkv + (long)b * T * ld;
+    const int qi = blockIdx.x * 128 + wave * 32 + li;
+    const bool qvalid = qi < T;
+
+    // bias table + 64 zero floats: the last key tile indexes past 2T-2 before it is masked
+    for (int i = tid; i < 2 * T - 1 + 64; i += 256) tb[i] = i < 2 * T - 1 ? table[(long)head * (2 * T - 1) + i] : 0.f;
+
+    // scores live in the log2 domain (softmax via v_exp_f32) and carry the operand scales: Q' = 16 log2(e)/8 Q,
+    // K' = 16 K  ->  accumulator = 256 * log2-score; the bias enters as 256 log2(e) g b, exp2 undoes the 256.
+    const float L2E = 1.44269504088896341f;
+    const float qscale = 0.125f * L2E * 16.0f;
+    // Q (scaled) split into two fp16 planes: qf[s][p] = 8 halves of d = 16 s + 8 h + 0..7
+    au32x4 qf[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (qvalid) {
+            const float* p = base + (long)qi * ld + head * HD + s * 16 + lh * 8;
+            v0 = *(const f32x4*)p; v1 = *(const f32x4*)(p + 4);
+        }
+        g2_u32x2 h0, l0, h1, l1;
+        f16x2_split4(v0, qscale, h0, l0); f16x2_split4(v1, qscale, h1, l1);
+        qf[s][0] = (au32x4){h0[0], h0[1], h1[0], h1[1]};
+        qf[s][1] = (au32x4){l0[0], l0[1], l1[0], l1[1]};
+    }
+    const float g_i = qvalid ? gate[((long)b * T + qi) * heads + head] * (L2E * 256.0f) : 0.f;
+    const l_f* tbq = tb + (T - 1 - (qvalid ? qi : T - 1)) + 4 * lh;     // tbq[key] = table[key - qi + T - 1]
+
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    const int srow = tid >> 4, scol = (tid & 15) * 4;       // staging: rows (keys) srow + 16 j, d = scol..scol+3
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = k0 + srow + 16 * j;
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < T) {
+                const float* p = base + (long)key * ld + head * HD + scol;
+                kk = *(const f32x4*)(p + E);
+                vv = *(const f32x4*)(p + 2 * E);
+            }
+            rk[j] = kk; rv[j] = vv;
+        }
+    };
+    gload(0);
+    const int ntiles = (T + KT - 1) / KT;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = srow + 16 * j;
+            g2_u32x2 hi, lo;
+            f16x2_split4(rk[j], 16.0f, hi, lo);
+            lc* kd = Ks + key * KP2 + scol * 2;
+            *(l_u2*)(kd) = hi;
+            *(l_u2*)(kd + 128) = lo;
+            f16x2_split4(rv[j], 16.0f, hi, lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lc* vd = Vs + (scol + e) * VP2 + key * 2;              // transposed: row = d, column = key
+                *(l_u16*)(vd) = (unsigned short)(hi[e >> 1] >> (16 * (e & 1)));
+                *(l_u16*)(vd + 128) = (unsigned short)(lo[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) gload((t + 1) * KT);
+
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kbase = t * KT + sub * 32;
+            if (kbase >= T) break;
+            // ---- S^T = K . Q^T : 4 d-steps x 6 products -----------------------------------------------
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const lc* kp = Ks + (sub * 32 + li) * KP2 + lh * 16;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const f16x8 k0 = __builtin_bit_cast(f16x8, *(const l_u4*)(kp + st * 32));
+                const f16x8 k1 = __builtin_bit_cast(f16x8, *(const l_u4*)(kp + 128 + st * 32));
+                const f16x8 q0 = __builtin_bit_cast(f16x8, qf[st][0]), q1 = __builtin_bit_cast(f16x8, qf[st][1]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q1, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q0, s, 0, 0, 0);
+            }
+            // rows past T hold zero Q (and zero gate): their scores are finite, nothing is written for them
+            const l_f* tp = tbq + kbase;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(g_i, tp[(r & 3) + 8 * (r >> 2)], s[r]);
+            if (kbase + 32 > T) {                                    // wave-uniform: only the last key tile masks
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= T) s[r] = -__builtin_inff();
+            }
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+            for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);                    // key 0 is always valid: finite from the first tile on
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * (1.0f / 256.0f));
+            const float mneg = fmaf(m_new, -1.0f / 256.0f, 14.0f);       // P carries 2^14 (cancels in O / l)
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], 1.0f / 256.0f, mneg)); ps += s[r]; }
+            ps += __shfl_xor(ps, 32, 64);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            // ---- O^T += V^T . P^T : 2 key-steps x 2 d-tiles x 6 products ---------------------------------------
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                g2_u32x2 h0, l0, h1, l1;
+                f16x2_split4((f32x4){s[8 * st + 0], s[8 * st + 1], s[8 * st + 2], s[8 * st + 3]}, 1.0f, h0, l0);
+                f16x2_split4((f32x4){s[8 * st + 4], s[8 * st + 5], s[8 * st + 6], s[8 * st + 7]}, 1.0f, h1, l1);
+                const f16x8 b0 = __builtin_bit_cast(f16x8, (au32x4){h0[0], h0[1], h1[0], h1[1]});
+                const f16x8 b1 = __builtin_bit_cast(f16x8, (au32x4){l0[0], l0[1], l1[0], l1[1]});
+                // element e of this lane's fragment is key sub*32 + 16 st + 8 (e>>2) + 4 h + (e&3): two runs of four keys
+                const int kcol = (sub * 32 + 16 * st + 4 * lh) * 2;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const lc* vp = Vs + (dt * 32 + li) * VP2 + kcol;
+                    const au32x2 x0 = *(const l_u2*)(vp), x1 = *(const l_u2*)(vp + 16);
+                    const au32x2 y0 = *(const l_u2*)(vp + 128), y1 = *(const l_u2*)(vp + 128 + 16);
+                    const f16x8 v0 = __builtin_bit_cast(f16x8, (au32x4){x0[0], x0[1], x1[0], x1[1]});
+                    const f16x8 v1 = __builtin_bit_cast(f16x8, (au32x4){y0[0], y0[1], y1[0], y1[1]});
+                    f32x16 c = o[dt];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b0, c, 0, 0, 0);
+                    o[dt] = c;
+                }
+            }
+        }
+    }
+    if (qvalid) {
+        const float inv = 0.0625f / l_run;          // V carried a factor 16
+        float* op = out + ((long)b * T + qi) * E + head * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {o[d][r4 * 4 + 0] * inv, o[d][r4 * 4 + 1] * inv, o[d][r4 * 4 + 2] * inv, o[d][r4 * 4 + 3] * inv};
+                *(f32x4*)(op + d * 32 + r4 * 8 + lh * 4) = v;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
@@ -380,9 +568,25 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
     KN_REQUIRE(qkv && gate && table && out, "wavlm_attention: null pointer");
     KN_REQUIRE(batches > 0 && T > 0 && heads > 0 && heads <= 65535 && batches <= 65535, "wavlm_attention: bad sizes");
     KN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "wavlm_attention: 16-byte alignment");
-    static int use3 = -1;
-    if (use3 < 0) { const char* e = getenv("KNNSVC_ATTENTION"); use3 = (e && e[0] == 'f') ? 0 : 1; }   // "fp32" = exact-f32 MFMA kernel
-    if (use3) {
+    static int mode = -1;          // KNNSVC_ATTENTION = f16x2 (default) | bf16x3 | fp32 (exact-f32 MFMA kernel)
+    if (mode < 0) {
+        const char* e = getenv("KNNSVC_ATTENTION");
+        mode = !e ? 2 : (e[0] == 'b') ? 3 : (e[0] == 'f' && e[1] == 'p') ? 0 : 2;
+    }
+    if (mode == 2) {
+        const size_t l2 = (size_t)KT * KP2 + (size_t)HD * VP2 + (size_t)(2 * T - 1 + 64) * 4;
+        KN_REQUIRE(l2 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~16000)");
+        static size_t attr2 = 0;
+        if (l2 > attr2) {
+            if (hipFuncSetAttribute((const void*)attention2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)
+                return knnsvc_fail(KNNSVC_EHIP, "wavlm_attention: hipFuncSetAttribute failed");
+            attr2 = l2;
+        }
+        dim3 grid2((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batches);
+        hipLaunchKernelGGL(attention2_kernel, grid2, dim3(256), l2, (hipStream_t)stream, qkv, gate, table, T, heads, out);
+        return knnsvc_check_launch("wavlm_attention2");
+    }
+    if (mode == 3) {
         const size_t l3 = (size_t)KT * KP3 + (size_t)HD * VP3 + (size_t)(2 * T - 1 + 64) * 4;
         KN_REQUIRE(l3 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~13000)");
         static size_t attr3 = 0;

@@ -3,6 +3,7 @@
 // reference call sites it replaces.
 #include "gemm_core.h"
 #include "gemm3_core.h"
+#include "gemm2_core.h"
 
 namespace {
 
@@ -18,6 +19,9 @@ struct ConvArgs {
     int convt_u, convt_cout, convt_pad, t_out;
     int K;
     const unsigned short* w3;   // weights pre-split into 3 bf16 planes ([n][K/32][3][32]) or null
+    const unsigned short* w2;   // weights pre-split into 2 fp16 planes ([n][K/32][2][32], scaled) or null
+    float out_scale;            // accumulator -> output factor (1 except on the f16x2 path)
+    float a_scale;              // f16x2 path: power-of-two factor applied to activations before the split
 };
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
@@ -188,6 +192,29 @@ struct Split3BLoader {
     }
 };
 
+// split weights [n][K/32][2][32] fp16: thread piece q = tid + 256 j -> row q / 8, 16-byte piece q % 8
+template <int NP, int NPIECES>
+struct Split2BLoader {
+    int off[NP]; int uoff;
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t desc(const unsigned short* w2, int N, int K) {
+        return uniform_rsrc(w2, (int)((long)N * (K / 32) * 128));
+    }
+    __device__ __forceinline__ Split2BLoader(int N, int K, int n0, int tid) {
+        const int row_bytes = (K / 32) * 128;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int q = tid + 256 * j;
+            const int n = n0 + (q >> 3);
+            off[j] = (q < NPIECES && n < N) ? n * row_bytes + (q & 7) * 16 : OOB;
+        }
+        uoff = 0;
+    }
+    __device__ __forceinline__ void begin(int kt) { uoff = kt * 128; }
+    __device__ __forceinline__ g2_u32x4 operator()(int, int j, __amdgpu_buffer_rsrc_t rsrc) const {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j] + uoff, 0, 0);
+    }
+};
+
 template <class G>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G::TM][G::TN], int m0, int n0, int b, int g) {
     // ---- epilogue -------------------------------------------------------------------------
@@ -213,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G
                     orow = (long)m * a.convt_u + phase - a.convt_pad;
                     if (orow < 0 || orow >= a.t_out) continue;
                 }
-                float v = acc[i][j][r] + bv;
+                float v = fmaf(acc[i][j][r], a.out_scale, bv);      // out_scale is a power of two: exact
                 if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
                 else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
@@ -279,6 +306,55 @@ __global__ __launch_bounds__(256, 3) void conv_gemm3_kernel(ConvArgs a) {
     conv_epilogue<G>(a, acc, m0, n0, b, g);
 }
 
+template <class G, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_gemm2_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;      // 64 halves = 128 B per (row, slab)
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    FastALoader<G::A_F4> al(a, m0, threadIdx.x);
+    Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
+    G::mainloop(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale);
+    conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G, int OCC = 3>
+int launch2(const ConvArgs& a, int batches, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm2_kernel<G, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    dim3 grid((unsigned)cdiv64(a.m, G::BM), (unsigned)cdiv64(a.n, G::BN), (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2_kernel<G, OCC>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm2");
+}
+
+// one thread per 4 consecutive k of one weight row: scale * fp32 -> (hi, lo) fp16 planes, round to nearest
+__global__ void split_weight2_kernel(const float* __restrict__ w, long n, int K, float scale, unsigned short* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long groups_per_row = K / 4;
+    if (i >= n * groups_per_row) return;
+    const long row = i / groups_per_row; const int k = (int)(i - row * groups_per_row) * 4;
+    g2_u32x2 hi, lo;
+    f16x2_split4(*(const f32x4*)(w + row * K + k), scale, hi, lo);
+    unsigned short* o = out + row * (long)(K / 32) * 64 + (k / 32) * 64 + (k % 32);
+    *(g2_u32x2*)o = hi;
+    *(g2_u32x2*)(o + 32) = lo;
+}
+
 template <class G>
 int launch3(const ConvArgs& a, int batches, hipStream_t st) {
     static bool attr = false;
@@ -326,6 +402,9 @@ using G32 = GemmTile<128, 32, 4, 1, 1, 1>;
 using H128 = Gemm3Tile<128, 128, 2, 2, 2, 2>;
 using H64 = Gemm3Tile<256, 64, 4, 1, 2, 2>;     // small-N layers: taller tiles so that a wave still issues 48 / 24
 using H32 = Gemm3Tile<256, 32, 4, 1, 2, 1>;     // MFMAs between the two barriers of a slab
+using F128 = Gemm2Tile<128, 128, 2, 2, 2, 2>;
+using F64 = Gemm2Tile<256, 64, 4, 1, 2, 2>;
+using F32 = Gemm2Tile<256, 32, 4, 1, 2, 1>;
 
 template <class G>
 int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
@@ -380,6 +459,8 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.convt_u = d->convt_u; a.convt_cout = d->convt_cout; a.convt_pad = d->convt_pad; a.t_out = d->t_out;
     a.K = d->cin * d->taps;
     a.w3 = (const unsigned short*)d->w_bf16x3;
+    a.w2 = (const unsigned short*)d->w_f16x2;
+    a.out_scale = 1.0f; a.a_scale = 1.0f;
 
     // 16-byte vector path needs every float4 of A and W to be aligned and inside one tap
     const bool vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
@@ -391,6 +472,20 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     // buffer-load fast path: every slab inside one tap, resources below 1 GiB
     const bool fast = vec4 && (d->cin % 32 == 0) && ((long)d->t_in * d->ldx * 4 < (1L << 30)) &&
                       ((long)d->n * a.K * 4 < (1L << 30)) && ((long)d->m * d->stride * d->ldx * 4 < (1L << 30));
+    if (fast && a.w2) {        // fp32 emulated on the fp16 matrix cores (gemm2_core.h)
+        KN_REQUIRE(d->w_f16x2_scale > 0.f, "conv_gemm: w_f16x2 without its scale");
+        a.a_scale = d->a_f16x2_scale > 0.f ? d->a_f16x2_scale : KN_F16X2_A_SCALE;
+        { int e2 = 0; KN_REQUIRE(frexpf(a.a_scale, &e2) == 0.5f && frexpf(d->w_f16x2_scale, &e2) == 0.5f, "conv_gemm: f16x2 scales must be powers of two"); }
+        a.out_scale = 1.0f / (a.a_scale * d->w_f16x2_scale);
+        static int tv = -1;
+        if (tv < 0) { const char* e = getenv("KNNSVC_F2TILE"); tv = e ? atoi(e) : 0; }
+        if (d->n > 64 && tv == 1) return launch2<F128, 4>(a, d->batches, st);
+        if (d->n > 64 && tv == 2) return launch2<Gemm2Tile<256, 128, 2, 2, 4, 2>, 2>(a, d->batches, st);
+        if (d->n > 64 && tv == 3) return launch2<Gemm2Tile<128, 256, 2, 2, 2, 4>, 2>(a, d->batches, st);
+        if (d->n > 64) return launch2<F128>(a, d->batches, st);
+        if (d->n > 32) return launch2<F64>(a, d->batches, st);
+        return launch2<F32>(a, d->batches, st);
+    }
     if (fast && a.w3) {        // fp32 emulated on the bf16 matrix cores (gemm3_core.h)
         if (d->n > 64) return launch3<H128>(a, d->batches, st);
         if (d->n > 32) return launch3<H64>(a, d->batches, st);
@@ -408,4 +503,15 @@ extern "C" int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t 
     hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)cdiv64(groups, 256)), dim3(256), 0, (hipStream_t)stream,
                        w, (long)rows, K, (unsigned short*)out);
     return knnsvc_check_launch("split_weight");
+}
+
+extern "C" int knnsvc_split_weight_f16x2(const float* w, int64_t rows, int32_t K, float scale, void* out, void* stream) {
+    KN_REQUIRE(w && out && rows > 0 && K > 0 && K % 32 == 0, "split_weight: K must be a positive multiple of 32");
+    KN_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0, "split_weight: 16-byte alignment");
+    int e = 0;
+    KN_REQUIRE(scale > 0.f && frexpf(scale, &e) == 0.5f, "split_weight: scale must be a power of two");
+    const long groups = rows * (K / 4);
+    hipLaunchKernelGGL(split_weight2_kernel, dim3((unsigned)cdiv64(groups, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, (long)rows, K, scale, (unsigned short*)out);
+    return knnsvc_check_launch("split_weight2");
 }

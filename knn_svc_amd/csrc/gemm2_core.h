@@ -1,0 +1,144 @@
+// fp32 GEMM emulated on the fp16 matrix cores ("f16x2"): every fp32 operand x is pre-scaled by a
+// power of two and split with round-to-nearest into two fp16 pieces  s x = hi + lo (+ <= 2^-22 |s x|),
+// and a product a*b is accumulated in fp32 from three fp16 MFMAs  lo_a hi_b + hi_a lo_b + hi_a hi_b
+// (the dropped lo_a lo_b term is below 2^-22 |a||b|).  Products of fp16 values are exact in fp32, so
+// the result stays at fp32-GEMM accuracy (simulated against fp64 at K = 1024: 7.6e-8 rms relative
+// representation error, vs 6.0e-8 for the bf16x3 split of gemm3_core.h and 3.4e-7 for an fp32 FMA
+// chain) at HALF the matrix-core work of bf16x3: 3/16 of the fp32-MFMA cycles per product.
+//
+// Range: fp16 tops out at 65504 and goes subnormal below 6.1e-5 (v_mfma_*_f16 keeps subnormal inputs —
+// tools/probe/mfma_f16_probe.hip), so both operands are moved into the middle of that range by exact
+// power-of-two factors: weights by the per-tensor factor chosen when they are split (max |w| lands in
+// [2^13, 2^14)), activations by a per-call factor (default 16: |x| < 4094 is representable and the
+// absolute error floor is 2^-25 / 16 per element, i.e. activations whose rms is below ~0.01 start to
+// lose relative accuracy — callers that know their range pass another power of two).  The epilogue
+// multiplies the accumulator by 1 / (a_scale * w_scale), again exact.  An activation beyond the range
+// becomes inf -> NaN in the output: loud, not silently wrong.
+//
+// Block = 256 threads, 4 waves (WM x WN), wave tile (32 TM) x (32 TN), K slab = 32.
+// A arrives as fp32 from HBM and is split while it is staged (3 VALU per element); B (weights) is split
+// once at load time into [n][K/32][2 planes][32] fp16.  LDS image per operand row: 2 planes x 64 B + 16 B
+// pad = 144 B (36 dwords: the 16 rows of a ds_read_b128 lane group land on 16 distinct 4-bank slots).
+#pragma once
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned g2_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned g2_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float KN_F16X2_A_SCALE = 16.0f;
+
+// 4 fp32 -> (hi, lo) planes of 4 fp16 each, as two dwords per plane
+__device__ __forceinline__ void f16x2_split4(f32x4 v, float scale, g2_u32x2& hi, g2_u32x2& lo) {
+    f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+    a *= scale; b *= scale;
+    const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
+    const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
+    const f16x2_t la = __builtin_convertvector(ra, f16x2_t), lb = __builtin_convertvector(rb, f16x2_t);
+    hi = (g2_u32x2){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    lo = (g2_u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+
+template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
+struct Gemm2Tile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int BK = 32, PITCH = 144, THREADS = 256;
+    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    static constexpr int A_F4 = BM / 32;                       // fp32 float4 per thread per slab
+    static constexpr int B_PIECES = BN * 8;                    // 16-byte pieces of split weights per slab
+    static constexpr int B_P = (B_PIECES + 255) / 256;         // per thread
+    static constexpr int LDS_BYTES = (BM + BN) * PITCH;
+
+    typedef __attribute__((address_space(3))) char lds_c;
+
+    __device__ __forceinline__ static void split_store(lds_c* dst, f32x4 v, float a_scale) {
+        g2_u32x2 hi, lo;
+        f16x2_split4(v, a_scale, hi, lo);
+        typedef __attribute__((address_space(3))) g2_u32x2 lds_u2;
+        *(lds_u2*)(dst) = hi;
+        *(lds_u2*)(dst + 64) = lo;
+    }
+
+    // aload: fp32 A loader (begin(kt), operator()(kt, j) -> f32x4 for row (tid>>3)+32j, k = (tid&7)*4, finish())
+    // bload: split-weight loader (begin(kt), operator()(kt, j) -> 16-byte piece j of this thread)
+    template <class ALoad, class BLoad, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, BLoad& bload,
+                                                    f32x16 (&acc)[TM][TN], RA ra_desc, RB rb_desc, float a_scale) {
+        lds_c* lds = (lds_c*)lds_generic;
+        typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int a_st = (tid >> 3) * PITCH + (tid & 7) * 8;               // staging address of float4 j = 0
+        const int li = lane & 31, lh = lane >> 5;
+        const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
+        const int b_frag = BM * PITCH + (wn * TN * 32 + li) * PITCH + lh * 16;
+
+        f32x4 ra[A_F4];
+        g2_u32x4 rb[B_P];
+#define KN_STAGE2()                                                                                           \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < A_F4; ++j)                                                     \
+            split_store(lds + a_st + 32 * j * PITCH, aload.finish(ra[j]), a_scale);                                   \
+        _Pragma("unroll") for (int j = 0; j < B_P; ++j) {                                                    \
+            const int q = tid + 256 * j;                                                                     \
+            if (B_PIECES % 256 == 0 || q < B_PIECES)                                                         \
+                *(lds_u4*)(lds + BM * PITCH + (q >> 3) * PITCH + (q & 7) * 16) = rb[j];                       \
+        }                                                                                                    \
+    }
+        aload.begin(0); bload.begin(0);
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) ra[j] = aload(0, j, ra_desc);
+#pragma unroll
+        for (int j = 0; j < B_P; ++j) rb[j] = bload(0, j, rb_desc);
+        KN_STAGE2();
+        __syncthreads();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1 < nk);
+            if (more) {
+                aload.begin(kt + 1); bload.begin(kt + 1);
+#pragma unroll
+                for (int j = 0; j < A_F4; ++j) ra[j] = aload(kt + 1, j, ra_desc);
+#pragma unroll
+                for (int j = 0; j < B_P; ++j) rb[j] = bload(kt + 1, j, rb_desc);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 fa[TM][2], fb[TN][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        fa[i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + a_frag + i * 32 * PITCH + p * 64 + ks * 32));
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        fb[i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + b_frag + i * 32 * PITCH + p * 64 + ks * 32));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], c, 0, 0, 0);   // small terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+            __syncthreads();                 // every wave is done reading this slab
+            if (more) KN_STAGE2();
+            __syncthreads();
+        }
+    }
+
+#undef KN_STAGE2
+    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
+        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
+        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
+    }
+};

@@ -8,6 +8,7 @@ fallback — a missing library or a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 
@@ -55,20 +56,41 @@ def pack_convT_weight(w: torch.Tensor, u: int) -> torch.Tensor:
     return w.reshape(cin, cout, r, u).permute(3, 1, 2, 0).reshape(u * cout, r * cin).contiguous()
 
 
-def attach_split(w: torch.Tensor) -> torch.Tensor:
-    """Pre-split a packed weight matrix [..., K] (K % 32 == 0) into three bf16 planes and hang the result on
-    the tensor (``w._w3``).  conv_gemm then runs the bf16x3 kernel for it (fp32-level accuracy, ~2.7x the
-    fp32-MFMA rate).  No-op when the shape does not qualify or KNNSVC_GEMM=fp32 is set."""
+def gemm_mode() -> str:
+    """KNNSVC_GEMM = f16x2 (default) | bf16x3 | fp32: how conv_gemm evaluates fp32 products for weights that
+    went through attach_split (all three keep fp32-GEMM accuracy; see gemm2_core.h / gemm3_core.h)."""
     import os
-    if os.environ.get("KNNSVC_GEMM", "") == "fp32" or not w.is_cuda or w.dtype != torch.float32:
+    mode = os.environ.get("KNNSVC_GEMM", "f16x2")
+    if mode not in ("f16x2", "bf16x3", "fp32"):
+        raise KnnSvcError(f"KNNSVC_GEMM={mode!r}: expected f16x2, bf16x3 or fp32")
+    return mode
+
+
+def attach_split(w: torch.Tensor) -> torch.Tensor:
+    """Pre-split a packed weight matrix [..., K] (K % 32 == 0) for the emulated-fp32 matrix-core kernels and
+    hang the result on the tensor: ``w._w2`` (+ ``w._w2_scale``) = two fp16 planes of scale*w with the
+    per-tensor power-of-two scale that puts max|w| in [2^13, 2^14) (default), or ``w._w3`` = three bf16
+    planes (KNNSVC_GEMM=bf16x3).  No-op when the shape does not qualify or KNNSVC_GEMM=fp32 is set."""
+    mode = gemm_mode()
+    if mode == "fp32" or not w.is_cuda or w.dtype != torch.float32:
         return w
     K = w.shape[-1]
     if K % 32 != 0 or not w.is_contiguous():
         return w
     rows = w.numel() // K
-    out = torch.empty(rows * (K // 32) * 96, device=w.device, dtype=torch.int16)
-    check(_lib.load().knnsvc_split_weight_bf16x3(_p(w), rows, K, _p(out), _stream()), "split_weight")
-    w._w3 = out
+    if mode == "bf16x3":
+        out = torch.empty(rows * (K // 32) * 96, device=w.device, dtype=torch.int16)
+        check(_lib.load().knnsvc_split_weight_bf16x3(_p(w), rows, K, _p(out), _stream()), "split_weight")
+        w._w3 = out
+        return w
+    wmax = float(w.abs().max())
+    if not math.isfinite(wmax):
+        raise KnnSvcError("attach_split: non-finite weight")
+    scale = 2.0 ** (13 - math.frexp(wmax)[1] + 1) if wmax > 0 else 1.0       # max|w| * scale in [2^13, 2^14)
+    scale = min(max(scale, 2.0 ** -60), 2.0 ** 60)
+    out = torch.empty(rows * (K // 32) * 64, device=w.device, dtype=torch.int16)
+    check(_lib.load().knnsvc_split_weight_f16x2(_p(w), rows, K, scale, _p(out), _stream()), "split_weight")
+    w._w2, w._w2_scale = out, scale
     return w
 
 
@@ -77,7 +99,7 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               bias=None, bias_period=0, act=ACT_NONE, act_slope=0.0, a_slope=1.0, resid=None, ldr=None,
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
-              convt_u=0, convt_cout=0, convt_pad=0, t_out=0):
+              convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0):
     """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr)."""
     lib = _lib.load()
     d = ConvDesc()
@@ -97,6 +119,10 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.convt_u = convt_u; d.convt_cout = convt_cout; d.convt_pad = convt_pad; d.t_out = t_out
     w3 = getattr(w, "_w3", None)
     d.w_bf16x3 = w3.data_ptr() if w3 is not None else None
+    w2 = getattr(w, "_w2", None)
+    d.w_f16x2 = w2.data_ptr() if w2 is not None else None
+    d.w_f16x2_scale = w._w2_scale if w2 is not None else 0.0
+    d.a_f16x2_scale = a_scale
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
     return out
 

@@ -37,21 +37,50 @@ def test_linear(M, K, N):
     assert _err(out, ref)[0] < 2e-5
 
 
+@pytest.mark.parametrize("mode,attr", [("f16x2", "_w2"), ("bf16x3", "_w3")])
 @pytest.mark.parametrize("M,K,N", [(300, 1024, 1024), (1500, 4096, 1024), (129, 64, 130), (500, 96, 40), (77, 32, 20)])
-def test_linear_bf16x3(M, K, N):
-    """fp32 emulated with six bf16 MFMAs per product: must be as accurate as the fp32 path (vs fp64)."""
+def test_linear_emulated_fp32(M, K, N, mode, attr, monkeypatch):
+    """fp32 emulated on the fp16 (3 MFMAs / product) or bf16 (6) matrix cores: must be as accurate as the
+    fp32-MFMA path (vs fp64)."""
     ops = _ops()
+    monkeypatch.setenv("KNNSVC_GEMM", mode)
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g) * 3; w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
     ref = x.double() @ w.double().T + b.double()
     wd = w.to(DEV)
     o32 = ops.linear(x.to(DEV), wd, b.to(DEV))
     ops.attach_split(wd)
-    assert hasattr(wd, "_w3")
+    assert hasattr(wd, attr)
     o3 = ops.linear(x.to(DEV), wd, b.to(DEV))
     e32, e3 = float((o32.cpu().double() - ref).abs().max()), float((o3.cpu().double() - ref).abs().max())
-    print(f"fp32 MFMA err {e32:.2e}, bf16x3 err {e3:.2e}")
+    print(f"fp32 MFMA err {e32:.2e}, {mode} err {e3:.2e}")
     assert e3 <= 2.0 * e32 + 1e-6 and e3 < 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("xs,ws,a_scale", [(1e-3, 1e-4, 4096.0), (30.0, 5.0, 0.0), (0.05, 40.0, 0.0)])
+def test_linear_f16x2_scales(xs, ws, a_scale, monkeypatch):
+    """The power-of-two operand scaling keeps small activations / odd weight magnitudes at fp32 accuracy,
+    and an activation beyond the fp16 range turns the output NaN instead of silently wrong."""
+    ops = _ops()
+    monkeypatch.setenv("KNNSVC_GEMM", "f16x2")
+    g = torch.Generator().manual_seed(7)
+    M, K, N = 200, 512, 96
+    x = torch.randn(M, K, generator=g) * xs; w = torch.randn(N, K, generator=g) * ws
+    ref = x.double() @ w.double().T
+    wd = ops.attach_split(w.to(DEV))
+    assert 2 ** 13 <= float(w.abs().max()) * wd._w2_scale < 2 ** 14
+    o = torch.empty(M, N, device=DEV)
+    ops.conv_gemm(x.to(DEV), wd, o, m=M, n=N, cin=K, a_scale=a_scale)
+    err = float((o.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"x scale {xs}, w scale {ws}: rms rel err {err:.2e}")
+    assert err < 4e-7
+    if a_scale:          # the default activation scale (16) is past its accuracy floor at rms 1e-3: degraded, not wrong
+        ops.conv_gemm(x.to(DEV), wd, o, m=M, n=N, cin=K)
+        err = float((o.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert err < 3e-6
+    x[3, 5] = 70000.0 / (a_scale or 16.0)
+    ops.conv_gemm(x.to(DEV), wd, o, m=M, n=N, cin=K, a_scale=a_scale)
+    assert not bool(torch.isfinite(o[3]).all()) and bool(torch.isfinite(o[4]).all())
 
 
 @pytest.mark.parametrize("cin,cout,k,s,d,T", [(1, 64, 10, 5, 1, 1000), (64, 64, 3, 2, 1, 199), (32, 32, 11, 1, 5, 700),

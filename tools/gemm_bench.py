@@ -9,7 +9,7 @@ x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K *
 out = torch.empty(M, N, device="cuda")
 if os.environ.get("SPLIT", "1") == "1":
     ops.attach_split(w)
-    print("bf16x3 path", hasattr(w, "_w3"))
+    print("split:", "f16x2" if hasattr(w, "_w2") else "bf16x3" if hasattr(w, "_w3") else "none")
 for _ in range(3):
     ops.linear(x, w, b, out=out)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
