@@ -23,6 +23,10 @@ import os
 import sys
 import time
 
+# One hardware queue per HIP stream: the runtime's default of 4 makes the encoder's stream share a queue with one of
+# the match streams, which serialises conversion i+1's encoder behind conversion i's single-workgroup recurrences.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -123,11 +127,15 @@ class stage:
             STAGES.setdefault(self.name, []).append((self.e0, e1))
 
 
-def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
+_FRONT_SIDE = {}
+
+
+def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
+    """Encoder (+ STFT / harmonic amplitudes on a second stream) -> sharded kNN -> all-gathers."""
     # The encoder is enqueued first (its first kernels are long, so the host runs ahead); STFT / harmonic
     # amplitudes only need the raw audio and run on a second stream next to it.
     main = torch.cuda.current_stream()
-    side = _side_stream(src.device)
+    side = _FRONT_SIDE.setdefault(src.device, torch.cuda.Stream(device=src.device))
     side.wait_stream(main)
     with stage("wavlm"):
         feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
@@ -151,11 +159,49 @@ def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
         P = kdist.all_gather_rows(P_loc)
         Pf0 = kdist.all_gather_rows(Pf0_loc)
         Ph = kdist.all_gather_rows(Ph_loc)
+    return dict(qf=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, nn32=nn32)
+
+
+def step_back(voc, f):
+    """f0 shift / re-rank / concat re-selection / Adam weights / gathers -> additive synth + generator."""
     with stage("match"):
-        of, hw, s0, dbg = match_features(qf, qf0, P, Pf0, Ph, "mix", "post_opt_0.2", nn32=nn32, return_debug=True)
+        of, hw, s0, dbg = match_features(f["qf"], f["qf0"], f["P"], f["Pf0"], f["Ph"], "mix", "post_opt_0.2", nn32=f["nn32"],
+                                         return_debug=True)
     with stage("vocoder"):
         y = voc.forward(of, s0, hw)
-    step.last = dict(dbg, q=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, of=of, hw=hw, s0=s0)
+    step.last = dict(dbg, q=f["qf"], qf0=f["qf0"], P=f["P"], Pf0=f["Pf0"], Ph=f["Ph"], of=of, hw=hw, s0=s0)
+    return y
+
+
+def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
+    return step_back(voc, step_front(enc, src, sf0, pool_w, pool_f0, max_batch))
+
+
+def run_steps(n, depth, enc, voc, src, sf0, pool_w, pool_f0, max_batch, streams):
+    """n conversions.  depth 1: one after the other on the current stream.  depth 2: the back half of
+    conversion i (match: single-workgroup recurrences on 2-4 CUs; vocoder) is enqueued on a second stream
+    and runs while the front half of conversion i+1 (the encoder) fills the rest of the chip — the way
+    bulk_match streams a list of sources.  Every conversion still does all of its work (cold pool)."""
+    if depth <= 1:
+        y = None
+        for _ in range(n):
+            y = step(enc, voc, src, sf0, pool_w, pool_f0, max_batch)
+        return y
+    front_s, back_s = streams
+    cur = torch.cuda.current_stream()
+    front_s.wait_stream(cur); back_s.wait_stream(cur)
+    y = None
+    for _ in range(n):
+        with torch.cuda.stream(front_s):
+            f = step_front(enc, src, sf0, pool_w, pool_f0, max_batch)
+            ev = front_s.record_event()
+        with torch.cuda.stream(back_s):
+            back_s.wait_event(ev)
+            for t in f.values():
+                t.record_stream(back_s)
+            y = step_back(voc, f)
+    cur.wait_stream(front_s); cur.wait_stream(back_s)
+    y.record_stream(cur)
     return y
 
 
@@ -225,6 +271,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=32, help="30 s chunks per WavLM batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print per-stage ms to stderr")
+    ap.add_argument("--pipeline-depth", type=int, default=2, choices=(1, 2),
+                    help="2 = overlap match+vocoder of conversion i with the encoder of conversion i+1 (default); 1 = sequential")
     a = ap.parse_args()
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,15 +299,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if a.pipeline_depth > 1 else None
+    args = (enc, voc, src, sf0, pool_w, pool_f0, a.max_batch, streams)
     with torch.inference_mode():
-        for _ in range(a.warmup):
-            y = step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
+        step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)              # one-time setup outside W: hipGraph capture, split weights
+        if a.warmup:
+            run_steps(a.warmup, a.pipeline_depth, *args)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            y = step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
+        y = run_steps(a.steps, a.pipeline_depth, *args)
         barrier()
         dt = time.perf_counter() - t0
+        # latency of ONE conversion with nothing overlapped (reported next to the throughput figure)
+        t1 = time.perf_counter()
+        run_steps(a.steps, 1, *args)
+        barrier()
+        dt_seq = time.perf_counter() - t1
         # Roofline pass: the timed region replays hipGraphs (encoder, vocoder), and HIP events cannot be
         # recorded around individual launches inside a replayed graph.  The same K steps are therefore run
         # once more eagerly with an event pair around every launch of the dominant kernel, on its own stream.
@@ -307,7 +362,11 @@ def main():
                                    "ckpt_type=mix, post_opt_0.2, cold (pool encoded inside the step); seeded random "
                                    "weights of WavLM-Large (6 layers executed) and the 22.9 M-param generator",
                        "nq": 1500, "np_per_rank": 30000, "pool_sharding": f"rows over {ws} rank(s), RCCL all-gather merge",
-                       "wavlm_batch_chunks": a.max_batch},
+                       "wavlm_batch_chunks": a.max_batch,
+                       "pipeline_depth": a.pipeline_depth,
+                       "pipeline": ("match + vocoder of conversion i run on a second stream under the encoder of conversion i+1"
+                                    if a.pipeline_depth > 1 else "none: conversions run one after the other"),
+                       "sequential_ms_per_step": round(dt_seq / a.steps * 1e3, 3)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
                          "kernel": kernel_name,

@@ -118,7 +118,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }      // pushes an offset out of every resource used here (< 1 GiB each)
 
-template <int NF4>
+template <int NF4, int RS = 32>
 struct FastALoader {
     int off[NF4]; int cin, step_tap; float slope;
     int c0, uoff;                     // uniform: channel offset inside the tap, byte offset of (tap, c0)
@@ -128,7 +128,7 @@ struct FastALoader {
     __device__ __forceinline__ FastALoader(const ConvArgs& a, int m0, int tid) : cin(a.cin), slope(a.a_slope) {
 #pragma unroll
         for (int j = 0; j < NF4; ++j) {
-            const int m = m0 + (tid >> 3) + 32 * j;
+            const int m = m0 + (tid >> 3) + RS * j;
             off[j] = (m < a.m) ? ((m * a.stride - a.pad) * a.ldx + (tid & 7) * 4) * 4 : OOB;
         }
         step_tap = (a.dil * a.ldx - a.cin) * 4;       // byte step from the end of one tap to the start of the next
@@ -193,7 +193,7 @@ struct Split3BLoader {
 };
 
 // split weights [n][K/32][2][32] fp16: thread piece q = tid + 256 j -> row q / 8, 16-byte piece q % 8
-template <int NP, int NPIECES>
+template <int NP, int NPIECES, int NT = 256>
 struct Split2BLoader {
     int off[NP]; int uoff;
     __device__ __forceinline__ static __amdgpu_buffer_rsrc_t desc(const unsigned short* w2, int N, int K) {
@@ -203,7 +203,7 @@ struct Split2BLoader {
         const int row_bytes = (K / 32) * 128;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int q = tid + 256 * j;
+            const int q = tid + NT * j;
             const int n = n0 + (q >> 3);
             off[j] = (q < NPIECES && n < N) ? n * row_bytes + (q & 7) * 16 : OOB;
         }
@@ -326,6 +326,44 @@ __global__ __launch_bounds__(256, OCC) void conv_gemm2_kernel(ConvArgs a) {
     Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
     G::mainloop(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale);
     conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G>
+__global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    typedef FastALoader<G::A_F4, G::RS> AL;
+    typedef Split2BLoader<G::B_P, G::B_PIECES, G::THREADS> BL;
+    AL al(a, m0, threadIdx.x);
+    BL bl(a.n, a.K, n0, threadIdx.x);
+    G::mainloop(lds, a.K / 32, al, bl, acc, AL::desc(a, xz), BL::desc(wz, a.n, a.K), a.a_scale);
+    conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G>
+int launch2big(const ConvArgs& a, int batches, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm2big_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    dim3 grid((unsigned)cdiv64(a.m, G::BM), (unsigned)cdiv64(a.n, G::BN), (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2big_kernel<G>), grid, dim3(G::THREADS), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm2big");
 }
 
 template <class G, int OCC = 3>
@@ -479,6 +517,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         a.out_scale = 1.0f / (a.a_scale * d->w_f16x2_scale);
         static int tv = -1;
         if (tv < 0) { const char* e = getenv("KNNSVC_F2TILE"); tv = e ? atoi(e) : 0; }
+        if (d->n > 64 && tv == 4) return launch2big<Gemm2Big<256, 256, 2, 4, 4, 2>>(a, d->batches, st);
         if (d->n > 64 && tv == 1) return launch2<F128, 4>(a, d->batches, st);
         if (d->n > 64 && tv == 2) return launch2<Gemm2Tile<256, 128, 2, 2, 4, 2>, 2>(a, d->batches, st);
         if (d->n > 64 && tv == 3) return launch2<Gemm2Tile<128, 256, 2, 2, 2, 4>, 2>(a, d->batches, st);

@@ -142,3 +142,127 @@ struct Gemm2Tile {
         return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
     }
 };
+
+// -------------------------------------------------------------------------------------------------
+// Large-tile variant: WM x WN waves (NT = 64 WM WN threads, one block per CU), double-buffered LDS,
+// ONE barrier per K slab.  At 128x128 the LDS port (reads 256 B/clk, writes ~80 B/clk per CU) and the
+// vector-memory path are each busy ~70-90 % of the MFMA time of a slab and the three interfere; a
+// 256x256 block halves both per MFMA.  Slab kt+1 is split and written into the idle buffer between
+// the two k-steps of slab kt, and the loads of slab kt+2 are issued right after, so a global load has
+// a full slab (~3000 MFMA cycles) to land.
+// -------------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
+struct Gemm2Big {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int BK = 32, PITCH = 144, THREADS = 64 * WM * WN, RS = THREADS / 8;
+    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    static_assert(BM % RS == 0 && (BN * 8) % THREADS == 0, "staging shape");
+    static constexpr int A_F4 = BM / RS;                       // fp32 float4 per thread per slab
+    static constexpr int B_PIECES = BN * 8;                    // 16-byte pieces of split weights per slab
+    static constexpr int B_P = B_PIECES / THREADS;
+    static constexpr int BUF = (BM + BN) * PITCH;
+    static constexpr int LDS_BYTES = 2 * BUF;
+
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
+    typedef __attribute__((address_space(3))) g2_u32x2 lds_u2;
+
+    template <class ALoad, class BLoad, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, BLoad& bload,
+                                                    f32x16 (&acc)[TM][TN], RA ra_desc, RB rb_desc, float a_scale) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int a_st = (tid >> 3) * PITCH + (tid & 7) * 8;
+        const int b_st = BM * PITCH + (tid >> 3) * PITCH + (tid & 7) * 16;
+        const int li = lane & 31, lh = lane >> 5;
+        const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
+        const int b_frag = BM * PITCH + (wn * TN * 32 + li) * PITCH + lh * 16;
+
+        f32x4 ra[A_F4];
+        g2_u32x4 rb[B_P];
+#define KN_LOAD2B(KT)                                                                                         \
+    {                                                                                                        \
+        aload.begin(KT); bload.begin(KT);                                                                    \
+        _Pragma("unroll") for (int j = 0; j < A_F4; ++j) ra[j] = aload(KT, j, ra_desc);                      \
+        _Pragma("unroll") for (int j = 0; j < B_P; ++j) rb[j] = bload(KT, j, rb_desc);                       \
+    }
+#define KN_STAGE2B(BUFOFF)                                                                                    \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                   \
+            g2_u32x2 hi, lo;                                                                                 \
+            f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                              \
+            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = hi;                                         \
+            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH + 64) = lo;                                    \
+        }                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < B_P; ++j)                                                      \
+            *(lds_u4*)(lds + (BUFOFF) + b_st + RS * j * PITCH) = rb[j];                                      \
+    }
+        // fragment reads run one (k-step, row-tile) ahead of the MFMAs that consume them, so a wave waits for
+        // LDS latency once per slab instead of once per row tile
+        f16x8 fa[2][2], fb[2][TN][2];
+#define KN_RD_A(BUFOFF, KS, I, SLOT)                                                                          \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                            \
+        fa[SLOT][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + a_frag + (I) * 32 * PITCH + p * 64 + (KS) * 32));
+#define KN_RD_B(BUFOFF, KS)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                           \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                        \
+            fb[KS][i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + b_frag + i * 32 * PITCH + p * 64 + (KS) * 32));
+#define KN_MFMA_ROW(KS, I, SLOT)                                                                              \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
+        f32x16 c = acc[I][j];                                                                                \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][1], fb[KS][j][0], c, 0, 0, 0);                   \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][1], c, 0, 0, 0);                   \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][0], c, 0, 0, 0);                   \
+        acc[I][j] = c;                                                                                       \
+    }
+        static_assert(TM % 2 == 0, "row tiles alternate between two fragment slots");
+        static_assert(A_F4 <= 2 * TM && B_P <= 2 * TM, "one staging piece per row step");
+        KN_LOAD2B(0);
+        KN_STAGE2B(0);
+        if (nk > 1) KN_LOAD2B(1);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = (kt & 1) * BUF, nxt = BUF - cur;
+            const bool st = kt + 1 < nk, ld = kt + 2 < nk;
+            KN_RD_B(cur, 0) KN_RD_A(cur, 0, 0, 0)
+            if (ld) { aload.begin(kt + 2); bload.begin(kt + 2); }
+            // 2 TM row steps; step r issues the reads of step r+1, then its own 3 TN MFMAs, then (while those run)
+            // moves one A and one B piece of slab kt+1 from registers into the idle buffer and re-issues their loads
+            // for slab kt+2 — the staging work is spread under the MFMAs instead of sitting between them
+#pragma unroll
+            for (int r = 0; r < 2 * TM; ++r) {
+                const int ks = r / TM, i = r % TM;
+                if (i + 1 < TM) { KN_RD_A(cur, ks, i + 1, (i + 1) & 1) }
+                else if (ks == 0) { KN_RD_B(cur, 1) KN_RD_A(cur, 1, 0, 0) }
+                __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
+                KN_MFMA_ROW(ks, i, i & 1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (r == TM - 1) {                   // between the two k-steps: slab kt+1 -> idle buffer, then reload for kt+2
+                    if (st) KN_STAGE2B(nxt);
+                    if (ld) {
+#pragma unroll
+                        for (int j = 0; j < A_F4; ++j) ra[j] = aload(kt + 2, j, ra_desc);
+#pragma unroll
+                        for (int j = 0; j < B_P; ++j) rb[j] = bload(kt + 2, j, rb_desc);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+#undef KN_RD_A
+#undef KN_RD_B
+#undef KN_MFMA_ROW
+#undef KN_LOAD2B
+#undef KN_STAGE2B
+#undef KN_KSTEP2B
+    }
+
+    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
+        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
+        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
+    }
+};

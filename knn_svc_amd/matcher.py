@@ -16,7 +16,7 @@ from pathlib import Path
 
 import torch
 
-from . import audio_io, config as C
+from . import audio_io, config as C, ops
 from .matching import match_at_inference_time
 from .vocoder import Vocoder
 from .wavlm import WavLMEncoder
@@ -47,7 +47,12 @@ class KNeighborsVC:
             harm = harmonics_out_feats_weighted[b] if harmonics_out_feats_weighted is not None else None
             outs.append(self.hifigan.forward(c[b].to(self.device).float(), f0[b].reshape(-1).to(self.device).float(),
                                              None if harm is None else harm.to(self.device).float()))
-        return torch.stack(outs, 0)
+        wav = torch.stack(outs, 0)
+        # the emulated-fp32 GEMMs turn an out-of-range activation into NaN instead of a wrong sample: surface it
+        if not bool(torch.isfinite(wav).all()):
+            raise ops.KnnSvcError("vocode: non-finite waveform (activation outside the f16x2 range, or non-finite input); "
+                                  "re-run with KNNSVC_GEMM=bf16x3")
+        return wav
 
     @torch.inference_mode()
     def special_match(self, src_wav_file, ref_wav_file, topk: int = 4, device=None, prioritize_f0=True,
