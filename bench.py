@@ -81,6 +81,9 @@ class GemmTimer:
             tile = "128" if kw["n"] > 64 else "64" if kw["n"] > 32 else "32"
             if fast and getattr(w, "_w2", None) is not None:
                 var = "F" + tile                      # conv_gemm2_kernel: fp32 emulated with three fp16 MFMAs
+                z = kw.get("batches", 1) * kw.get("groups", 1)
+                if kw["n"] % 256 == 0 and K >= 2048 and -(-kw["m"] // 256) * (kw["n"] // 256) * z >= 384:
+                    var = "F256"                      # conv_gemm2big_kernel (long-K shapes, see conv_gemm.hip)
             elif fast and getattr(w, "_w3", None) is not None:
                 var = "H" + tile                      # conv_gemm3_kernel: fp32 emulated with six bf16 MFMAs
             else:

@@ -57,6 +57,24 @@ def test_linear_emulated_fp32(M, K, N, mode, attr, monkeypatch):
     assert e3 <= 2.0 * e32 + 1e-6 and e3 < 1e-5 * float(ref.abs().max())
 
 
+def test_linear_f16x2_big_tile():
+    """Long-K, wide-N GEMMs take the 256x256 double-buffered tile (conv_gemm2big_kernel): ragged last row tile,
+    bias + GELU epilogue, rows sampled from the first, a middle and the last tile against fp64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 24577 + 130, 2048, 1024
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    wd = ops.attach_split(w.to(DEV))
+    if not hasattr(wd, "_w2"):
+        pytest.skip("KNNSVC_GEMM is not f16x2")
+    o = ops.linear(x.to(DEV), wd, b.to(DEV), act=ops.ACT_GELU).cpu()
+    rows = torch.cat([torch.arange(0, 200), torch.arange(12000, 12200), torch.arange(M - 200, M)])
+    ref = torch.nn.functional.gelu(x[rows].double() @ w.double().T + b.double())
+    err = float((o[rows].double() - ref).abs().max())
+    print(f"big tile max err {err:.2e}")
+    assert err < 2e-5 and bool(torch.isfinite(o).all())
+
+
 @pytest.mark.parametrize("xs,ws,a_scale", [(1e-3, 1e-4, 4096.0), (30.0, 5.0, 0.0), (0.05, 40.0, 0.0)])
 def test_linear_f16x2_scales(xs, ws, a_scale, monkeypatch):
     """The power-of-two operand scaling keeps small activations / odd weight magnitudes at fp32 accuracy,
