@@ -23,10 +23,6 @@ import os
 import sys
 import time
 
-# One hardware queue per HIP stream: the runtime's default of 4 makes the encoder's stream share a queue with one of
-# the match streams, which serialises conversion i+1's encoder behind conversion i's single-workgroup recurrences.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -36,7 +32,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from knn_svc_amd import config as C, dist as kdist, ops, synthetic as S      # noqa: E402
-from knn_svc_amd.matching import _side_stream, match_features, side_features               # noqa: E402
+from knn_svc_amd.matching import match_features, side_features               # noqa: E402
+from knn_svc_amd.pipeline import LanePipeline                                 # noqa: E402
 from knn_svc_amd.vocoder import Vocoder                                       # noqa: E402
 from knn_svc_amd.wavlm import WavLMEncoder                                    # noqa: E402
 
@@ -180,32 +177,19 @@ def step(enc, voc, src, sf0, pool_w, pool_f0, max_batch):
     return step_back(voc, step_front(enc, src, sf0, pool_w, pool_f0, max_batch))
 
 
-def run_steps(n, depth, enc, voc, src, sf0, pool_w, pool_f0, max_batch, streams):
-    """n conversions.  depth 1: one after the other on the current stream.  depth 2: the back half of
-    conversion i (match: single-workgroup recurrences on 2-4 CUs; vocoder) is enqueued on a second stream
-    and runs while the front half of conversion i+1 (the encoder) fills the rest of the chip — the way
-    bulk_match streams a list of sources.  Every conversion still does all of its work (cold pool)."""
+def run_steps(n, depth, enc, voc, src, sf0, pool_w, pool_f0, max_batch, pipe):
+    """n conversions.  depth 1: one after the other on the current stream.  depth 2: through the package's
+    stream scheduler (knn_svc_amd.pipeline.LanePipeline) — the back half of conversion i (match:
+    single-workgroup recurrences on 2-4 CUs; vocoder) is enqueued on a second stream and runs while the front
+    half of conversion i+1 (the encoder) fills the rest of the chip, the way bulk_match streams a list of
+    sources.  Every conversion still does all of its work (cold pool)."""
     if depth <= 1:
         y = None
         for _ in range(n):
             y = step(enc, voc, src, sf0, pool_w, pool_f0, max_batch)
         return y
-    front_s, back_s = streams
-    cur = torch.cuda.current_stream()
-    front_s.wait_stream(cur); back_s.wait_stream(cur)
-    y = None
-    for _ in range(n):
-        with torch.cuda.stream(front_s):
-            f = step_front(enc, src, sf0, pool_w, pool_f0, max_batch)
-            ev = front_s.record_event()
-        with torch.cuda.stream(back_s):
-            back_s.wait_event(ev)
-            for t in f.values():
-                t.record_stream(back_s)
-            y = step_back(voc, f)
-    cur.wait_stream(front_s); cur.wait_stream(back_s)
-    y.record_stream(cur)
-    return y
+    return pipe.run(range(n), lambda _i: step_front(enc, src, sf0, pool_w, pool_f0, max_batch),
+                    lambda _i, f: step_back(voc, f))[-1]
 
 
 def effective_cores() -> int:
@@ -302,8 +286,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if a.pipeline_depth > 1 else None
-    args = (enc, voc, src, sf0, pool_w, pool_f0, a.max_batch, streams)
+    pipe = LanePipeline(dev, lanes=1) if a.pipeline_depth > 1 else None
+    args = (enc, voc, src, sf0, pool_w, pool_f0, a.max_batch, pipe)
     with torch.inference_mode():
         step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)              # one-time setup outside W: hipGraph capture, split weights
         if a.warmup:

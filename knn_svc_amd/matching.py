@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import audio_io, config as C, features, ops, pool_cache
+from . import audio_io, config as C, features, ops, pipeline, pool_cache
 from .wavlm import WavLMEncoder, chunk_plan
 
 AUDIO_EXT = {".flac", ".wav", ".mp3"}
@@ -135,16 +135,21 @@ _SIDE = {}
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """Partner stream of the CURRENT stream (one per (device, stream)): concurrent match_features calls on
+    different streams (pipeline.LanePipeline) must not meet on one shared side stream."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=key)
+        _SIDE[key] = torch.cuda.Stream(device=idx)
     return _SIDE[key]
 
 
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
-                   return_debug=False, nn32=None):
+                   return_debug=False, nn32=None, nan_flags=None):
     """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors.  ``nn32`` may carry
-    neighbours already found by the pool-sharded search (knn_svc_amd.dist.sharded_knn)."""
+    neighbours already found by the pool-sharded search (knn_svc_amd.dist.sharded_knn).  ``nan_flags``: a
+    list that receives the kNN NaN flag instead of the host checking it here (the caller then calls
+    ``ops.raise_if_nan`` on each entry once everything is enqueued — keeps a stream pipeline free of syncs)."""
     q = query_seq.contiguous()
     P = matching_list
     qn, qs = ops.row_norms(q)
@@ -186,7 +191,10 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
         if t is not None:
             t.record_stream(main)
     if nan_flag is not None:
-        ops.raise_if_nan(nan_flag)
+        if nan_flags is not None:
+            nan_flags.append(nan_flag)
+        else:
+            ops.raise_if_nan(nan_flag)
     if return_debug:
         return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2,
                                                 iters_wavlm=it1 if it1 is not None else 0,
@@ -230,12 +238,19 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     harmonics_list = torch.cat([harm_pool[k] for k in keys], 0).contiguous()
 
     out_c, harm_c, audio_c, f0_c = {}, {}, {}, {}
-    for item in query_pool:
-        if required_subset is not None and \
-                os.path.basename(item).split(".")[0] + "/" + os.path.basename(ref_wav_file) not in required_subset:
-            continue
-        of, hw, sf0 = match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
-                                     harmonics_list, ckpt_type, post_opt)
+    items = [item for item in query_pool
+             if required_subset is None or
+             os.path.basename(item).split(".")[0] + "/" + os.path.basename(ref_wav_file) in required_subset]
+    # the per-item bodies are independent chains of mostly single-workgroup kernels: three at a time, each on
+    # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
+    flags = []
+    body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
+                                       harmonics_list, ckpt_type, post_opt, nan_flags=flags)
+    lanes = min(3, len(items))
+    results = pipeline.LanePipeline(matching_list.device, lanes).run(items, body) if lanes > 1 else [body(i) for i in items]
+    for f in flags:
+        ops.raise_if_nan(f)
+    for item, (of, hw, sf0) in zip(items, results):
         out_c[item] = of; audio_c[item] = None; f0_c[item] = sf0
         if hw is not None:
             harm_c[item] = hw

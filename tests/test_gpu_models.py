@@ -224,3 +224,32 @@ def test_bulk_match_dataset_mode_uses_pool_store(tmp_path):
         xa, _ = audio_io.read_wav(a); xb, _ = audio_io.read_wav(b)
         assert np.array_equal(xa, xb)
     matching._POOL_CACHE = None
+
+
+def test_lane_pipeline_matches_sequential_order():
+    """pipeline.LanePipeline: three match bodies in flight on their own stream pairs + a tail stream give
+    bit-identical results to running the items one after the other (same kernels, same inputs)."""
+    from knn_svc_amd import matching, ops
+    from knn_svc_amd.pipeline import LanePipeline
+    g = torch.Generator().manual_seed(5)
+    P = S.clustered_features(3000, 256, seed=3).to(DEV)
+    Pf0 = (torch.rand(3000, generator=g) * 200 + 100).to(DEV)
+    Pf0[::7] = 0
+    Ph = torch.rand(3000, 49, generator=g).to(DEV)
+    items = []
+    for i in range(5):
+        q = S.clustered_features(120 + 8 * i, 256, seed=20 + i).to(DEV)
+        f = (torch.rand(q.shape[0], generator=g) * 200 + 100).to(DEV)
+        f[::5] = 0
+        items.append((q, f))
+    body = lambda it, flags=None: matching.match_features(it[0], it[1], P, Pf0, Ph, "mix", "post_opt_0.2", nan_flags=flags)
+    seq = [body(it) for it in items]
+    flags = []
+    tail = lambda it, h: (h[0] * 2.0, h[1], h[2])
+    par = LanePipeline(DEV, lanes=3).run(items, lambda it: body(it, flags), tail)
+    assert len(flags) == 5
+    for f in flags:
+        ops.raise_if_nan(f)
+    torch.cuda.synchronize()
+    for (a0, a1, a2), (b0, b1, b2) in zip(seq, par):
+        assert torch.equal(a0 * 2.0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
