@@ -333,7 +333,15 @@ __global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
-    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
+    // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2; the fp32 A panel of a
+    // row tile is re-read by every column tile, so all column tiles of one row tile get ids that are congruent mod 8
+    // (same XCD) and adjacent in dispatch order: the panel comes from HBM once and from that L2 afterwards
+    // (what-if with cache-hot A: 0.99 -> 0.87 ms on FFN2).  Ids are grouped 8 row tiles x all column tiles.
+    const int gy = (a.n + G::BN - 1) / G::BN;
+    const int L = blockIdx.x, grp = L / (8 * gy), rem = L - grp * 8 * gy;
+    const int mt = grp * 8 + (rem & 7), nt = rem >> 3;
+    const int m0 = mt * G::BM, n0 = nt * G::BN;
+    if (m0 >= a.m) return;                                    // padding of the last group
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
 
@@ -345,10 +353,9 @@ __global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     typedef FastALoader<G::A_F4, G::RS> AL;
-    typedef Split2BLoader<G::B_P, G::B_PIECES, G::THREADS> BL;
     AL al(a, m0, threadIdx.x);
-    BL bl(a.n, a.K, n0, threadIdx.x);
-    G::mainloop(lds, a.K / 32, al, bl, acc, AL::desc(a, xz), BL::desc(wz, a.n, a.K), a.a_scale);
+    G::mainloop(lds, a.K / 32, al, acc, AL::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)), a.n, a.K, n0,
+                a.a_scale);
     conv_epilogue<G>(a, acc, m0, n0, b, g);
 }
 
@@ -361,7 +368,8 @@ int launch2big(const ConvArgs& a, int batches, hipStream_t st) {
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
-    dim3 grid((unsigned)cdiv64(a.m, G::BM), (unsigned)cdiv64(a.n, G::BN), (unsigned)(batches * a.groups));
+    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;          // row tiles padded to whole groups of 8 (one per XCD)
+    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm2big_kernel<G>), grid, dim3(G::THREADS), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2big");
 }
@@ -519,7 +527,9 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         // 256x256 double-buffered tile (one block per CU): fewer L2/LDS bytes per MFMA, so the chip holds a higher
         // clock (1.65 vs 1.39 GHz measured) — pays when the K loop is long enough to amortise the exposed
         // prologue/epilogue of a lone block and the grid still covers the chip (FFN2: 279 vs 242 TFLOP/s)
-        if (d->n >= 256 && d->n % 256 == 0 && a.K >= 2048 &&
+        static int kmin = -1;
+        if (kmin < 0) { const char* e = getenv("KNNSVC_F256_KMIN"); kmin = e ? atoi(e) : 2048; }
+        if (d->n >= 256 && d->n % 256 == 0 && a.K >= kmin &&
             cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
             return launch2big<F256>(a, d->batches, st);
         if (d->n > 64) return launch2<F128>(a, d->batches, st);

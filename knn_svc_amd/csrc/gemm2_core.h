@@ -145,69 +145,109 @@ struct Gemm2Tile {
 
 // -------------------------------------------------------------------------------------------------
 // Large-tile variant: WM x WN waves (NT = 64 WM WN threads, one block per CU), double-buffered LDS,
-// ONE barrier per K slab.  At 128x128 the LDS port (reads 256 B/clk, writes ~80 B/clk per CU) and the
-// vector-memory path are each busy ~70-90 % of the MFMA time of a slab and the three interfere; a
-// 256x256 block halves both per MFMA.  Slab kt+1 is split and written into the idle buffer between
-// the two k-steps of slab kt, and the loads of slab kt+2 are issued right after, so a global load has
-// a full slab (~3000 MFMA cycles) to land.
+// ONE barrier per K slab.  At 128x128 the LDS port and the vector-memory path are each busy ~70-90 % of
+// the MFMA time of a slab and the three interfere; a 256x256 block halves both per MFMA and the chip
+// holds a higher clock on it (1.65 vs 1.39 GHz measured).
+//   A: fp32 from HBM -> registers (one slab ahead) -> split -> LDS rows of 144 B (as Gemm2Tile).
+//   B: the pre-split weights go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no VGPRs and no
+//      ds_write: the VGPR->LDS store path moves only ~80 B/clk per CU and was the largest stall of the slab
+//      (what-if build without staging: 380 vs 284 TFLOP/s).  A DMA instruction fills 1 KiB of CONTIGUOUS LDS
+//      (lane L -> base + 16 L), so B rows are unpadded (128 B) and bank conflicts are avoided by an XOR
+//      swizzle instead: 16-byte piece q of row r lives in slot q ^ ((r >> 1) & 7); the DMA applies it through
+//      its per-lane SOURCE address, the fragment reads through their LDS address.
+// Order inside a slab: DMA of B(kt+1) first, A loads of kt+2 later; vmcnt completes in issue order, so
+// `s_waitcnt vmcnt(#A loads)` before the barrier guarantees the DMA has landed while the A loads stay in flight.
 // -------------------------------------------------------------------------------------------------
 template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
 struct Gemm2Big {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
-    static constexpr int BK = 32, PITCH = 144, THREADS = 64 * WM * WN, RS = THREADS / 8;
+    static constexpr int BK = 32, PITCH = 144, BROW = 128, NW = WM * WN, THREADS = 64 * NW, RS = THREADS / 8;
     static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    static_assert(BM % RS == 0 && (BN * 8) % THREADS == 0, "staging shape");
+    static_assert(BM % RS == 0 && (BN * BROW) % (1024 * NW) == 0, "staging shape");
+    static_assert(TM % 2 == 0, "row tiles alternate between two fragment slots");
     static constexpr int A_F4 = BM / RS;                       // fp32 float4 per thread per slab
-    static constexpr int B_PIECES = BN * 8;                    // 16-byte pieces of split weights per slab
-    static constexpr int B_P = B_PIECES / THREADS;
-    static constexpr int BUF = (BM + BN) * PITCH;
+    static constexpr int B_DMA = BN * BROW / 1024 / NW;        // LDS-DMA instructions per wave per slab
+    static constexpr int BOFF = BM * PITCH;                    // B region inside a buffer
+    static constexpr int BUF = BOFF + BN * BROW;
     static constexpr int LDS_BYTES = 2 * BUF;
+    static constexpr int OOB_OFF = 0x40000000;
 
     typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) void lds_v;
     typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
     typedef __attribute__((address_space(3))) g2_u32x2 lds_u2;
 
-    template <class ALoad, class BLoad, class RA, class RB>
-    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, BLoad& bload,
-                                                    f32x16 (&acc)[TM][TN], RA ra_desc, RB rb_desc, float a_scale) {
+    __device__ __forceinline__ static void wait_vm(bool keep_a_loads) {   // all but the A_F4 youngest VMEM ops done
+        if (keep_a_loads) __builtin_amdgcn_s_waitcnt(0x0F70 | A_F4);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+
+    // aload: fp32 A loader (begin(kt), operator()(kt, j, desc), finish()); rb_desc: buffer resource over the split
+    // weights of this group ([N][K/32][2][32] fp16); n0: first weight row of the block
+    template <class ALoad, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, f32x16 (&acc)[TM][TN],
+                                                    RA ra_desc, RB rb_desc, int N, int K, int n0, float a_scale) {
+        static_assert(A_F4 < 16, "vmcnt immediate");
+        static_assert(B_DMA <= TM, "the DMA pieces are issued in the first k-step, before the early waves reload A");
         lds_c* lds = (lds_c*)lds_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wm = wave / WN, wn = wave % WN;
         const int a_st = (tid >> 3) * PITCH + (tid & 7) * 8;
-        const int b_st = BM * PITCH + (tid >> 3) * PITCH + (tid & 7) * 16;
         const int li = lane & 31, lh = lane >> 5;
         const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
-        const int b_frag = BM * PITCH + (wn * TN * 32 + li) * PITCH + lh * 16;
+        const int b_row = BOFF + (wn * TN * 32 + li) * BROW;
+        const int swz = (li >> 1) & 7;
+        int b_x[2][2];                                             // [k-step][plane]: swizzled slot offset of this lane's piece
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) b_x[ks][p] = ((p * 4 + ks * 2 + lh) ^ swz) * 16;
+        int b_src[B_DMA];                                          // per-lane source byte offset of each DMA piece (slab 0)
+        const int row_bytes = (K / 32) * 128;
+#pragma unroll
+        for (int t = 0; t < B_DMA; ++t) {
+            const int row = (wave * B_DMA + t) * 8 + (lane >> 3);
+            const int piece = (lane & 7) ^ ((row >> 1) & 7);
+            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + piece * 16 : OOB_OFF;
+        }
+        const bool early = wave < NW / 2;        // waves w and w + NW/2 share a SIMD (cyclic wave -> SIMD assignment)
 
         f32x4 ra[A_F4];
-        g2_u32x4 rb[B_P];
-#define KN_LOAD2B(KT)                                                                                         \
-    {                                                                                                        \
-        aload.begin(KT); bload.begin(KT);                                                                    \
-        _Pragma("unroll") for (int j = 0; j < A_F4; ++j) ra[j] = aload(KT, j, ra_desc);                      \
-        _Pragma("unroll") for (int j = 0; j < B_P; ++j) rb[j] = bload(KT, j, rb_desc);                       \
-    }
-#define KN_STAGE2B(BUFOFF)                                                                                    \
-    {                                                                                                        \
-        _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                   \
-            g2_u32x2 hi, lo;                                                                                 \
-            f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                              \
-            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = hi;                                         \
-            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH + 64) = lo;                                    \
-        }                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < B_P; ++j)                                                      \
-            *(lds_u4*)(lds + (BUFOFF) + b_st + RS * j * PITCH) = rb[j];                                      \
-    }
-        // fragment reads run one (k-step, row-tile) ahead of the MFMAs that consume them, so a wave waits for
-        // LDS latency once per slab instead of once per row tile
         f16x8 fa[2][2], fb[2][TN][2];
+#define KN_DMA_B1(BUFOFF, KT, T)                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + (BUFOFF) + BOFF + (wave * B_DMA + (T)) * 1024), 16, \
+                                             b_src[T], (KT) * 128, 0, 0);
+#define KN_DMA_B(BUFOFF, KT) _Pragma("unroll") for (int t = 0; t < B_DMA; ++t) { KN_DMA_B1(BUFOFF, KT, t) }
+#define KN_LOAD_A(KT)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) ra[j] = aload(KT, j, ra_desc);
+#if defined(KN_WHATIF_SINK_SPLIT)
+#define KN_STAGE_A(BUFOFF)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                       \
+        g2_u32x2 hi, lo;                                                                                     \
+        f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                                  \
+        asm volatile("" ::"v"(hi[0]), "v"(hi[1]), "v"(lo[0]), "v"(lo[1]));                                   \
+    }
+#elif defined(KN_WHATIF_SINK_RAW)
+#define KN_STAGE_A(BUFOFF)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                       \
+        asm volatile("" ::"v"(ra[j][0]), "v"(ra[j][1]), "v"(ra[j][2]), "v"(ra[j][3]));                       \
+    }
+#else
+#define KN_STAGE_A(BUFOFF)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                       \
+        g2_u32x2 hi, lo;                                                                                     \
+        f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                                  \
+        *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = hi;                                             \
+        *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH + 64) = lo;                                        \
+    }
+#endif
 #define KN_RD_A(BUFOFF, KS, I, SLOT)                                                                          \
     _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                            \
         fa[SLOT][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + a_frag + (I) * 32 * PITCH + p * 64 + (KS) * 32));
 #define KN_RD_B(BUFOFF, KS)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                           \
         _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                        \
-            fb[KS][i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + b_frag + i * 32 * PITCH + p * 64 + (KS) * 32));
+            fb[KS][i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + b_row + i * 32 * BROW + b_x[KS][p]));
 #define KN_MFMA_ROW(KS, I, SLOT)                                                                              \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
         f32x16 c = acc[I][j];                                                                                \
@@ -216,20 +256,22 @@ struct Gemm2Big {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][0], c, 0, 0, 0);                   \
         acc[I][j] = c;                                                                                       \
     }
-        static_assert(TM % 2 == 0, "row tiles alternate between two fragment slots");
-        static_assert(A_F4 <= 2 * TM && B_P <= 2 * TM, "one staging piece per row step");
-        KN_LOAD2B(0);
-        KN_STAGE2B(0);
-        if (nk > 1) KN_LOAD2B(1);
+        aload.begin(0);
+        KN_LOAD_A(0)
+        __builtin_amdgcn_sched_barrier(0);
+        KN_DMA_B(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        KN_STAGE_A(0)
+        if (nk > 1) { aload.begin(1); KN_LOAD_A(1) }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm(nk > 1);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = (kt & 1) * BUF, nxt = BUF - cur;
             const bool st = kt + 1 < nk, ld = kt + 2 < nk;
             KN_RD_B(cur, 0) KN_RD_A(cur, 0, 0, 0)
-            if (ld) { aload.begin(kt + 2); bload.begin(kt + 2); }
-            // 2 TM row steps; step r issues the reads of step r+1, then its own 3 TN MFMAs, then (while those run)
-            // moves one A and one B piece of slab kt+1 from registers into the idle buffer and re-issues their loads
-            // for slab kt+2 — the staging work is spread under the MFMAs instead of sitting between them
+            if (ld) aload.begin(kt + 2);
+            // 2 TM row steps; step r issues the fragment reads of step r+1, then its own 3 TN MFMAs
 #pragma unroll
             for (int r = 0; r < 2 * TM; ++r) {
                 const int ks = r / TM, i = r % TM;
@@ -238,25 +280,32 @@ struct Gemm2Big {
                 __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
                 KN_MFMA_ROW(ks, i, i & 1)
                 __builtin_amdgcn_sched_barrier(0);
-                if (r == TM - 1) {                   // between the two k-steps: slab kt+1 -> idle buffer, then reload for kt+2
-                    if (st) KN_STAGE2B(nxt);
-                    if (ld) {
-#pragma unroll
-                        for (int j = 0; j < A_F4; ++j) ra[j] = aload(kt + 2, j, ra_desc);
-#pragma unroll
-                        for (int j = 0; j < B_P; ++j) rb[j] = bload(kt + 2, j, rb_desc);
-                    }
+                // one DMA piece of B(kt+1) behind each of the first row steps (its ~100-cycle issue hides under the
+                // six MFMAs just queued); all of them precede this wave's A loads of the slab (see wait_vm)
+#ifndef KN_WHATIF_NODMA
+                if (r < B_DMA && st) { KN_DMA_B1(nxt, kt + 1, r) }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                // The two waves of a SIMD (w and w + NW/2) stage A at different times — one between the k-steps, the
+                // other after the second — so one of them is always issuing MFMAs while the other splits and stores.
+                if ((r == TM - 1 && early) || (r == 2 * TM - 1 && !early)) {
+#ifndef KN_WHATIF_NOSTAGE_A
+                    if (st) { KN_STAGE_A(nxt) }
+#endif
+                    if (ld) { KN_LOAD_A(kt + 2) }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            wait_vm(ld);
             __syncthreads();
         }
+#undef KN_DMA_B
+#undef KN_DMA_B1
+#undef KN_LOAD_A
+#undef KN_STAGE_A
 #undef KN_RD_A
 #undef KN_RD_B
 #undef KN_MFMA_ROW
-#undef KN_LOAD2B
-#undef KN_STAGE2B
-#undef KN_KSTEP2B
     }
 
     __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
