@@ -79,8 +79,9 @@ class GemmTimer:
             if fast and getattr(w, "_w2", None) is not None:
                 var = "F" + tile                      # conv_gemm2_kernel: fp32 emulated with three fp16 MFMAs
                 z = kw.get("batches", 1) * kw.get("groups", 1)
-                if kw["n"] % 256 == 0 and K >= 2048 and -(-kw["m"] // 256) * (kw["n"] // 256) * z >= 384:
-                    var = "F256"                      # conv_gemm2big_kernel (long-K shapes, see conv_gemm.hip)
+                kmin = os.environ.get("KNNSVC_F256_KMIN")
+                if kmin and kw["n"] % 256 == 0 and K >= max(2048, int(kmin)) and -(-kw["m"] // 256) * (kw["n"] // 256) * z >= 384:
+                    var = "F256"                      # opt-in conv_gemm2big_kernel (see conv_gemm.hip)
             elif fast and getattr(w, "_w3", None) is not None:
                 var = "H" + tile                      # conv_gemm3_kernel: fp32 emulated with six bf16 MFMAs
             else:

@@ -311,7 +311,21 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
-    const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
+    // XCD-aware tile order (see conv_gemm2big_kernel): ids congruent mod 8 share an L2; a group is 8 row tiles x all
+    // column tiles, so the column tiles of one row tile run on one XCD, next to each other in time
+    // and the columns are walked in patches of CW tiles, so an XCD's ~96 resident blocks form a (12 x 8)-ish patch
+    // that shares both A and B panels through its L2.
+    const int gy = (a.n + G::BN - 1) / G::BN;
+    const int gx8 = (int)gridDim.x / gy;                      // row tiles padded to a multiple of 8
+    constexpr int CW = 8;
+    int L = blockIdx.x;
+    const int full = (gy / CW) * CW * gx8;                    // ids covered by full-width column patches
+    int c0, cw;
+    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
+    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
+    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
+    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
+    if (m0 >= a.m) return;                                    // padding of the last group
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;      // 64 halves = 128 B per (row, slab)
 
@@ -383,7 +397,8 @@ int launch2(const ConvArgs& a, int batches, hipStream_t st) {
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
-    dim3 grid((unsigned)cdiv64(a.m, G::BM), (unsigned)cdiv64(a.n, G::BN), (unsigned)(batches * a.groups));
+    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;          // row tiles padded to whole groups of 8 (one per XCD)
+    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm2_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2");
 }
@@ -524,14 +539,15 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         a.a_scale = d->a_f16x2_scale > 0.f ? d->a_f16x2_scale : KN_F16X2_A_SCALE;
         { int e2 = 0; KN_REQUIRE(frexpf(a.a_scale, &e2) == 0.5f && frexpf(d->w_f16x2_scale, &e2) == 0.5f, "conv_gemm: f16x2 scales must be powers of two"); }
         a.out_scale = 1.0f / (a.a_scale * d->w_f16x2_scale);
-        // 256x256 double-buffered tile (one block per CU): fewer L2/LDS bytes per MFMA, so the chip holds a higher
-        // clock (1.65 vs 1.39 GHz measured) — pays when the K loop is long enough to amortise the exposed
-        // prologue/epilogue of a lone block and the grid still covers the chip (FFN2: 279 vs 242 TFLOP/s)
-        static int kmin = -1;
-        if (kmin < 0) { const char* e = getenv("KNNSVC_F256_KMIN"); kmin = e ? atoi(e) : 2048; }
-        if (d->n >= 256 && d->n % 256 == 0 && a.K >= kmin &&
-            cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
-            return launch2big<F256>(a, d->batches, st);
+        // 256x256 double-buffered tile with LDS-DMA weights (one block per CU): fewer L2/LDS bytes per MFMA and a
+        // higher sustained clock (1.65 vs 1.39 GHz) — 279 vs 242 TFLOP/s on an isolated long-K GEMM (FFN2), but a lone
+        // block per CU cannot hide its prologue/epilogue and loses when other streams share the chip (end-to-end bench:
+        // 505 vs 511 xRT), so it is opt-in: KNNSVC_F256_KMIN=<smallest K that takes it> (read per qualifying launch).
+        if (d->n >= 256 && d->n % 256 == 0 && a.K >= 2048) {
+            const char* e = getenv("KNNSVC_F256_KMIN");
+            if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
+                return launch2big<F256>(a, d->batches, st);
+        }
         if (d->n > 64) return launch2<F128>(a, d->batches, st);
         if (d->n > 32) return launch2<F64>(a, d->batches, st);
         return launch2<F32>(a, d->batches, st);

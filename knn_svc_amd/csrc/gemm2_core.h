@@ -77,16 +77,24 @@ struct Gemm2Tile {
 
         f32x4 ra[A_F4];
         g2_u32x4 rb[B_P];
-#define KN_STAGE2()                                                                                           \
-    {                                                                                                        \
+#ifdef KN_T_NOSTAGE_A
+#define KN_STAGE2_A() _Pragma("unroll") for (int j = 0; j < A_F4; ++j) asm volatile("" ::"v"(ra[j][0]), "v"(ra[j][1]), "v"(ra[j][2]), "v"(ra[j][3]));
+#else
+#define KN_STAGE2_A()                                                                                         \
         _Pragma("unroll") for (int j = 0; j < A_F4; ++j)                                                     \
-            split_store(lds + a_st + 32 * j * PITCH, aload.finish(ra[j]), a_scale);                                   \
+            split_store(lds + a_st + 32 * j * PITCH, aload.finish(ra[j]), a_scale);
+#endif
+#ifdef KN_T_NOSTAGE_B
+#define KN_STAGE2_B() _Pragma("unroll") for (int j = 0; j < B_P; ++j) asm volatile("" ::"v"(rb[j][0]), "v"(rb[j][1]), "v"(rb[j][2]), "v"(rb[j][3]));
+#else
+#define KN_STAGE2_B()                                                                                         \
         _Pragma("unroll") for (int j = 0; j < B_P; ++j) {                                                    \
             const int q = tid + 256 * j;                                                                     \
             if (B_PIECES % 256 == 0 || q < B_PIECES)                                                         \
                 *(lds_u4*)(lds + BM * PITCH + (q >> 3) * PITCH + (q & 7) * 16) = rb[j];                       \
-        }                                                                                                    \
-    }
+        }
+#endif
+#define KN_STAGE2() { KN_STAGE2_A() KN_STAGE2_B() }
         aload.begin(0); bload.begin(0);
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) ra[j] = aload(0, j, ra_desc);
@@ -135,6 +143,8 @@ struct Gemm2Tile {
     }
 
 #undef KN_STAGE2
+#undef KN_STAGE2_A
+#undef KN_STAGE2_B
     __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
         return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     }

@@ -57,10 +57,12 @@ def test_linear_emulated_fp32(M, K, N, mode, attr, monkeypatch):
     assert e3 <= 2.0 * e32 + 1e-6 and e3 < 1e-5 * float(ref.abs().max())
 
 
-def test_linear_f16x2_big_tile():
-    """Long-K, wide-N GEMMs take the 256x256 double-buffered tile (conv_gemm2big_kernel): ragged last row tile,
-    bias + GELU epilogue, rows sampled from the first, a middle and the last tile against fp64."""
+def test_linear_f16x2_big_tile(monkeypatch):
+    """The opt-in 256x256 double-buffered tile with LDS-DMA weights (conv_gemm2big_kernel, KNNSVC_F256_KMIN): ragged
+    last row tile, bias + GELU epilogue, rows sampled from the first, a middle and the last tile against fp64; the
+    default 128x128 kernel must agree with it to fp32 rounding."""
     ops = _ops()
+    monkeypatch.setenv("KNNSVC_F256_KMIN", "2048")
     g = torch.Generator().manual_seed(11)
     M, K, N = 24577 + 130, 2048, 1024
     x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
@@ -73,6 +75,9 @@ def test_linear_f16x2_big_tile():
     err = float((o[rows].double() - ref).abs().max())
     print(f"big tile max err {err:.2e}")
     assert err < 2e-5 and bool(torch.isfinite(o).all())
+    monkeypatch.delenv("KNNSVC_F256_KMIN")
+    o128 = ops.linear(x.to(DEV), wd, b.to(DEV), act=ops.ACT_GELU).cpu()
+    assert float((o128 - o).abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("xs,ws,a_scale", [(1e-3, 1e-4, 4096.0), (30.0, 5.0, 0.0), (0.05, 40.0, 0.0)])
