@@ -94,6 +94,28 @@ def attach_split(w: torch.Tensor) -> torch.Tensor:
     return w
 
 
+_GRAPH_READY = set()
+
+
+def prepare_graph_capture(device) -> None:
+    """torch registers per-generator graph-state tensors at the first ``capture_begin`` on a device.  If that first
+    capture happens under ``torch.inference_mode()`` (KNeighborsVC's methods are decorated with it) they become
+    inference tensors, and every later capture outside inference mode dies with "Inplace update to inference tensor".
+    Doing one trivial capture in normal mode first makes the capture sites order-independent."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx in _GRAPH_READY:
+        return
+    with torch.inference_mode(False):
+        t = torch.zeros(1, device=torch.device("cuda", idx))
+        torch.cuda.synchronize(idx)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            t.add_(1.0)
+        del g
+    _GRAPH_READY.add(idx)
+
+
 # ------------------------------------------------------------------ implicit-GEMM convolution
 def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None, ldx=None, ldo=None,
               bias=None, bias_period=0, act=ACT_NONE, act_slope=0.0, a_slope=1.0, resid=None, ldr=None,

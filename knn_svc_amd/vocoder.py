@@ -82,6 +82,7 @@ class Vocoder:
     def _conv(self, x, w, out, *, T_in, cin, cout, k, **kw):
         return ops.conv_gemm(x, w, out, n=cout, cin=cin, taps=k, t_in=T_in, **kw)
 
+    @torch.inference_mode()
     def forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None) -> torch.Tensor:
         """c [N, hubert_dim], f0 [N], harm [N, 49] (mix only), all fp32 on the GPU -> waveform [N*hop].
 
@@ -101,6 +102,7 @@ class Vocoder:
                 sh.copy_(harm)
             self._forward(sc, sf, sh)                      # warm-up: one-time function attributes, allocator pools
             torch.cuda.synchronize()
+            ops.prepare_graph_capture(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._forward(sc, sf, sh)

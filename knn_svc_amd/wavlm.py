@@ -115,6 +115,7 @@ class WavLMEncoder:
             self._tables[T] = self.rel_emb[lut].T.contiguous().to(self.device)       # [H, 2T-1]
         return self._tables[T]
 
+    @torch.inference_mode()
     def encode_batch(self, wav: torch.Tensor) -> torch.Tensor:
         """[B, L] equal-length (already padded) chunks on the GPU -> [B, T, E].
 
@@ -129,6 +130,7 @@ class WavLMEncoder:
             sin = wav.clone()
             self._encode_batch(sin)                        # warm-up: bias table upload, function attributes, pools
             torch.cuda.synchronize()
+            ops.prepare_graph_capture(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._encode_batch(sin)

@@ -16,7 +16,7 @@ def avg(path, counter, key):
                 vals.setdefault(name, []).append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in vals.items()}
 
-KEY = "conv_gemm3_kernel<Gemm3Tile<128, 128"
+KEY = sys.argv[3] if len(sys.argv) > 3 else "conv_gemm2_kernel<Gemm2Tile<128, 128"
 f = avg(sys.argv[1], "FETCH_SIZE", KEY)
 w = avg(sys.argv[2], "WRITE_SIZE", KEY)
 name = next(iter(f))
@@ -24,6 +24,6 @@ fk, n = f[name]
 wk, _ = w[name]
 out = dict(kernel=name, launches=n, fetch_size_kib_avg=round(fk, 1), write_size_kib_avg=round(wk, 1),
            hbm_bytes_per_launch=int((2 * fk + wk) * 1024),
-           note="2 x FETCH_SIZE + WRITE_SIZE, averaged over every launch of the kernel in a 3-step bench.py run "
-                "(1 warm-up + 2 timed); separate --pmc passes")
+           note="2 x FETCH_SIZE + WRITE_SIZE, averaged over every launch of the kernel in a bench.py run (--steps 2 --warmup 1, plus the "
+                "setup, latency and eager roofline passes bench.py adds); separate --pmc passes")
 print(json.dumps(out, indent=1))
