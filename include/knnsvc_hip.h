@@ -49,6 +49,8 @@ const char* knnsvc_last_error(void);
  * With convt_u > 0 the output element (m, n) is scattered to row m*convt_u + n/convt_cout - convt_pad,
  * column n % convt_cout (rows outside [0,t_out) dropped): a stride-u transposed convolution whose
  * kernel is taps*u wide, written as one GEMM over K = taps*cin, N = u*cout.
+ * X rows are ldx floats apart; ldx >= cin, except that taps == 1 also accepts overlapping rows (ldx < cin):
+ * the framed view of a signal, row t = x[t*ldx .. t*ldx + cin) — how the 400-point STFT (hop 320) is a GEMM.
  * ------------------------------------------------------------------------------------------ */
 enum { KNNSVC_ACT_NONE = 0, KNNSVC_ACT_GELU = 1, KNNSVC_ACT_LRELU = 2, KNNSVC_ACT_TANH = 3 };
 

@@ -495,7 +495,8 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     KN_REQUIRE(d && d->x && d->w && d->out, "conv_gemm: null operand");
     KN_REQUIRE(d->cin > 0 && d->taps > 0 && d->n > 0 && d->m >= 0 && d->t_in >= 0, "conv_gemm: bad sizes");
     KN_REQUIRE(d->batches > 0 && d->groups > 0, "conv_gemm: batches/groups must be positive");
-    KN_REQUIRE(d->ldx >= d->cin && d->stride > 0, "conv_gemm: ldx < cin or stride <= 0");
+    // rows may overlap (ldx < cin) only without taps: the framed-signal view of an STFT (row t = x[t*hop .. t*hop+cin))
+    KN_REQUIRE((d->ldx >= d->cin || (d->taps == 1 && d->ldx > 0)) && d->stride > 0, "conv_gemm: ldx < cin or stride <= 0");
     KN_REQUIRE((long)d->batches * d->groups <= 65535, "conv_gemm: batches*groups > 65535");
     KN_REQUIRE(cdiv64(d->n, 32) <= 65535, "conv_gemm: n too large for grid.y");
     if (d->convt_u) {

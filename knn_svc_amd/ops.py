@@ -309,8 +309,11 @@ def weighted_gather(idx4, w, pool):
 
 
 # ------------------------------------------------------------------ side features + synth
-def reflect_pad(x1d, pad):
-    out = torch.empty(x1d.numel() + 2 * pad, device=x1d.device, dtype=torch.float32)
+def reflect_pad(x1d, pad, extra=0):
+    """-> [n + 2 pad (+ extra zeros at the end)]"""
+    out = torch.empty(x1d.numel() + 2 * pad + extra, device=x1d.device, dtype=torch.float32)
+    if extra:
+        out[-extra:].zero_()
     check(_lib.load().knnsvc_reflect_pad(_p(x1d), x1d.numel(), pad, _p(out), _stream()), "reflect_pad")
     return out
 
