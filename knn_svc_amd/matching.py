@@ -140,7 +140,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
     idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=idx)
+        _SIDE[key] = torch.cuda.Stream(device=idx, priority=torch.cuda.current_stream(idx).priority)
     return _SIDE[key]
 
 

@@ -34,7 +34,11 @@ class LanePipeline:
             raise ValueError("lanes must be >= 1")
         self.device = torch.device(device)
         self.lanes = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
-        self.tail_stream = torch.cuda.Stream(device=self.device)
+        # The tail carries the single-workgroup recurrences: high priority puts it (and its partner stream, see
+        # matching._side_stream) on hardware queues of their own — normal-priority streams can collide with each
+        # other on a queue (more so once RCCL has created its streams) but never with these — and lets a lone
+        # workgroup take the first CU that frees up.
+        self.tail_stream = torch.cuda.Stream(device=self.device, priority=-1)
 
     def run(self, items, head, tail=None):
         """results[i] = tail(item_i, head(item_i)) (or head(item_i) without a tail), in item order.
