@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 3
+#define KNNSVC_ABI_VERSION 4
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -70,6 +70,8 @@ typedef struct knnsvc_conv_desc {
     const void* w_f16x2;               /* optional: w pre-split by knnsvc_split_weight_f16x2; wins over w_bf16x3 */
     float w_f16x2_scale;               /* the power-of-two scale w_f16x2 was split with                         */
     float a_f16x2_scale;               /* power-of-two activation pre-scale of the f16x2 path; 0 = default 16    */
+    int32_t x_f16x2;                   /* 1: x already is in the f16x2 split layout (see below), scale 16           */
+    int32_t out_f16x2;                 /* 1: write out in the f16x2 split layout (scale 16) for the next GEMM       */
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
@@ -89,24 +91,34 @@ int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* ou
  * below ~0.2 / a_f16x2_scale lose relative accuracy (absolute floor 3e-8 / a_f16x2_scale per element). */
 int knnsvc_split_weight_f16x2(const float* w, int64_t rows, int32_t K, float scale, void* out, void* stream);
 
+/* Activations in the f16x2 split layout ("A2"): a [rows, C] matrix (C % 32 == 0, row pitch ld floats, ld % 32 == 0)
+ * occupies the same bytes as fp32, but every group of 32 channels is stored as 32 fp16 `hi` values followed by
+ * 32 fp16 `lo` values with 16*x = hi + lo (round to nearest twice): element (r, c) -> byte r*ld*4 + (c/32)*128 +
+ * plane*64 + (c%32)*2.  Producers that feed ONLY GEMMs write it (out_f16x2 here, the split flags of
+ * knnsvc_layernorm / knnsvc_wavlm_conv0 / knnsvc_wavlm_attention), consumers set x_f16x2: the GEMM then stages A with
+ * plain copies instead of splitting it once per column tile. */
+
 /* ------------------------------------------------------------------------------------------
  * Row-wise layer norm over the last dim (eps 1e-5, affine), optional exact-erf GELU after it.
  * Replaces F.layer_norm at wavlm/WavLM.py:342, 415 (+nn.GELU :418), 692, 706.  In place allowed.
  * ------------------------------------------------------------------------------------------ */
+/* flags: bit 0 = GELU after the norm, bit 1 = write the f16x2 split layout (dim % 32 == 0, ldo % 32 == 0). */
 int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32_t ldx, const float* gamma,
-                     const float* beta, int32_t gelu, float* out, int32_t ldo, void* stream);
+                     const float* beta, int32_t flags, float* out, int32_t ldo, void* stream);
 
 /* Layer 0 of the conv feature extractor fused: Conv1d(1->C, k, stride, no bias) -> LayerNorm(C) -> GELU
  * (wavlm/WavLM.py:401-419 with in_d = 1).  x [batches, L] -> out [batches * T, C], T = (L-k)/stride + 1,
  * w [C, k].  C in {64,128,256,512}, k <= 16, stride <= 8. */
 int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, const float* w, int32_t channels, int32_t k,
-                       int32_t stride, const float* gamma, const float* beta, float* out, void* stream);
+                       int32_t stride, const float* gamma, const float* beta, float* out, int32_t out_f16x2,
+                       void* stream);
 
 /* Gated relative-position multiplier, wavlm/modules.py:523-533:
  *   gate[row, h] = ga*(gb*grep_a[h] - 1) + 2, (ga, gb) = sigmoid(W2 @ xn[row, h*hd:(h+1)*hd] + b2)
  * where W2 [2, hd] / b2 [2] are grep_linear's weight rows / bias summed in groups of four. */
 int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head_dim, int32_t ldx,
-                      const float* w2, const float* b2, const float* grep_a, float* gate, void* stream);
+                      const float* w2, const float* b2, const float* grep_a, float* gate, int32_t x_f16x2,
+                      void* stream);
 
 /* Fused bidirectional self-attention with the gated bucketed relative-position bias
  * (wavlm/modules.py:504-506, 533-563 -> F.multi_head_attention_forward, need_weights=False):
@@ -115,7 +127,7 @@ int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head
  * (bucket LUT already applied), gate [batches*T, heads], out [batches*T, E].  head_dim must be 64.
  * Nothing of size T x T is ever written to HBM. */
 int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
-                           int32_t T, int32_t heads, float* out, void* stream);
+                           int32_t T, int32_t heads, float* out, int32_t out_f16x2, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cosine-distance kNN (lib_ongaku_test.py:148-175 fast_cosine_dist + Tensor.topk(k, largest=False),

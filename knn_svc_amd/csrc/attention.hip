@@ -387,7 +387,7 @@ constexpr int VP2 = 264;
 
 __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
                                                            const float* __restrict__ table, int T, int heads,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int out_split) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef __attribute__((address_space(3))) char lc;
     typedef __attribute__((address_space(3))) au32x4 l_u4;
@@ -556,7 +556,15 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 f32x4 v = {o[d][r4 * 4 + 0] * inv, o[d][r4 * 4 + 1] * inv, o[d][r4 * 4 + 2] * inv, o[d][r4 * 4 + 3] * inv};
-                *(f32x4*)(op + d * 32 + r4 * 8 + lh * 4) = v;
+                if (out_split) {          // f16x2 split layout for the output projection (4 consecutive channels of the row)
+                    g2_u32x2 hi, lo;
+                    f16x2_split4(v, KN_F16X2_A_SCALE, hi, lo);
+                    const int c = head * HD + d * 32 + r4 * 8 + lh * 4;
+                    char* ob = (char*)(out + ((long)b * T + qi) * E) + (c >> 5) * 128 + (c & 31) * 2;
+                    *(g2_u32x2*)ob = hi;
+                    *(g2_u32x2*)(ob + 64) = lo;
+                } else
+                    *(f32x4*)(op + d * 32 + r4 * 8 + lh * 4) = v;
             }
     }
 }
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
 }  // namespace
 
 extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
-                                      int32_t T, int32_t heads, float* out, void* stream) {
+                                      int32_t T, int32_t heads, float* out, int32_t out_f16x2, void* stream) {
     KN_REQUIRE(qkv && gate && table && out, "wavlm_attention: null pointer");
     KN_REQUIRE(batches > 0 && T > 0 && heads > 0 && heads <= 65535 && batches <= 65535, "wavlm_attention: bad sizes");
     KN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "wavlm_attention: 16-byte alignment");
@@ -583,9 +591,10 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
             attr2 = l2;
         }
         dim3 grid2((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batches);
-        hipLaunchKernelGGL(attention2_kernel, grid2, dim3(256), l2, (hipStream_t)stream, qkv, gate, table, T, heads, out);
+        hipLaunchKernelGGL(attention2_kernel, grid2, dim3(256), l2, (hipStream_t)stream, qkv, gate, table, T, heads, out, out_f16x2);
         return knnsvc_check_launch("wavlm_attention2");
     }
+    KN_REQUIRE(!out_f16x2, "wavlm_attention: split output is only implemented by the f16x2 kernel");
     if (mode == 3) {
         const size_t l3 = (size_t)KT * KP3 + (size_t)HD * VP3 + (size_t)(2 * T - 1 + 64) * 4;
         KN_REQUIRE(l3 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~13000)");

@@ -20,6 +20,8 @@ struct ConvArgs {
     int K;
     const unsigned short* w3;   // weights pre-split into 3 bf16 planes ([n][K/32][3][32]) or null
     const unsigned short* w2;   // weights pre-split into 2 fp16 planes ([n][K/32][2][32], scaled) or null
+    int x_split;                // A operand already in the f16x2 split layout (same pitch in bytes)
+    int out_split;              // epilogue writes the f16x2 split layout (scale 16) instead of fp32
     float out_scale;            // accumulator -> output factor (1 except on the f16x2 path)
     float a_scale;              // f16x2 path: power-of-two factor applied to activations before the split
 };
@@ -244,6 +246,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G
                 if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
                 else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
+                if (a.out_split) {
+                    // f16x2 split layout for the next GEMM's A operand: element (row, c) -> hi at (c/32)*128 + (c%32)*2,
+                    // lo 64 bytes further.  Lanes n and n^1 hold neighbouring columns of the same row: the even lane
+                    // stores both hi halves, the odd lane both lo halves — one 4-byte store per lane, as in fp32 mode.
+                    const float xs = v * KN_F16X2_A_SCALE;
+                    const _Float16 h = (_Float16)xs;
+                    const _Float16 l = (_Float16)(xs - (float)h);
+                    const unsigned hl = (unsigned)__builtin_bit_cast(unsigned short, h) |
+                                        ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                    const unsigned pr = (unsigned)__builtin_amdgcn_mov_dpp((int)hl, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                    const bool odd = (lane & 1) != 0;
+                    const unsigned ow = odd ? ((pr >> 16) | (hl & 0xFFFF0000u)) : ((hl & 0xFFFFu) | (pr << 16));
+                    const int ce = col & ~1;
+                    char* ob = (char*)oz + orow * (long)a.ldo * 4 + (ce >> 5) * 128 + (ce & 31) * 2 + (odd ? 64 : 0);
+                    *(unsigned*)ob = ow;
+                    continue;
+                }
                 if (rz) v += rz[orow * a.ldr + col];
                 float* op = oz + orow * a.ldo + col;
                 if (a.accumulate) v += *op;
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm3_kernel(ConvArgs a) {
     conv_epilogue<G>(a, acc, m0, n0, b, g);
 }
 
-template <class G>
+template <class G, bool A2>
 __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int z = blockIdx.z;
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     FastALoader<G::A_F4> al(a, m0, threadIdx.x);
     Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
-    G::mainloop(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale);
+    G::template mainloop<A2>(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale);
     conv_epilogue<G>(a, acc, m0, n0, b, g);
 }
 
@@ -388,19 +407,23 @@ int launch2big(const ConvArgs& a, int batches, hipStream_t st) {
     return knnsvc_check_launch("conv_gemm2big");
 }
 
-template <class G>
-int launch2(const ConvArgs& a, int batches, hipStream_t st) {
+template <class G, bool A2>
+int launch2v(const ConvArgs& a, int batches, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_gemm2_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_gemm2_kernel<G, A2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G::LDS_BYTES) != hipSuccess)
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
     const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;          // row tiles padded to whole groups of 8 (one per XCD)
     dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_gemm2_kernel<G, A2>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2");
+}
+template <class G>
+int launch2(const ConvArgs& a, int batches, hipStream_t st) {
+    return a.x_split ? launch2v<G, true>(a, batches, st) : launch2v<G, false>(a, batches, st);
 }
 
 // one thread per 4 consecutive k of one weight row: scale * fp32 -> (hi, lo) fp16 planes, round to nearest
@@ -524,6 +547,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.w3 = (const unsigned short*)d->w_bf16x3;
     a.w2 = (const unsigned short*)d->w_f16x2;
     a.out_scale = 1.0f; a.a_scale = 1.0f;
+    a.x_split = d->x_f16x2; a.out_split = d->out_f16x2;
 
     // 16-byte vector path needs every float4 of A and W to be aligned and inside one tap
     const bool vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
@@ -535,6 +559,12 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     // buffer-load fast path: every slab inside one tap, resources below 1 GiB
     const bool fast = vec4 && (d->cin % 32 == 0) && ((long)d->t_in * d->ldx * 4 < (1L << 30)) &&
                       ((long)d->n * a.K * 4 < (1L << 30)) && ((long)d->m * d->stride * d->ldx * 4 < (1L << 30));
+    if (a.out_split)
+        KN_REQUIRE(!d->resid && !d->accumulate && a.div == 1.0f && !d->convt_u && d->n % 32 == 0 && d->ldo % 32 == 0 &&
+                   ((uintptr_t)d->out & 15) == 0, "conv_gemm: out_f16x2 needs a plain [m, n % 32 == 0] output (no resid/accumulate/div/convt)");
+    if (a.x_split)
+        KN_REQUIRE(fast && a.w2 && d->a_slope == 1.0f && (d->a_f16x2_scale == 0.f || d->a_f16x2_scale == KN_F16X2_A_SCALE),
+                   "conv_gemm: x_f16x2 needs the f16x2 fast path (cin % 32 == 0, split weights), a_slope 1 and the default scale");
     if (fast && a.w2) {        // fp32 emulated on the fp16 matrix cores (gemm2_core.h)
         KN_REQUIRE(d->w_f16x2_scale > 0.f, "conv_gemm: w_f16x2 without its scale");
         a.a_scale = d->a_f16x2_scale > 0.f ? d->a_f16x2_scale : KN_F16X2_A_SCALE;

@@ -1,8 +1,30 @@
 // Small HBM-bound kernels: layer norm (+GELU), gated rel-pos multiplier, weighted neighbour
 // gather, reflect padding, complex magnitude, harmonic-amplitude extraction.
 #include "common.h"
+#include "gemm2_core.h"      // f16x2_split4: the split ("A2") activation layout of the emulated-fp32 GEMMs
 
 namespace {
+
+// 4 consecutive channels c..c+3 (c % 4 == 0) of a row in the f16x2 split layout: hi plane at (c/32)*128 + (c%32)*2, lo 64 B on
+__device__ __forceinline__ void store_split4(float* row, int c, f32x4 y) {
+    g2_u32x2 hi, lo;
+    f16x2_split4(y, KN_F16X2_A_SCALE, hi, lo);
+    char* ob = (char*)row + (c >> 5) * 128 + (c & 31) * 2;
+    *(g2_u32x2*)ob = hi;
+    *(g2_u32x2*)(ob + 64) = lo;
+}
+// 4 consecutive channels back to fp32 (exact: hi + lo spans < 24 bits)
+__device__ __forceinline__ f32x4 load_split4(const float* row, int c) {
+    const char* ib = (const char*)row + (c >> 5) * 128 + (c & 31) * 2;
+    const g2_u32x2 hi = *(const g2_u32x2*)ib, lo = *(const g2_u32x2*)(ib + 64);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned short hb = (unsigned short)(hi[e >> 1] >> (16 * (e & 1))), lb = (unsigned short)(lo[e >> 1] >> (16 * (e & 1)));
+        y[e] = ((float)__builtin_bit_cast(_Float16, hb) + (float)__builtin_bit_cast(_Float16, lb)) * (1.0f / KN_F16X2_A_SCALE);
+    }
+    return y;
+}
 
 __device__ __forceinline__ float gelu_erf(float v) {
 #pragma clang fp contract(off)
@@ -64,9 +86,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = fmaf((v[r][i][e] - mean[r]) * rstd, g[e], b[e]);
-                    y[e] = gelu ? gelu_erf(t) : t;
+                    y[e] = (gelu & 1) ? gelu_erf(t) : t;
                 }
-                *(f32x4*)(orow + c) = y;
+                if (gelu & 2) store_split4(orow, c, y);      // flags bit 1: f16x2 split layout for a GEMM consumer
+                else *(f32x4*)(orow + c) = y;
             }
         }
     }
@@ -80,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int CPL, int KMAXT>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ x, long L, long T, int k, int stride,
                                                            const float* __restrict__ w, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ out) {
+                                                           const float* __restrict__ beta, float* __restrict__ out, int split) {
     __shared__ float xs[64 * 8 + 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = CPL * 64;
@@ -125,8 +148,14 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
 #pragma unroll
         for (int c = 0; c < CPL; ++c) y[c] = gelu_erf((y[c] - mean) * rstd * g[c] + be[c]);
         if (CPL % 4 == 0) {
+            if (split) {
+                float* orow = out + (b * T + m) * C;
 #pragma unroll
-            for (int c = 0; c < CPL; c += 4) *(f32x4*)(o + c) = (f32x4){y[c], y[c + 1], y[c + 2], y[c + 3]};
+                for (int c = 0; c < CPL; c += 4) store_split4(orow, lane * CPL + c, (f32x4){y[c], y[c + 1], y[c + 2], y[c + 3]});
+            } else {
+#pragma unroll
+                for (int c = 0; c < CPL; c += 4) *(f32x4*)(o + c) = (f32x4){y[c], y[c + 1], y[c + 2], y[c + 3]};
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < CPL; ++c) o[c] = y[c];
@@ -137,7 +166,7 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
 // one wave per row; lane l covers channels 16l..16l+15 (a quarter of a 64-wide head)
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ xn, long rows, int heads, int ldx,
                                                   const float* __restrict__ w2, const float* __restrict__ b2,
-                                                  const float* __restrict__ grep_a, float* __restrict__ gate) {
+                                                  const float* __restrict__ grep_a, float* __restrict__ gate, int split) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ xn,
         const float* xr = xn + row * (long)ldx + lane * 16;
 #pragma unroll
         for (int e = 0; e < 16; e += 4) {
-            const f32x4 xv = *(const f32x4*)(xr + e);
+            const f32x4 xv = split ? load_split4(xn + row * (long)ldx, lane * 16 + e) : *(const f32x4*)(xr + e);
             const f32x4 wa = *(const f32x4*)(w2 + part * 16 + e), wb = *(const f32x4*)(w2 + 64 + part * 16 + e);
 #pragma unroll
             for (int t = 0; t < 4; ++t) { sa += xv[t] * wa[t]; sb += xv[t] * wb[t]; }
@@ -233,6 +262,7 @@ extern "C" int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32
     KN_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
     KN_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 2048, "layernorm: dim must be a multiple of 4 and <= 2048");
     KN_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= dim && ldo >= dim, "layernorm: bad row strides");
+    KN_REQUIRE(!(gelu & 2) || (dim % 32 == 0 && ldo % 32 == 0), "layernorm: split output needs dim % 32 == 0 and ldo % 32 == 0");
     KN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
                ((uintptr_t)beta & 15) == 0, "layernorm: pointers must be 16-byte aligned");
     if (rows <= 0) return KNNSVC_OK;
@@ -250,14 +280,14 @@ extern "C" int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32
 }
 
 extern "C" int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head_dim, int32_t ldx,
-                                 const float* w2, const float* b2, const float* grep_a, float* gate, void* stream) {
+                                 const float* w2, const float* b2, const float* grep_a, float* gate, int32_t x_f16x2, void* stream) {
     KN_REQUIRE(xn && w2 && b2 && grep_a && gate, "wavlm_gate: null pointer");
     KN_REQUIRE(head_dim == 64 && heads >= 1 && heads <= 16, "wavlm_gate: head_dim must be 64, heads <= 16");
     KN_REQUIRE(ldx % 4 == 0 && ldx >= heads * 64 && ((uintptr_t)xn & 15) == 0 && ((uintptr_t)w2 & 15) == 0,
                "wavlm_gate: alignment");
     if (rows <= 0) return KNNSVC_OK;
     hipLaunchKernelGGL(gate_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       xn, (long)rows, heads, ldx, w2, b2, grep_a, gate);
+                       xn, (long)rows, heads, ldx, w2, b2, grep_a, gate, x_f16x2);
     return knnsvc_check_launch("wavlm_gate");
 }
 
@@ -298,15 +328,16 @@ extern "C" int knnsvc_harmonic_amps(const float* spec, const float* f0, int64_t 
 }
 
 extern "C" int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, const float* w, int32_t channels, int32_t k,
-                                  int32_t stride, const float* gamma, const float* beta, float* out, void* stream) {
+                                  int32_t stride, const float* gamma, const float* beta, float* out, int32_t out_f16x2, void* stream) {
     KN_REQUIRE(x && w && gamma && beta && out, "wavlm_conv0: null pointer");
     KN_REQUIRE(batches > 0 && batches <= 65535 && L >= k && k >= 1 && k <= 16 && stride >= 1 && stride <= 8,
                "wavlm_conv0: needs 1 <= k <= 16, 1 <= stride <= 8");
     KN_REQUIRE(channels == 64 || channels == 128 || channels == 256 || channels == 512, "wavlm_conv0: channels must be 64/128/256/512");
+    KN_REQUIRE(!out_f16x2 || channels >= 256, "wavlm_conv0: split output needs >= 256 channels");
     const long T = (L - k) / stride + 1;
     dim3 grid((unsigned)cdiv64(T, 64), (unsigned)batches);
     hipStream_t st = (hipStream_t)stream;
-#define KN_C0(CPL, KM) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, KM>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out)
+#define KN_C0(CPL, KM) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, KM>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out, out_f16x2)
     if (k <= 10) {        // WavLM's k = 10: no padded taps in the unrolled FIR
         if (channels == 512) KN_C0(8, 10); else if (channels == 256) KN_C0(4, 10); else if (channels == 128) KN_C0(2, 10); else KN_C0(1, 10);
     } else {

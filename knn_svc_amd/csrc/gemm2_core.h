@@ -63,14 +63,17 @@ struct Gemm2Tile {
 
     // aload: fp32 A loader (begin(kt), operator()(kt, j) -> f32x4 for row (tid>>3)+32j, k = (tid&7)*4, finish())
     // bload: split-weight loader (begin(kt), operator()(kt, j) -> 16-byte piece j of this thread)
-    template <class ALoad, class BLoad, class RA, class RB>
+    // A2 = true: the activations already are in the split layout ([rows][C/32][2][32] fp16, the same bytes per element
+    // as fp32, written by the producing kernel with the default activation scale): the 16 bytes a thread loads are
+    // one finished piece of its row's LDS image and staging is a plain copy.
+    template <bool A2 = false, class ALoad, class BLoad, class RA, class RB>
     __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, BLoad& bload,
                                                     f32x16 (&acc)[TM][TN], RA ra_desc, RB rb_desc, float a_scale) {
         lds_c* lds = (lds_c*)lds_generic;
         typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int wm = wave / WN, wn = wave % WN;
-        const int a_st = (tid >> 3) * PITCH + (tid & 7) * 8;               // staging address of float4 j = 0
+        const int a_st = (tid >> 3) * PITCH + (tid & 7) * (A2 ? 16 : 8);   // staging address of piece j = 0
         const int li = lane & 31, lh = lane >> 5;
         const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
         const int b_frag = BM * PITCH + (wn * TN * 32 + li) * PITCH + lh * 16;
@@ -81,8 +84,10 @@ struct Gemm2Tile {
 #define KN_STAGE2_A() _Pragma("unroll") for (int j = 0; j < A_F4; ++j) asm volatile("" ::"v"(ra[j][0]), "v"(ra[j][1]), "v"(ra[j][2]), "v"(ra[j][3]));
 #else
 #define KN_STAGE2_A()                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < A_F4; ++j)                                                     \
-            split_store(lds + a_st + 32 * j * PITCH, aload.finish(ra[j]), a_scale);
+        _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                   \
+            if constexpr (A2) *(lds_u4*)(lds + a_st + 32 * j * PITCH) = __builtin_bit_cast(g2_u32x4, ra[j]); \
+            else split_store(lds + a_st + 32 * j * PITCH, aload.finish(ra[j]), a_scale);                     \
+        }
 #endif
 #ifdef KN_T_NOSTAGE_B
 #define KN_STAGE2_B() _Pragma("unroll") for (int j = 0; j < B_P; ++j) asm volatile("" ::"v"(rb[j][0]), "v"(rb[j][1]), "v"(rb[j][2]), "v"(rb[j][3]));
@@ -107,10 +112,14 @@ struct Gemm2Tile {
             const bool more = (kt + 1 < nk);
             if (more) {
                 aload.begin(kt + 1); bload.begin(kt + 1);
+#ifndef KN_T_NOLOAD_A
 #pragma unroll
                 for (int j = 0; j < A_F4; ++j) ra[j] = aload(kt + 1, j, ra_desc);
+#endif
+#ifndef KN_T_NOLOAD_B
 #pragma unroll
                 for (int j = 0; j < B_P; ++j) rb[j] = bload(kt + 1, j, rb_desc);
+#endif
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {

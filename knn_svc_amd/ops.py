@@ -121,7 +121,7 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               bias=None, bias_period=0, act=ACT_NONE, act_slope=0.0, a_slope=1.0, resid=None, ldr=None,
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
-              convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0):
+              convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False):
     """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr)."""
     lib = _lib.load()
     d = ConvDesc()
@@ -145,54 +145,75 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.w_f16x2 = w2.data_ptr() if w2 is not None else None
     d.w_f16x2_scale = w._w2_scale if w2 is not None else 0.0
     d.a_f16x2_scale = a_scale
+    d.x_f16x2 = 1 if x_split else 0; d.out_f16x2 = 1 if out_split else 0
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
     return out
 
 
-def linear(x2d, w, bias=None, act=ACT_NONE, resid=None, out=None):
-    """out[M,N] = act(x2d[M,K] @ w[N,K]^T + bias) (+ resid)."""
+def linear(x2d, w, bias=None, act=ACT_NONE, resid=None, out=None, x_split=False, out_split=False):
+    """out[M,N] = act(x2d[M,K] @ w[N,K]^T + bias) (+ resid).  x_split / out_split: operand / result in the f16x2
+    split layout (include/knnsvc_hip.h, "A2"), carried in float32 tensors of the usual shape."""
     _need(x2d, name="linear.x"); _need(w, name="linear.w")
     M, K = x2d.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
-    return conv_gemm(x2d, w, out, m=M, n=N, cin=K, bias=bias, act=act, resid=resid)
+    return conv_gemm(x2d, w, out, m=M, n=N, cin=K, bias=bias, act=act, resid=resid, x_split=x_split, out_split=out_split)
+
+
+def split_pack(x2d: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, C] (C % 32 == 0) -> the f16x2 split layout in a float32 tensor of the same shape (torch ops;
+    for tests and debugging — the kernels write this layout themselves)."""
+    rows, C = x2d.shape
+    xs = x2d.float() * 16.0
+    hi = xs.half()
+    lo = (xs - hi.float()).half()
+    packed = torch.stack([hi.view(rows, C // 32, 32), lo.view(rows, C // 32, 32)], 2).contiguous()   # [rows, C/32, 2, 32]
+    return packed.view(torch.float32).view(rows, C)
+
+
+def split_unpack(t2d: torch.Tensor) -> torch.Tensor:
+    """inverse of split_pack (up to the 2^-22 relative split error)."""
+    rows, C = t2d.shape
+    h = t2d.contiguous().view(torch.float16).view(rows, C // 32, 2, 32)
+    return ((h[:, :, 0].float() + h[:, :, 1].float()) / 16.0).reshape(rows, C)
 
 
 # ------------------------------------------------------------------ WavLM pieces
-def layernorm(x2d, gamma, beta, gelu=False, out=None):
+def layernorm(x2d, gamma, beta, gelu=False, out=None, out_split=False):
+    """out_split: write the f16x2 split layout (the result then only makes sense as a GEMM's x_split operand)."""
     _need(x2d, name="layernorm.x")
     rows, dim = x2d.shape
     if out is None:
         out = torch.empty_like(x2d)
-    check(_lib.load().knnsvc_layernorm(_p(x2d), rows, dim, x2d.stride(0), _p(gamma), _p(beta), 1 if gelu else 0,
+    check(_lib.load().knnsvc_layernorm(_p(x2d), rows, dim, x2d.stride(0), _p(gamma), _p(beta), (1 if gelu else 0) | (2 if out_split else 0),
                                        _p(out), out.stride(0), _stream()), "layernorm")
     return out
 
 
-def wavlm_conv0(x, w, gamma, beta, k, stride):
+def wavlm_conv0(x, w, gamma, beta, k, stride, out_split=False):
     """[B, L] waveform -> [B*T, C] = GELU(LN(conv1d(x))) of the first feature-extractor layer, one kernel."""
     B, L = x.shape
     C_ = gamma.numel()
     T = (L - k) // stride + 1
     out = torch.empty(B * T, C_, device=x.device, dtype=torch.float32)
-    check(_lib.load().knnsvc_wavlm_conv0(_p(x), B, L, _p(w), C_, k, stride, _p(gamma), _p(beta), _p(out), _stream()),
-          "wavlm_conv0")
+    check(_lib.load().knnsvc_wavlm_conv0(_p(x), B, L, _p(w), C_, k, stride, _p(gamma), _p(beta), _p(out),
+                                         1 if out_split else 0, _stream()), "wavlm_conv0")
     return out
 
 
-def wavlm_gate(xn2d, heads, w2, b2, grep_a):
+def wavlm_gate(xn2d, heads, w2, b2, grep_a, x_split=False):
     rows = xn2d.shape[0]
     gate = torch.empty(rows, heads, device=xn2d.device, dtype=torch.float32)
     check(_lib.load().knnsvc_wavlm_gate(_p(xn2d), rows, heads, 64, xn2d.stride(0), _p(w2), _p(b2), _p(grep_a),
-                                        _p(gate), _stream()), "wavlm_gate")
+                                        _p(gate), 1 if x_split else 0, _stream()), "wavlm_gate")
     return gate
 
 
-def wavlm_attention(qkv, gate, table, batches, T, heads):
+def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False):
     out = torch.empty(batches * T, heads * 64, device=qkv.device, dtype=torch.float32)
-    check(_lib.load().knnsvc_wavlm_attention(_p(qkv), _p(gate), _p(table), batches, T, heads, _p(out), _stream()),
-          "wavlm_attention")
+    check(_lib.load().knnsvc_wavlm_attention(_p(qkv), _p(gate), _p(table), batches, T, heads, _p(out),
+                                             1 if out_split else 0, _stream()), "wavlm_attention")
     return out
 
 

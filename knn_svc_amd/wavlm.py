@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 
 from . import config as C
@@ -147,20 +149,30 @@ class WavLMEncoder:
         dev = wav.device
         x = wav.contiguous()
         t_in, cin = L, 1
+        # Activations that only feed GEMMs travel in the f16x2 split layout ("A2", include/knnsvc_hip.h): the
+        # producer (LayerNorm, the fused first conv, the GELU epilogue of FFN1, attention) splits every element once
+        # and the GEMM stages its A operand with plain copies instead of re-splitting it in every column tile.
+        a2 = ops.gemm_mode() == "f16x2" and os.environ.get("KNNSVC_A2", "1") != "0"
+        sp = lambda dim: a2 and dim % 32 == 0           # a [*, dim] activation can be carried split
+        x_sp = False                                    # is x currently in the split layout?
         for li, c in enumerate(self.conv):
             t_out = (t_in - c["k"]) // c["s"] + 1
             if li == 0 and cin == 1 and c["dim"] in (64, 128, 256, 512) and c["k"] <= 16 and c["s"] <= 8:
-                x = ops.wavlm_conv0(x, c["w"], c["g"], c["b"], c["k"], c["s"])       # conv + LN + GELU in one pass
+                x_sp = sp(c["dim"]) and c["dim"] >= 256 and len(self.conv) > 1
+                x = ops.wavlm_conv0(x, c["w"], c["g"], c["b"], c["k"], c["s"], out_split=x_sp)   # conv + LN + GELU in one pass
                 t_in, cin = t_out, c["dim"]
                 continue
             y = torch.empty(B * t_out, c["dim"], device=dev, dtype=torch.float32)
             ops.conv_gemm(x, c["w"], y, m=t_out, n=c["dim"], cin=cin, taps=c["k"], stride=c["s"], t_in=t_in,
-                          batches=B, x_bstride=t_in * cin, o_bstride=t_out * c["dim"])
-            ops.layernorm(y, c["g"], c["b"], gelu=True, out=y)
+                          batches=B, x_bstride=t_in * cin, o_bstride=t_out * c["dim"], x_split=x_sp)
+            x_sp = sp(c["dim"]) and li + 1 < len(self.conv)         # the last layer's output feeds a LayerNorm, not a GEMM
+            ops.layernorm(y, c["g"], c["b"], gelu=True, out=y, out_split=x_sp)
             x, t_in, cin = y, t_out, c["dim"]
         T = t_in
-        feats = ops.layernorm(x, self.ln_g, self.ln_b)
-        x = ops.linear(feats, self.proj_w, self.proj_b)                       # [B*T, E]
+        assert not x_sp
+        f_sp = sp(cin)
+        feats = ops.layernorm(x, self.ln_g, self.ln_b, out_split=f_sp)
+        x = ops.linear(feats, self.proj_w, self.proj_b, x_split=f_sp)             # [B*T, E]
         E, H, G, K = self.E, self.H, self.G, self.Kpos
         cg = E // G
         x2 = torch.empty_like(x)
@@ -170,15 +182,16 @@ class WavLMEncoder:
                       o_bstride=T * E, o_gstride=cg, r_bstride=T * E, r_gstride=cg)
         x = x2
         table = self._table(T)
+        e_sp, h_sp = sp(E), sp(self.layers[0]["w1"].shape[0]) if self.layers else False
         for ly in self.layers:
-            xn = ops.layernorm(x, ly["ln1_g"], ly["ln1_b"])
-            gate = ops.wavlm_gate(xn, H, ly["gate_w"], ly["gate_b"], ly["grep_a"])
-            qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"])
-            att = ops.wavlm_attention(qkv, gate, table, B, T, H)
-            x = ops.linear(att, ly["wo"], ly["bo"], resid=x)
-            xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"])
-            hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU)
-            x = ops.linear(hmid, ly["w2"], ly["b2"], resid=x)
+            xn = ops.layernorm(x, ly["ln1_g"], ly["ln1_b"], out_split=e_sp)
+            gate = ops.wavlm_gate(xn, H, ly["gate_w"], ly["gate_b"], ly["grep_a"], x_split=e_sp)
+            qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"], x_split=e_sp)
+            att = ops.wavlm_attention(qkv, gate, table, B, T, H, out_split=e_sp)
+            x = ops.linear(att, ly["wo"], ly["bo"], resid=x, x_split=e_sp)
+            xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"], out_split=e_sp)
+            hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU, x_split=e_sp, out_split=h_sp)
+            x = ops.linear(hmid, ly["w2"], ly["b2"], resid=x, x_split=h_sp)
         return x.view(B, T, E)
 
     def full_features(self, wav_1d: torch.Tensor, max_batch: int = 8) -> torch.Tensor:

@@ -57,6 +57,30 @@ def test_linear_emulated_fp32(M, K, N, mode, attr, monkeypatch):
     assert e3 <= 2.0 * e32 + 1e-6 and e3 < 1e-5 * float(ref.abs().max())
 
 
+def test_linear_split_layout_in_and_out():
+    """A2: a GEMM fed with pre-split activations gives bit-identical results to splitting them in the kernel, and a
+    GEMM writing the split layout round-trips to its fp32 output within the split error (2^-22 relative)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    M, K, N = 700, 1024, 384
+    x = (torch.randn(M, K, generator=g) * 2).to(DEV); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    wd = ops.attach_split(w)
+    if not hasattr(wd, "_w2"):
+        pytest.skip("KNNSVC_GEMM is not f16x2")
+    ref = ops.linear(x, wd, b, act=ops.ACT_GELU)
+    got = ops.linear(ops.split_pack(x), wd, b, act=ops.ACT_GELU, x_split=True)
+    assert torch.equal(ref, got)
+    packed = ops.linear(x, wd, b, act=ops.ACT_GELU, out_split=True)
+    back = ops.split_unpack(packed)
+    assert float((back - ref).abs().max()) <= 4e-7 * float(ref.abs().max())
+    # same round-to-nearest split as the packer (compared as values: the sign of a zero half may differ)
+    assert torch.equal(packed.view(torch.float16).float(), ops.split_pack(ref).view(torch.float16).float())
+    from knn_svc_amd._lib import KnnSvcError
+    with pytest.raises(KnnSvcError):
+        ops.linear(x, wd, b, resid=ref, out_split=True)
+
+
 def test_linear_f16x2_big_tile(monkeypatch):
     """The opt-in 256x256 double-buffered tile with LDS-DMA weights (conv_gemm2big_kernel, KNNSVC_F256_KMIN): ragged
     last row tile, bias + GELU epilogue, rows sampled from the first, a middle and the last tile against fp64; the
