@@ -361,6 +361,62 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     conv_epilogue<G>(a, acc, m0, n0, b, g);
 }
 
+// A2 activations + split weights, both by LDS-DMA (gemm2_core.h, Gemm2Dma)
+template <class G>
+__global__ __launch_bounds__(256, 2) void conv_gemm2dma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
+    const int gx8 = (int)gridDim.x / gy;
+    constexpr int CW = 8;
+    int L = blockIdx.x;
+    const int full = (gy / CW) * CW * gx8;
+    int c0, cw;
+    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
+    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
+    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
+    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
+    if (m0 >= a.m) return;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
+    auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
+    // wave-uniform walk over (tap, channel): 128 bytes per slab inside a tap, then on to the next tap's first channel
+    int c_in_tap = 0, uoff = 0;
+    const int cin = a.cin, step_tap = (a.dil * a.ldx - a.cin) * 4;
+    auto step = [&](int kt) -> int {
+        if (kt > 0) { c_in_tap += 32; uoff += 128; if (c_in_tap == cin) { c_in_tap = 0; uoff += step_tap; } }
+        return uoff;
+    };
+    G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
+                a.n, a.K, m0, n0, acc);
+    conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G>
+int launch2dma(const ConvArgs& a, int batches, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm2dma_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
+    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2dma_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm2dma");
+}
+
 template <class G>
 __global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -490,6 +546,7 @@ using F128 = Gemm2Tile<128, 128, 2, 2, 2, 2>;
 using F64 = Gemm2Tile<256, 64, 4, 1, 2, 2>;
 using F32 = Gemm2Tile<256, 32, 4, 1, 2, 1>;
 using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
+using D128 = Gemm2Dma<128, 128, 2, 2, 2, 2>;
 
 template <class G>
 int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
@@ -578,6 +635,13 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             const char* e = getenv("KNNSVC_F256_KMIN");
             if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
                 return launch2big<F256>(a, d->batches, st);
+        }
+        if (d->n > 64 && a.x_split) {
+            // Opt-in (KNNSVC_DMA=1): both operands by LDS-DMA, double-buffered, 2 blocks/CU.  Measured 252 vs 275 TFLOP/s
+            // for the register-staged A2 kernel on FFN1: with one slab of prefetch the vmcnt(0) + barrier at the end
+            // of every slab exposes the DMA latency; it needs a 3-stage ring (1 block/CU) to pay.
+            const char* e = getenv("KNNSVC_DMA");
+            if (e && e[0] == '1') return launch2dma<D128>(a, d->batches, st);
         }
         if (d->n > 64) return launch2<F128>(a, d->batches, st);
         if (d->n > 32) return launch2<F64>(a, d->batches, st);

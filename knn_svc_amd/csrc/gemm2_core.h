@@ -334,3 +334,142 @@ struct Gemm2Big {
         return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
     }
 };
+
+// -------------------------------------------------------------------------------------------------
+// DMA-fed variant for pre-split activations ("A2" layout): BOTH operands go global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds) into unpadded, XOR-swizzled 128-byte rows; no staging registers, no VALU
+// split, no ds_write.  4 waves, double-buffered LDS (2 x 32 KB at 128x128: two blocks per CU), one barrier
+// per K slab: the DMA of slab kt+1 is issued piece by piece behind the MFMA groups of slab kt and
+// `s_waitcnt vmcnt(0)` + the barrier at the end of the slab publish it.  What-if builds put the operand
+// delivery of the register-staged kernel at 34 % of its time (19 % A, 10 % B); this removes the VALU,
+// LDS-store and register-wait parts of it.
+//   image: row r = 128 bytes = 8 pieces of 16 B (hi plane pieces 0-3, lo plane 4-7); piece q sits in slot
+//   q ^ ((r >> 1) & 7).  DMA instruction c of a slab fills rows 8c..8c+7 (lane L -> row 8c + L/8, slot L%8)
+//   and applies the swizzle through its per-lane SOURCE offset.
+// The A side takes the implicit-GEMM view of the conv kernel: per-lane row offsets + a wave-uniform
+// (tap, channel) offset advanced slab by slab; rows in the conv padding or past M fall outside the buffer
+// resource and land as zeros.
+// -------------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
+struct Gemm2Dma {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int BK = 32, BROW = 128, NW = WM * WN, THREADS = 64 * NW;
+    static_assert(NW == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    static_assert(TM % 2 == 0, "row tiles alternate between two fragment slots");
+    static constexpr int A_DMA = BM * BROW / 1024 / NW;        // LDS-DMA instructions per wave per slab (A, B)
+    static constexpr int B_DMA = BN * BROW / 1024 / NW;
+    static_assert(A_DMA * 1024 * NW == BM * BROW && B_DMA * 1024 * NW == BN * BROW, "whole DMA pieces");
+    static constexpr int BOFF = BM * BROW;
+    static constexpr int BUF = (BM + BN) * BROW;
+    static constexpr int LDS_BYTES = 2 * BUF;
+    static constexpr int OOB_OFF = 0x40000000;
+
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) void lds_v;
+    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
+
+    // a_row_off(m): byte offset of row m's first channel in the A buffer resource, or OOB_OFF (evaluated per lane once);
+    // a_step(kt): wave-uniform byte offset of slab kt (tap / channel walk)
+    template <class RowOff, class Step, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
+                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 31, lh = lane >> 5;
+        const int swz = (li >> 1) & 7;
+        const int a_row = (wm * TM * 32 + li) * BROW;
+        const int b_row = BOFF + (wn * TN * 32 + li) * BROW;
+        int x_off[2][2];                                           // [k-step][plane]: swizzled slot of this lane's piece
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) x_off[ks][p] = ((p * 4 + ks * 2 + lh) ^ swz) * 16;
+        int a_src[A_DMA], b_src[B_DMA];
+        const int row_bytes = (K / 32) * 128;
+#pragma unroll
+        for (int t = 0; t < A_DMA; ++t) {
+            const int row = (wave * A_DMA + t) * 8 + (lane >> 3);
+            const int ro = a_row_off(m0 + row);
+            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < B_DMA; ++t) {
+            const int row = (wave * B_DMA + t) * 8 + (lane >> 3);
+            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (((lane & 7) ^ ((row >> 1) & 7)) * 16) : OOB_OFF;
+        }
+        f16x8 fa[2][2], fb[2][TN][2];
+#define KN_DMA_A1(BUFOFF, UOFF, T)                                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_desc, (lds_v*)(lds + (BUFOFF) + (wave * A_DMA + (T)) * 1024), 16, a_src[T] + (UOFF), 0, 0, 0);   /* slab offset in the VGPR offset: the range check ignores soffset, and conv padding relies on it */
+#define KN_DMA_B1(BUFOFF, KT, T)                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + (BUFOFF) + BOFF + (wave * B_DMA + (T)) * 1024), 16, b_src[T], (KT) * 128, 0, 0);
+#define KN_RD_A(BUFOFF, KS, I, SLOT)                                                                          \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                            \
+        fa[SLOT][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + a_row + (I) * 32 * BROW + x_off[KS][p]));
+#define KN_RD_B(BUFOFF, KS)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                           \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                        \
+            fb[KS][i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + b_row + i * 32 * BROW + x_off[KS][p]));
+#define KN_MFMA_ROW(KS, I, SLOT)                                                                              \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
+        f32x16 c = acc[I][j];                                                                                \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][1], fb[KS][j][0], c, 0, 0, 0);                   \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][1], c, 0, 0, 0);                   \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][0], c, 0, 0, 0);                   \
+        acc[I][j] = c;                                                                                       \
+    }
+        {
+            const int u0 = a_step(0);
+#pragma unroll
+            for (int t = 0; t < A_DMA; ++t) { KN_DMA_A1(0, u0, t) }
+#pragma unroll
+            for (int t = 0; t < B_DMA; ++t) { KN_DMA_B1(0, 0, t) }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        constexpr int STEPS = 2 * TM;                               // row steps of a slab
+#ifdef KN_DMA_EARLY
+        constexpr int PER = A_DMA + B_DMA;                          // all pieces behind the first row step
+#else
+        constexpr int PER = (A_DMA + B_DMA + STEPS - 1) / STEPS;    // DMA pieces issued behind each row step
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = (kt & 1) * BUF, nxt = BUF - cur;
+            const bool st = kt + 1 < nk;
+            const int un = st ? a_step(kt + 1) : 0;
+            KN_RD_B(cur, 0) KN_RD_A(cur, 0, 0, 0)
+#pragma unroll
+            for (int r = 0; r < STEPS; ++r) {
+                const int ks = r / TM, i = r % TM;
+                if (i + 1 < TM) { KN_RD_A(cur, ks, i + 1, (i + 1) & 1) }
+                else if (ks == 0) { KN_RD_B(cur, 1) KN_RD_A(cur, 1, 0, 0) }
+                __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
+                KN_MFMA_ROW(ks, i, i & 1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (st) {                               // slab kt+1 -> idle buffer, a few pieces behind every MFMA group
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) {
+                        const int t = r * PER + e;
+                        if (t < A_DMA) { KN_DMA_A1(nxt, un, t) }
+                        else if (t < A_DMA + B_DMA) { KN_DMA_B1(nxt, kt + 1, t - A_DMA) }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's pieces of slab kt+1 have landed
+            __syncthreads();
+        }
+#undef KN_DMA_A1
+#undef KN_DMA_B1
+#undef KN_RD_A
+#undef KN_RD_B
+#undef KN_MFMA_ROW
+    }
+
+    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
+        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
+        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
+    }
+};

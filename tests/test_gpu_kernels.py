@@ -57,7 +57,7 @@ def test_linear_emulated_fp32(M, K, N, mode, attr, monkeypatch):
     assert e3 <= 2.0 * e32 + 1e-6 and e3 < 1e-5 * float(ref.abs().max())
 
 
-def test_linear_split_layout_in_and_out():
+def test_linear_split_layout_in_and_out(monkeypatch):
     """A2: a GEMM fed with pre-split activations gives bit-identical results to splitting them in the kernel, and a
     GEMM writing the split layout round-trips to its fp32 output within the split error (2^-22 relative)."""
     ops = _ops()
@@ -79,6 +79,8 @@ def test_linear_split_layout_in_and_out():
     from knn_svc_amd._lib import KnnSvcError
     with pytest.raises(KnnSvcError):
         ops.linear(x, wd, b, resid=ref, out_split=True)
+    monkeypatch.setenv("KNNSVC_DMA", "1")           # opt-in kernel: both operands by LDS-DMA — same arithmetic
+    assert torch.equal(ops.linear(ops.split_pack(x), wd, b, act=ops.ACT_GELU, x_split=True), ref)
 
 
 def test_linear_f16x2_big_tile(monkeypatch):

@@ -10,12 +10,14 @@ out = torch.empty(M, N, device="cuda")
 if os.environ.get("SPLIT", "1") == "1":
     ops.attach_split(w)
     print("split:", "f16x2" if hasattr(w, "_w2") else "bf16x3" if hasattr(w, "_w3") else "none")
+A2 = os.environ.get("A2", "0") == "1"          # feed pre-split activations (x_split): the DMA-fed kernel
+xin = ops.split_pack(x) if A2 else x
 for _ in range(3):
-    ops.linear(x, w, b, out=out)
+    ops.linear(xin, w, b, out=out, x_split=A2)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
 for _ in range(iters):
-    ops.linear(x, w, b, out=out)
+    ops.linear(xin, w, b, out=out, x_split=A2)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 print(f"M={M} N={N} K={K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
