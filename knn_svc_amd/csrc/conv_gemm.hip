@@ -233,15 +233,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G
         if (a.convt_u) { phase = n / a.convt_cout; col = n - phase * a.convt_cout; }
 #pragma unroll
         for (int i = 0; i < G::TM; ++i) {
+            // output row of accumulator element r of this 32x32 tile, or -1 (past M, or a transposed-conv row cropped away)
+            auto out_row = [&](int r) -> long {
+                const int m = m0 + G::acc_row(wave, lane, i, r);
+                if (m >= a.m) return -1;
+                if (!a.convt_u) return m;
+                const long o = (long)m * a.convt_u + phase - a.convt_pad;
+                return (o < 0 || o >= a.t_out) ? -1 : o;
+            };
+            // residual / accumulate operands: all 16 loads of the tile are issued before the first use (the straight
+            // per-element "load, add, store" form serialised on s_waitcnt vmcnt(0) — one memory round trip per element —
+            // and made the short-K layers with a residual epilogue-bound: out-proj 177 vs 277 TFLOP/s for QKV)
+            float rv[16], av[16];
+            if (rz) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const long o = out_row(r); rv[r] = o >= 0 ? rz[o * a.ldr + col] : 0.f; }
+            }
+            if (a.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const long o = out_row(r); av[r] = o >= 0 ? oz[o * a.ldo + col] : 0.f; }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + G::acc_row(wave, lane, i, r);
-                if (m >= a.m) continue;
-                long orow = m;
-                if (a.convt_u) {
-                    orow = (long)m * a.convt_u + phase - a.convt_pad;
-                    if (orow < 0 || orow >= a.t_out) continue;
-                }
+                const long orow = out_row(r);
+                if (orow < 0) continue;
                 float v = fmaf(acc[i][j][r], a.out_scale, bv);      // out_scale is a power of two: exact
                 if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
@@ -263,11 +278,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G
                     *(unsigned*)ob = ow;
                     continue;
                 }
-                if (rz) v += rz[orow * a.ldr + col];
-                float* op = oz + orow * a.ldo + col;
-                if (a.accumulate) v += *op;
+                if (rz) v += rv[r];
+                if (a.accumulate) v += av[r];
                 if (a.div != 1.0f) v = v / a.div;
-                *op = v;
+                oz[orow * a.ldo + col] = v;
             }
         }
     }
