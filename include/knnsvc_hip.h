@@ -147,6 +147,14 @@ int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int6
                     int64_t* out_idx, float* out_dist, void* workspace, size_t workspace_bytes,
                     int32_t* nan_flag, void* stream);
 
+/* Second half of the two-kernel kNN route: `dots`[nq, np] (row pitch ld) holds q.p^T computed by knnsvc_conv_gemm
+ * on the emulated-fp32 matrix-core path (q as the A operand, the pool rows as pre-split "weights"); this replays the
+ * reference's distance formula (lib_ongaku_test.py:148-175) on every entry and selects each row's ascending top-k with
+ * the same (distance, lower index) order, NaN flag and idx_offset semantics as knnsvc_knn_topk. */
+int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const float* q_sq, int64_t nq,
+                      const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                      int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
+
 /* Merge `parts` per-shard top-k lists ([parts][nq][k], e.g. after an RCCL all-gather) into one. */
 int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx, int32_t parts, int64_t nq,
                      int32_t k, int64_t* out_idx, float* out_dist, void* stream);

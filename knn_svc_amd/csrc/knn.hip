@@ -169,6 +169,69 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
     }
 }
 
+// Top-k from a precomputed dot-product matrix (the two-kernel route: q.p^T comes from the emulated-fp32 GEMM of
+// conv_gemm.hip, 3-4x the rate of the fp32 MFMA tile above; this kernel replays the reference's distance formula on it
+// and selects).  One block per query row, 4 waves; wave w scans pool columns [128 w + 512 t, +128) with the same
+// threshold filter + 64-lane bitonic merge as knn_tile_kernel, wave 0 then folds the four sorted lists.
+__global__ __launch_bounds__(256) void knn_select_kernel(
+    const float* __restrict__ dots, long ld, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
+    const float* __restrict__ pn, const float* __restrict__ psq, long np, int k, long idx_offset,
+    long* __restrict__ out_idx, float* __restrict__ out_dist, int* nan_flag) {
+    __shared__ unsigned long long lists[4][KMAX];
+    __shared__ unsigned long long scratch[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long row = blockIdx.x;
+    const float* drow = dots + row * ld;
+    const float v_qn = qn[row], v_qsq = qsq[row];
+    unsigned long long* lst = lists[wave];
+    unsigned long long* my_scratch = scratch[wave];
+    if (lane < KMAX) lst[lane] = KEY_INF;
+    __builtin_amdgcn_wave_barrier();
+    bool saw_nan = false;
+    for (long base = (long)wave * 128; base < np; base += 512) {
+        const long p0 = base + lane, p1 = base + 64 + lane;
+        float d0 = __builtin_inff(), d1 = __builtin_inff();
+        if (p0 < np) { d0 = ref_distance(drow[p0], v_qsq, psq[p0], v_qn, pn[p0]); if (d0 != d0) saw_nan = true; }
+        if (p1 < np) { d1 = ref_distance(drow[p1], v_qsq, psq[p1], v_qn, pn[p1]); if (d1 != d1) saw_nan = true; }
+        const unsigned long long thr = lst[k - 1];
+        // NaN / +inf never enter: their sortable bits are >= those of +inf
+        const unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)p0;
+        const unsigned long long k1 = ((unsigned long long)sortable(d1) << 32) | (unsigned)p1;
+        const bool f0 = (d0 < __builtin_inff()) && k0 < thr;
+        const bool f1 = (d1 < __builtin_inff()) && k1 < thr;
+        const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+        if ((b0 | b1) == 0ull) continue;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int c0 = __popcll(b0), total = c0 + __popcll(b1);
+        if (f0) my_scratch[__popcll(b0 & lt)] = k0;
+        if (f1) my_scratch[c0 + __popcll(b1 & lt)] = k1;
+        __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < total; b += 32) {
+            unsigned long long v;
+            if (lane < 32) v = lane < k ? lst[lane] : KEY_INF;
+            else v = (b + lane - 32) < total ? my_scratch[b + lane - 32] : KEY_INF;
+            v = wave_sort64(v, lane);
+            if (lane < k) lst[lane] = v;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (saw_nan) atomicOr(nan_flag, 1);
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long best = lane < k ? lists[0][lane] : KEY_INF;
+        for (int s = 1; s < 4; ++s) {
+            unsigned long long v = best;
+            if (lane >= 32) v = (lane - 32) < k ? lists[s][lane - 32] : KEY_INF;
+            else if (lane >= k) v = KEY_INF;
+            best = wave_sort64(v, lane);
+        }
+        if (lane < k) {
+            out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull) + idx_offset;
+            out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
+        }
+    }
+}
+
 // one wave per query row: fold `parts` sorted key lists into one
 __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const unsigned long long* __restrict__ part,
                                                             int parts, long nq, int k, long idx_offset,
@@ -301,4 +364,17 @@ extern "C" int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx,
     hipLaunchKernelGGL(knn_merge_pairs_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream,
                        part_dist, (const long*)part_idx, parts, (long)nq, k, (long*)out_idx, out_dist);
     return knnsvc_check_launch("knn_merge_pairs");
+}
+
+extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const float* q_sq, int64_t nq,
+                                 const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                                 int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream) {
+    KN_REQUIRE(dots && q_norm && q_sq && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_select: null pointer");
+    KN_REQUIRE(nq > 0 && np > 0 && ld >= np, "knn_select: empty query or pool, or ld < np");
+    KN_REQUIRE(k >= 1 && k <= KMAX, "knn_select: k must be in 1..32");
+    KN_REQUIRE(np >= k, "knn_select: pool smaller than k (the reference's topk would raise)");
+    KN_REQUIRE(np < (1ll << 32) && nq <= 0x7FFFFFFFll, "knn_select: pool rows must fit 32 bits");
+    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
+                       (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long*)out_idx, out_dist, nan_flag);
+    return knnsvc_check_launch("knn_select");
 }

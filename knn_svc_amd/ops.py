@@ -121,7 +121,8 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               bias=None, bias_period=0, act=ACT_NONE, act_slope=0.0, a_slope=1.0, resid=None, ldr=None,
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
-              convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False):
+              convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False,
+              w2=None, w2_scale=0.0):
     """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr)."""
     lib = _lib.load()
     d = ConvDesc()
@@ -141,9 +142,10 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.convt_u = convt_u; d.convt_cout = convt_cout; d.convt_pad = convt_pad; d.t_out = t_out
     w3 = getattr(w, "_w3", None)
     d.w_bf16x3 = w3.data_ptr() if w3 is not None else None
-    w2 = getattr(w, "_w2", None)
+    if w2 is None:
+        w2, w2_scale = getattr(w, "_w2", None), getattr(w, "_w2_scale", 0.0)
     d.w_f16x2 = w2.data_ptr() if w2 is not None else None
-    d.w_f16x2_scale = w._w2_scale if w2 is not None else 0.0
+    d.w_f16x2_scale = w2_scale if w2 is not None else 0.0
     d.a_f16x2_scale = a_scale
     d.x_f16x2 = 1 if x_split else 0; d.out_f16x2 = 1 if out_split else 0
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
@@ -228,6 +230,55 @@ def row_norms(x2d):
     return norm, sq
 
 
+KNN_FEATURE_SCALE = 16.0     # fixed power-of-two pre-scale of both operands on the f16x2 kNN route (|x| < 4094)
+
+
+def knn_mode() -> str:
+    """KNNSVC_KNN = f16x2 | fp32.  f16x2 (default while KNNSVC_GEMM is f16x2): q.p^T from the emulated-fp32 GEMM +
+    knnsvc_knn_select; fp32: the fused exact-fp32-MFMA tile kernel (knnsvc_knn_topk)."""
+    import os
+    mode = os.environ.get("KNNSVC_KNN", "f16x2" if gemm_mode() == "f16x2" else "fp32")
+    if mode not in ("f16x2", "fp32"):
+        raise KnnSvcError(f"KNNSVC_KNN={mode!r}: expected f16x2 or fp32")
+    return mode
+
+
+def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag):
+    """Two-kernel route: dot products on the f16x2 GEMM (pool rows = pre-split "weights", fixed scale 16), then the
+    reference's distance formula + selection (knnsvc_knn_select).  Pool and query are chunked so that every buffer
+    resource stays below 1 GiB and the dot matrix below ~1 GiB; pool chunks are folded with knnsvc_knn_merge."""
+    lib = _lib.load()
+    nq, dim = q.shape
+    npool = pool.shape[0]
+    dev = q.device
+    p_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
+    n_chunks = -(-npool // p_cap)
+    p_rows = -(-npool // n_chunks)                    # balanced chunks: no tail shorter than k
+    q_rows_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
+    parts_i, parts_d = [], []
+    for p0 in range(0, npool, p_rows):
+        pc = pool[p0:p0 + p_rows]
+        npc = pc.shape[0]
+        if npc < k:        # a tail chunk shorter than k: fold it into the fused exact kernel (any size works there)
+            raise KnnSvcError("knn_topk: pool chunk smaller than k")
+        p2 = torch.empty(npc * (dim // 32) * 64, device=dev, dtype=torch.int16)
+        check(lib.knnsvc_split_weight_f16x2(_p(pc), npc, dim, KNN_FEATURE_SCALE, _p(p2), _stream()), "split_weight")
+        idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
+        dist = torch.empty(nq, k, device=dev, dtype=torch.float32)
+        q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npc, 1) // 128 * 128))
+        for q0 in range(0, nq, q_rows):
+            qc = q[q0:q0 + q_rows]
+            m = qc.shape[0]
+            dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
+            conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, a_scale=KNN_FEATURE_SCALE, w2=p2, w2_scale=KNN_FEATURE_SCALE)
+            check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
+                                        idx_offset + p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag), _stream()), "knn_select")
+        parts_i.append(idx); parts_d.append(dist)
+    if len(parts_i) == 1:
+        return parts_i[0], parts_d[0]
+    return knn_merge(torch.stack(parts_d), torch.stack(parts_i))
+
+
 def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False):
     """Ascending cosine-distance top-k of each q row among pool rows -> (idx int64 [nq,k], dist f32 [nq,k])."""
     _need(q, name="knn.q"); _need(pool, name="knn.pool")
@@ -238,6 +289,12 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     npool = pool.shape[0]
     qn, qs = q_stats if q_stats is not None else row_norms(q)
     pn, ps = p_stats if p_stats is not None else row_norms(pool)
+    if knn_mode() == "f16x2" and dim % 32 == 0 and npool >= k and nq > 0 and 1 <= k <= 32:
+        flag = torch.zeros(1, device=q.device, dtype=torch.int32)
+        idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag)
+        if check_nan:
+            raise_if_nan(flag)
+        return (idx, dist, flag) if return_flag else (idx, dist)
     ws_bytes = lib.knnsvc_knn_workspace_bytes(nq, npool, k)
     ws = torch.empty(max(ws_bytes, 8), device=q.device, dtype=torch.uint8)
     idx = torch.empty(nq, k, device=q.device, dtype=torch.int64)
