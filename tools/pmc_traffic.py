@@ -19,10 +19,11 @@ def avg(path, counter, key):
 KEY = sys.argv[3] if len(sys.argv) > 3 else "conv_gemm2_kernel<Gemm2Tile<128, 128"
 f = avg(sys.argv[1], "FETCH_SIZE", KEY)
 w = avg(sys.argv[2], "WRITE_SIZE", KEY)
-name = next(iter(f))
-fk, n = f[name]
-wk, _ = w[name]
-out = dict(kernel=name, launches=n, fetch_size_kib_avg=round(fk, 1), write_size_kib_avg=round(wk, 1),
+# every instantiation whose name matches (e.g. the A2 = true / false variants of the 128x128 kernel), launch-weighted
+n = sum(c for _v, c in f.values())
+fk = sum(v * c for v, c in f.values()) / n
+wk = sum(v * c for v, c in w.values()) / max(1, sum(c for _v, c in w.values()))
+out = dict(kernel=" | ".join(sorted(f)), launches=n, fetch_size_kib_avg=round(fk, 1), write_size_kib_avg=round(wk, 1),
            hbm_bytes_per_launch=int((2 * fk + wk) * 1024),
            note="2 x FETCH_SIZE + WRITE_SIZE, averaged over every launch of the kernel in a bench.py run (--steps 2 --warmup 1, plus the "
                 "setup, latency and eager roofline passes bench.py adds); separate --pmc passes")
