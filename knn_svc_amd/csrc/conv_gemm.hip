@@ -218,7 +218,7 @@ struct Split2BLoader {
 };
 
 template <class G>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G::TM][G::TN], int m0, int n0, int b, int g) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], int m0, int n0, int b, int g) {
     // ---- epilogue -------------------------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
@@ -244,17 +244,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[G
             // residual / accumulate operands: all 16 loads of the tile are issued before the first use (the straight
             // per-element "load, add, store" form serialised on s_waitcnt vmcnt(0) — one memory round trip per element —
             // and made the short-K layers with a residual epilogue-bound: out-proj 177 vs 277 TFLOP/s for QKV)
-            float rv[16], av[16];
+            constexpr int NR = G::NR;
+            float rv[NR], av[NR];
             if (rz) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const long o = out_row(r); rv[r] = o >= 0 ? rz[o * a.ldr + col] : 0.f; }
+                for (int r = 0; r < NR; ++r) { const long o = out_row(r); rv[r] = o >= 0 ? rz[o * a.ldr + col] : 0.f; }
             }
             if (a.accumulate) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const long o = out_row(r); av[r] = o >= 0 ? oz[o * a.ldo + col] : 0.f; }
+                for (int r = 0; r < NR; ++r) { const long o = out_row(r); av[r] = o >= 0 ? oz[o * a.ldo + col] : 0.f; }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 const long orow = out_row(r);
                 if (orow < 0) continue;
                 float v = fmaf(acc[i][j][r], a.out_scale, bv);      // out_scale is a power of two: exact
@@ -362,13 +363,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;      // 64 halves = 128 B per (row, slab)
 
-    f32x16 acc[G::TM][G::TN];
+    typename G::acc_t acc[G::TM][G::TN];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i)
 #pragma unroll
         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < G::NR; ++r) acc[i][j][r] = 0.f;
     FastALoader<G::A_F4> al(a, m0, threadIdx.x);
     Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
     G::template mainloop<A2>(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale);

@@ -43,6 +43,8 @@ __device__ __forceinline__ void f16x2_split4(f32x4 v, float scale, g2_u32x2& hi,
 
 template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
 struct Gemm2Tile {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;               // accumulator elements per MFMA tile and lane
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BK = 32, PITCH = 144, THREADS = 256;
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
@@ -179,6 +181,8 @@ struct Gemm2Tile {
 // -------------------------------------------------------------------------------------------------
 template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
 struct Gemm2Big {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;               // accumulator elements per MFMA tile and lane
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BK = 32, PITCH = 144, BROW = 128, NW = WM * WN, THREADS = 64 * NW, RS = THREADS / 8;
     static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
@@ -352,6 +356,8 @@ struct Gemm2Big {
 // -------------------------------------------------------------------------------------------------
 template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
 struct Gemm2Dma {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;               // accumulator elements per MFMA tile and lane
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BK = 32, BROW = 128, NW = WM * WN, THREADS = 64 * NW;
     static_assert(NW == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");

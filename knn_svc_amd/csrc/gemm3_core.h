@@ -22,6 +22,8 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
 struct Gemm3Tile {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BK = 32, PITCH = 208, THREADS = 256;
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");

@@ -19,6 +19,8 @@
 
 template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_, int NT_ = 256>
 struct GemmTile {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BK = 32, LDK = 36, THREADS = NT_;
     static constexpr int RP = THREADS / 8;        // rows staged per pass (8 float4 per 32-float row)
