@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 4
+#define KNNSVC_ABI_VERSION 5
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -140,10 +140,13 @@ size_t knnsvc_knn_workspace_bytes(int64_t nq, int64_t np, int32_t k);
 
 /* Ascending top-k of d(q_i, p_j) per query row, d evaluated with the reference's operation
  * sequence on top of an MFMA dot product.  Ties: lower pool index first.  Indices are written
- * as idx_offset + j (so that a pool shard reports global rows).  k <= 32. */
+ * as idx_offset + j (so that a pool shard reports global rows).  k <= 32.
+ * [mask_lo, mask_hi): local pool rows whose distance is replaced by exactly 1 before selection — the
+ * self-matching rule of per_spk_extract (ddsp_prematch_dataset.py:1606-1607, `dists[:, start:end] = 1`);
+ * mask_lo >= mask_hi disables it. */
 int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int64_t nq,
                     const float* pool, const float* p_norm, const float* p_sq, int64_t np,
-                    int32_t dim, int32_t k, int64_t idx_offset,
+                    int32_t dim, int32_t k, int64_t idx_offset, int64_t mask_lo, int64_t mask_hi,
                     int64_t* out_idx, float* out_dist, void* workspace, size_t workspace_bytes,
                     int32_t* nan_flag, void* stream);
 
@@ -153,6 +156,7 @@ int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int6
  * the same (distance, lower index) order, NaN flag and idx_offset semantics as knnsvc_knn_topk. */
 int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const float* q_sq, int64_t nq,
                       const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                      int64_t mask_lo, int64_t mask_hi,
                       int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
 
 /* Merge `parts` per-shard top-k lists ([parts][nq][k], e.g. after an RCCL all-gather) into one. */
@@ -186,15 +190,27 @@ int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, const float* q
  * Adam(amsgrad) on softmax weights with the reference's stopping rules, run entirely on the
  * device (no per-iteration host sync).  scale = 0.1 (WavLM) or 1000 (harmonics).
  * out_w [nq,4]; out_iters[0] = iterations executed.  workspace from knnsvc_smooth_workspace_bytes. */
+/* row_scale (may be NULL) [nq,4]: compute_weight_with_amp (ddsp_prematch_dataset.py:684-804) — candidate k of
+ * frame t and its two neighbours are multiplied by row_scale[t,k] (the amp_ratio of per_spk_extract) before the
+ * loss is formed; with scale = 1000 this is the prematch weight optimisation. */
 size_t knnsvc_smooth_workspace_bytes(int64_t nq);
 int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float* pool, int64_t np, int32_t dim,
-                          int32_t ld, float scale, int32_t max_iter, float* out_w, int32_t* out_iters,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          int32_t ld, float scale, const float* row_scale, int32_t max_iter, float* out_w,
+                          int32_t* out_iters, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[i,:] = sum_k w[i,k] * pool[idx[i,k], :]   (ddsp_prematch_dataset.py:1358, 1444; w NULL = mean of 4
  * for harmonics :1446 / softmax(ones) :1361-1364) */
 int knnsvc_weighted_gather(const int64_t* idx, const float* w, int64_t nq, int32_t k, const float* pool,
                            int32_t dim, int32_t ld, int32_t mean_mode, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Prematch (training-pool generation, ddsp_prematch_dataset.py:1464-1772 per_spk_extract).
+ * ------------------------------------------------------------------------------------------ */
+/* out = float(half(x)) element-wise, round-to-nearest-even (`.half().float()`, :1509, 1561, 1592) */
+int knnsvc_round_f16(const float* x, int64_t n, float* out, void* stream);
+/* amp_ratio[t,k] = ||spec_q[t,:]||_1 / (||spec_pool[idx[t,k],:]||_1 + 1e-5)   (:1657-1660) */
+int knnsvc_amp_ratio(const float* spec_q, int32_t ld_q, const float* spec_pool, int32_t ld_pool, int64_t np,
+                     const int64_t* idx, int64_t nq, int32_t k, int32_t bins, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pool side features and the additive synthesiser.

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libknnsvc_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -49,16 +49,18 @@ SIGNATURES = {
     "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp]),
     "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp]),
     "knnsvc_knn_workspace_bytes": (sz, [i64, i64, i32]),
-    "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, vp, vp, vp, sz, vp, vp]),
-    "knnsvc_knn_select": (i32, [vp, i64, vp, vp, i64, vp, vp, i64, i32, i64, vp, vp, vp, vp]),
+    "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, i64, i64, vp, vp, vp, sz, vp, vp]),
+    "knnsvc_knn_select": (i32, [vp, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i64, vp, vp, vp, vp]),
     "knnsvc_knn_merge": (i32, [vp, vp, i32, i64, i32, vp, vp, vp]),
     "knnsvc_log_f0_median": (i32, [vp, i64, vp, vp, vp]),
     "knnsvc_shift_f0": (i32, [vp, i64, vp, vp, vp, vp]),
     "knnsvc_f0_rerank": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "knnsvc_concat_reselect": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, i32, f32, vp, vp]),
     "knnsvc_smooth_workspace_bytes": (sz, [i64]),
-    "knnsvc_smooth_weights": (i32, [vp, i64, vp, i64, i32, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "knnsvc_smooth_weights": (i32, [vp, i64, vp, i64, i32, i32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "knnsvc_weighted_gather": (i32, [vp, vp, i64, i32, vp, i32, i32, i32, vp, vp]),
+    "knnsvc_round_f16": (i32, [vp, i64, vp, vp]),
+    "knnsvc_amp_ratio": (i32, [vp, i32, vp, i32, i64, vp, i64, i32, i32, vp, vp]),
     "knnsvc_reflect_pad": (i32, [vp, i64, i32, vp, vp]),
     "knnsvc_complex_mag": (i32, [vp, i64, i32, i32, vp, vp]),
     "knnsvc_harmonic_amps": (i32, [vp, vp, i64, i32, i32, vp, vp]),

@@ -346,3 +346,63 @@ extern "C" int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, co
 #undef KN_C0
     return knnsvc_check_launch("wavlm_conv0");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Prematch helpers (per_spk_extract, ddsp_prematch_dataset.py:1464-1772)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// `.half().float()`: round-to-nearest-even to fp16 (overflow -> inf, as torch), widened back
+__global__ __launch_bounds__(256) void round_f16_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *(const f32x4*)(x + i);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)v[e];
+        *(f32x4*)(out + i) = r;
+    } else {
+        for (long j = i; j < n; ++j) out[j] = (float)(_Float16)x[j];
+    }
+}
+
+// one wave per query frame: L1 norm of its own spectrum row and of the k gathered pool rows (sums in f64, rounded once)
+__global__ __launch_bounds__(256) void amp_ratio_kernel(const float* __restrict__ spec_q, int ld_q,
+                                                       const float* __restrict__ spec_pool, int ld_pool, long np,
+                                                       const long* __restrict__ idx, long nq, int k, int bins,
+                                                       float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= nq) return;
+    double s = 0.0;
+    for (int c = lane; c < bins; c += 64) s += (double)fabsf(spec_q[t * ld_q + c]);
+    const float orig = (float)wave_sum_d(s);
+    for (int j = 0; j < k; ++j) {
+        long id = idx[t * k + j];
+        id = id < 0 ? 0 : (id > np - 1 ? np - 1 : id);
+        double a = 0.0;
+        for (int c = lane; c < bins; c += 64) a += (double)fabsf(spec_pool[id * ld_pool + c]);
+        const float l1 = (float)wave_sum_d(a);
+        if (lane == 0) out[t * k + j] = orig / (l1 + 1e-5f);
+    }
+}
+
+}  // namespace
+
+extern "C" int knnsvc_round_f16(const float* x, int64_t n, float* out, void* stream) {
+    KN_REQUIRE(x && out && n >= 0, "round_f16: bad arguments");
+    KN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "round_f16: pointers must be 16-byte aligned");
+    if (n == 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(round_f16_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+    return knnsvc_check_launch("round_f16");
+}
+
+extern "C" int knnsvc_amp_ratio(const float* spec_q, int32_t ld_q, const float* spec_pool, int32_t ld_pool, int64_t np,
+                                const int64_t* idx, int64_t nq, int32_t k, int32_t bins, float* out, void* stream) {
+    KN_REQUIRE(spec_q && spec_pool && idx && out, "amp_ratio: null pointer");
+    KN_REQUIRE(np > 0 && k > 0 && bins > 0 && ld_q >= bins && ld_pool >= bins, "amp_ratio: bad sizes");
+    if (nq <= 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(amp_ratio_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream, spec_q, ld_q,
+                       spec_pool, ld_pool, (long)np, (const long*)idx, (long)nq, k, bins, out);
+    return knnsvc_check_launch("amp_ratio");
+}

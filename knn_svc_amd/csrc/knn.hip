@@ -75,7 +75,7 @@ constexpr int KNN_LDS_BYTES = LDS_STAGE * 4 + 128 * KMAX * 8 /*lists*/ + 8 * 128
 __global__ __launch_bounds__(512) void knn_tile_kernel(
     const float* __restrict__ q, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
     const float* __restrict__ pool, const float* __restrict__ pn, const float* __restrict__ psq, long np,
-    int dim, int k, long rows_per_split, unsigned long long* __restrict__ part, int* nan_flag) {
+    int dim, int k, long rows_per_split, long mask_lo, long mask_hi, unsigned long long* __restrict__ part, int* nan_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dist = lds;                                                       // [128][LDD] (aliases staging)
     unsigned long long* lists = (unsigned long long*)(lds + LDS_STAGE);      // [128][32]
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
                     const int row = G::acc_row(wave, lane, i, r);
                     float d = ref_distance(acc[i][j][r], s_qsq[row], v_psq, s_qn[row], v_pn);
                     if (pv && (q0 + row) < nq && d != d) saw_nan = true;
+                    if (p >= mask_lo && p < mask_hi) d = 1.f;          // dists[:, start:end] = 1 (ddsp_prematch_dataset.py:1607)
                     dist[row * LDD + c] = pv ? d : __builtin_inff();
                 }
         }
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
 __global__ __launch_bounds__(256) void knn_select_kernel(
     const float* __restrict__ dots, long ld, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
     const float* __restrict__ pn, const float* __restrict__ psq, long np, int k, long idx_offset,
-    long* __restrict__ out_idx, float* __restrict__ out_dist, int* nan_flag) {
+    long mask_lo, long mask_hi, long* __restrict__ out_idx, float* __restrict__ out_dist, int* nan_flag) {
     __shared__ unsigned long long lists[4][KMAX];
     __shared__ unsigned long long scratch[4][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -193,6 +194,10 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
         float d0 = __builtin_inff(), d1 = __builtin_inff();
         if (p0 < np) { d0 = ref_distance(drow[p0], v_qsq, psq[p0], v_qn, pn[p0]); if (d0 != d0) saw_nan = true; }
         if (p1 < np) { d1 = ref_distance(drow[p1], v_qsq, psq[p1], v_qn, pn[p1]); if (d1 != d1) saw_nan = true; }
+        // self-matching (ddsp_prematch_dataset.py:1606-1607): the query's own utterance competes at distance exactly 1,
+        // after the NaN check (fast_cosine_dist exits on NaN before the caller overwrites anything)
+        if (p0 >= mask_lo && p0 < mask_hi) d0 = 1.f;
+        if (p1 >= mask_lo && p1 < mask_hi) d1 = 1.f;
         const unsigned long long thr = lst[k - 1];
         // NaN / +inf never enter: their sortable bits are >= those of +inf
         const unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)p0;
@@ -324,7 +329,8 @@ extern "C" size_t knnsvc_knn_workspace_bytes(int64_t nq, int64_t np, int32_t k) 
 
 extern "C" int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int64_t nq,
                                const float* pool, const float* p_norm, const float* p_sq, int64_t np,
-                               int32_t dim, int32_t k, int64_t idx_offset, int64_t* out_idx, float* out_dist,
+                               int32_t dim, int32_t k, int64_t idx_offset, int64_t mask_lo, int64_t mask_hi,
+                               int64_t* out_idx, float* out_dist,
                                void* workspace, size_t workspace_bytes, int32_t* nan_flag, void* stream) {
     KN_REQUIRE(q && q_norm && q_sq && pool && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_topk: null pointer");
     KN_REQUIRE(nq > 0 && np > 0, "knn_topk: empty query or pool");
@@ -349,7 +355,7 @@ extern "C" int knnsvc_knn_topk(const float* q, const float* q_norm, const float*
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv64(nq, 128), (unsigned)S);
     hipLaunchKernelGGL(knn_tile_kernel, grid, dim3(NT), KNN_LDS_BYTES, st, q, q_norm, q_sq, (long)nq, pool, p_norm,
-                       p_sq, (long)np, dim, k, rows_per_split, (unsigned long long*)workspace, nan_flag);
+                       p_sq, (long)np, dim, k, rows_per_split, (long)mask_lo, (long)mask_hi, (unsigned long long*)workspace, nan_flag);
     int rc = knnsvc_check_launch("knn_tile");
     if (rc) return rc;
     hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, st,
@@ -368,6 +374,7 @@ extern "C" int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx,
 
 extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const float* q_sq, int64_t nq,
                                  const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                                 int64_t mask_lo, int64_t mask_hi,
                                  int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream) {
     KN_REQUIRE(dots && q_norm && q_sq && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_select: null pointer");
     KN_REQUIRE(nq > 0 && np > 0 && ld >= np, "knn_select: empty query or pool, or ld < np");
@@ -375,6 +382,6 @@ extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_n
     KN_REQUIRE(np >= k, "knn_select: pool smaller than k (the reference's topk would raise)");
     KN_REQUIRE(np < (1ll << 32) && nq <= 0x7FFFFFFFll, "knn_select: pool rows must fit 32 bits");
     hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
-                       (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long*)out_idx, out_dist, nan_flag);
+                       (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi, (long*)out_idx, out_dist, nan_flag);
     return knnsvc_check_launch("knn_select");
 }

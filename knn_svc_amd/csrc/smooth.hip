@@ -25,14 +25,21 @@ __device__ __forceinline__ int tri(int i, int j) { return i < j ? i * 7 - i * (i
 // block per frame pair t.  Both cost terms are quadratic forms in the SAME coefficient vector
 // c = [w[t+1,:], -w[t,:]] (term a over rows F[idx[t+1,k]-1], F[idx[t,k]]; term b over F[idx[t+1,k]], F[idx[t,k]+1]),
 // so only the sum of the two centred 8x8 Gram matrices is kept: its 28 off-diagonal entries per pair.
+// row_scale (optional) [nq][4]: candidate k of frame t and its +-1 neighbours are multiplied by row_scale[t][k]
+// (compute_weight_with_amp, ddsp_prematch_dataset.py:684-713); the centring argument is unchanged because the
+// coefficient vector still sums to zero.
 __global__ __launch_bounds__(256) void gram_kernel(const long* __restrict__ idx, long nq, const float* __restrict__ pool,
-                                                  long np, int dim, int ld, float* __restrict__ gram) {
+                                                  long np, int dim, int ld, const float* __restrict__ row_scale,
+                                                  float* __restrict__ gram) {
     extern __shared__ float sm[];           // [8][dim] centred vectors of the current term
     const long t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[GE / 4];
 #pragma unroll
     for (int q = 0; q < GE / 4; ++q) acc[q] = 0.0;
+    float rs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rs[r] = row_scale ? (r < 4 ? row_scale[(t + 1) * KW + r] : row_scale[t * KW + (r - 4)]) : 1.f;
     for (int term = 0; term < 2; ++term) {
         __syncthreads();
         for (int c = tid; c < dim; c += 256) {
@@ -44,6 +51,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const long* __restrict__ idx,
                 else id = idx[t * KW + (r - 4)] + (term == 0 ? 0 : 1);
                 id = id < 0 ? 0 : (id > np - 1 ? np - 1 : id);
                 v[r] = pool[id * (long)ld + c];
+                if (row_scale) v[r] *= rs[r];
                 mean += v[r];
             }
             mean *= 0.125f;
@@ -322,8 +330,8 @@ inline size_t ws_floats(long nq) { return (size_t)GE * nq + (size_t)6 * 4 * nq +
 extern "C" size_t knnsvc_smooth_workspace_bytes(int64_t nq) { return nq > 0 ? ws_floats(nq) * 4 + 64 : 0; }
 
 extern "C" int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float* pool, int64_t np, int32_t dim,
-                                     int32_t ld, float scale, int32_t max_iter, float* out_w, int32_t* out_iters,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     int32_t ld, float scale, const float* row_scale, int32_t max_iter, float* out_w,
+                                     int32_t* out_iters, void* workspace, size_t workspace_bytes, void* stream) {
     KN_REQUIRE(idx && pool && out_w && workspace, "smooth_weights: null pointer");
     KN_REQUIRE(nq > 0 && np > 0 && dim > 0 && ld >= dim && max_iter > 0, "smooth_weights: bad sizes");
     KN_REQUIRE(((uintptr_t)out_w & 15) == 0, "smooth_weights: out_w must be 16-byte aligned");
@@ -349,7 +357,7 @@ extern "C" int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float
         gattr = gl;
     }
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nq - 1)), dim3(256), gl, st, (const long*)idx, (long)nq, pool, (long)np,
-                       dim, ld, gram);
+                       dim, ld, row_scale, gram);
     int rc = knnsvc_check_launch("gram");
     if (rc) return rc;
     if (nq <= 1536) {            // register-resident loop

@@ -144,8 +144,15 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
+def prepare_pool(matching_list):
+    """Per-pool quantities that do not depend on the query (row norms, the split image the kNN GEMM reads): computed
+    once per target pool in dataset mode instead of once per utterance."""
+    P = matching_list
+    return dict(stats=ops.row_norms(P), split=ops.prepare_knn_pool(P, C.KNN_K))
+
+
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
-                   return_debug=False, nn32=None, nan_flags=None):
+                   return_debug=False, nn32=None, nan_flags=None, pool_prep=None):
     """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors.  ``nn32`` may carry
     neighbours already found by the pool-sharded search (knn_svc_amd.dist.sharded_knn).  ``nan_flags``: a
     list that receives the kNN NaN flag instead of the host checking it here (the caller then calls
@@ -153,12 +160,12 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
     q = query_seq.contiguous()
     P = matching_list
     qn, qs = ops.row_norms(q)
-    pn, ps = ops.row_norms(P)
+    pn, ps = pool_prep["stats"] if pool_prep is not None else ops.row_norms(P)
     nan_flag = None
     if nn32 is None:
         # NaN check deferred to the end of the launch sequence (one host sync instead of a split stream)
         nn32, _, nan_flag = ops.knn_topk(q, P, C.KNN_K, q_stats=(qn, qs), p_stats=(pn, ps), check_nan=False,
-                                         return_flag=True)
+                                         return_flag=True, prepared=pool_prep["split"] if pool_prep is not None else None)
     cw, run_adam = parse_post_opt(post_opt)
     with_harm = "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type
     # The WavLM-feature branch (concat re-selection -> Adam -> weighted sum) and the pitched branch
@@ -244,8 +251,9 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     # the per-item bodies are independent chains of mostly single-workgroup kernels: three at a time, each on
     # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
     flags = []
+    prep = prepare_pool(matching_list) if len(items) > 1 else None
     body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
-                                       harmonics_list, ckpt_type, post_opt, nan_flags=flags)
+                                       harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep)
     lanes = min(3, len(items))
     results = pipeline.LanePipeline(matching_list.device, lanes).run(items, body) if lanes > 1 else [body(i) for i in items]
     for f in flags:

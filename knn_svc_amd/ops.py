@@ -243,26 +243,41 @@ def knn_mode() -> str:
     return mode
 
 
-def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag):
+def prepare_knn_pool(pool, k=32):
+    """Pre-split image of a pool for the two-kernel kNN route, reusable across searches against the same pool
+    (dataset mode and prematch search one pool once per utterance): list of (first row, rows view, f16x2 image).
+    Returns None when the route does not apply (see knn_topk)."""
+    _need(pool, name="knn.pool")
+    npool, dim = pool.shape
+    if not (knn_mode() == "f16x2" and dim % 32 == 0 and npool >= k and pool.is_contiguous()):
+        return None
+    lib = _lib.load()
+    p_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
+    n_chunks = -(-npool // p_cap)
+    p_rows = -(-npool // n_chunks)                    # balanced chunks: no tail shorter than k
+    chunks = []
+    for p0 in range(0, npool, p_rows):
+        pc = pool[p0:p0 + p_rows]
+        npc = pc.shape[0]
+        if npc < k:
+            raise KnnSvcError("knn_topk: pool chunk smaller than k")
+        p2 = torch.empty(npc * (dim // 32) * 64, device=pool.device, dtype=torch.int16)
+        check(lib.knnsvc_split_weight_f16x2(_p(pc), npc, dim, KNN_FEATURE_SCALE, _p(p2), _stream()), "split_weight")
+        chunks.append((p0, pc, p2))
+    return chunks
+
+
+def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None):
     """Two-kernel route: dot products on the f16x2 GEMM (pool rows = pre-split "weights", fixed scale 16), then the
     reference's distance formula + selection (knnsvc_knn_select).  Pool and query are chunked so that every buffer
     resource stays below 1 GiB and the dot matrix below ~1 GiB; pool chunks are folded with knnsvc_knn_merge."""
     lib = _lib.load()
     nq, dim = q.shape
-    npool = pool.shape[0]
     dev = q.device
-    p_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
-    n_chunks = -(-npool // p_cap)
-    p_rows = -(-npool // n_chunks)                    # balanced chunks: no tail shorter than k
     q_rows_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
     parts_i, parts_d = [], []
-    for p0 in range(0, npool, p_rows):
-        pc = pool[p0:p0 + p_rows]
+    for p0, pc, p2 in (prepared if prepared is not None else prepare_knn_pool(pool, k)):
         npc = pc.shape[0]
-        if npc < k:        # a tail chunk shorter than k: fold it into the fused exact kernel (any size works there)
-            raise KnnSvcError("knn_topk: pool chunk smaller than k")
-        p2 = torch.empty(npc * (dim // 32) * 64, device=dev, dtype=torch.int16)
-        check(lib.knnsvc_split_weight_f16x2(_p(pc), npc, dim, KNN_FEATURE_SCALE, _p(p2), _stream()), "split_weight")
         idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
         dist = torch.empty(nq, k, device=dev, dtype=torch.float32)
         q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npc, 1) // 128 * 128))
@@ -272,15 +287,20 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag):
             dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
             conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, a_scale=KNN_FEATURE_SCALE, w2=p2, w2_scale=KNN_FEATURE_SCALE)
             check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
-                                        idx_offset + p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag), _stream()), "knn_select")
+                                        idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
+                                        _stream()), "knn_select")
         parts_i.append(idx); parts_d.append(dist)
     if len(parts_i) == 1:
         return parts_i[0], parts_d[0]
     return knn_merge(torch.stack(parts_d), torch.stack(parts_i))
 
 
-def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False):
-    """Ascending cosine-distance top-k of each q row among pool rows -> (idx int64 [nq,k], dist f32 [nq,k])."""
+def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False, mask=None,
+             prepared=None):
+    """Ascending cosine-distance top-k of each q row among pool rows -> (idx int64 [nq,k], dist f32 [nq,k]).
+    ``mask`` = (lo, hi): pool rows [lo, hi) compete at distance exactly 1 (self-matching of per_spk_extract,
+    ddsp_prematch_dataset.py:1606-1607)."""
+    mask = (0, 0) if mask is None else (int(mask[0]), int(mask[1]))
     _need(q, name="knn.q"); _need(pool, name="knn.pool")
     if not (q.is_contiguous() and pool.is_contiguous()):
         raise KnnSvcError("knn_topk: q and pool must be contiguous")
@@ -291,7 +311,7 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     pn, ps = p_stats if p_stats is not None else row_norms(pool)
     if knn_mode() == "f16x2" and dim % 32 == 0 and npool >= k and nq > 0 and 1 <= k <= 32:
         flag = torch.zeros(1, device=q.device, dtype=torch.int32)
-        idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag)
+        idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask, prepared)
         if check_nan:
             raise_if_nan(flag)
         return (idx, dist, flag) if return_flag else (idx, dist)
@@ -300,7 +320,7 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     idx = torch.empty(nq, k, device=q.device, dtype=torch.int64)
     dist = torch.empty(nq, k, device=q.device, dtype=torch.float32)
     flag = torch.zeros(1, device=q.device, dtype=torch.int32)
-    check(lib.knnsvc_knn_topk(_p(q), _p(qn), _p(qs), nq, _p(pool), _p(pn), _p(ps), npool, dim, k, idx_offset,
+    check(lib.knnsvc_knn_topk(_p(q), _p(qn), _p(qs), nq, _p(pool), _p(pn), _p(ps), npool, dim, k, idx_offset, mask[0], mask[1],
                               _p(idx), _p(dist), _p(ws), ws_bytes, _p(flag), _stream()), "knn_topk")
     if check_nan:
         raise_if_nan(flag)
@@ -360,8 +380,13 @@ def concat_reselect(idx4, q, q_norm, pool, p_norm, shifted_f0=None, pool_f0=None
     return out
 
 
-def smooth_weights(idx4, pool, scale, max_iter=100000, return_iters=False):
+def smooth_weights(idx4, pool, scale, max_iter=100000, return_iters=False, row_scale=None):
+    """``row_scale`` [nq,4]: the amp_ratio of compute_weight_with_amp (ddsp_prematch_dataset.py:684-804)."""
     _need(idx4, torch.int64, "idx4"); _need(pool, name="pool")
+    if row_scale is not None:
+        _need(row_scale, name="row_scale")
+        if tuple(row_scale.shape) != tuple(idx4.shape) or not row_scale.is_contiguous():
+            raise KnnSvcError("smooth_weights: row_scale must be a contiguous [nq,4] tensor")
     lib = _lib.load()
     idx4 = idx4.contiguous()
     nq = idx4.shape[0]
@@ -370,7 +395,7 @@ def smooth_weights(idx4, pool, scale, max_iter=100000, return_iters=False):
     ws = torch.empty(ws_bytes, device=pool.device, dtype=torch.uint8)
     w = torch.empty(nq, 4, device=pool.device, dtype=torch.float32)
     iters = torch.zeros(1, device=pool.device, dtype=torch.int32)
-    check(lib.knnsvc_smooth_weights(_p(idx4), nq, _p(pool), npool, dim, pool.stride(0), float(scale), int(max_iter),
+    check(lib.knnsvc_smooth_weights(_p(idx4), nq, _p(pool), npool, dim, pool.stride(0), float(scale), _p(row_scale), int(max_iter),
                                     _p(w), _p(iters), _p(ws), ws_bytes, _stream()), "smooth_weights")
     return (w, iters) if return_iters else w
 
@@ -383,6 +408,29 @@ def weighted_gather(idx4, w, pool):
     out = torch.empty(nq, dim, device=pool.device, dtype=torch.float32)
     check(_lib.load().knnsvc_weighted_gather(_p(idx4), _p(w), nq, k, _p(pool), dim, pool.stride(0), 0, _p(out),
                                              _stream()), "weighted_gather")
+    return out
+
+
+# ------------------------------------------------------------------ prematch helpers
+def round_f16(x):
+    """x.half().float() (ddsp_prematch_dataset.py:1509, 1561, 1592) as one pass."""
+    _need(x, name="round_f16.x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.load().knnsvc_round_f16(_p(x), x.numel(), _p(out), _stream()), "round_f16")
+    return out
+
+
+def amp_ratio(spec_q, spec_pool, idx):
+    """[nq,k]: L1(spec_q[t]) / (L1(spec_pool[idx[t,k]]) + 1e-5)  (ddsp_prematch_dataset.py:1657-1660)."""
+    _need(spec_q, name="spec_q"); _need(spec_pool, name="spec_pool"); _need(idx, torch.int64, "idx")
+    idx = idx.contiguous()
+    nq, k = idx.shape
+    if spec_q.shape[0] != nq or spec_q.shape[1] != spec_pool.shape[1] or spec_q.stride(1) != 1 or spec_pool.stride(1) != 1:
+        raise KnnSvcError("amp_ratio: shape mismatch")
+    out = torch.empty(nq, k, device=spec_q.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_amp_ratio(_p(spec_q), spec_q.stride(0), _p(spec_pool), spec_pool.stride(0), spec_pool.shape[0],
+                                       _p(idx), nq, k, spec_q.shape[1], _p(out), _stream()), "amp_ratio")
     return out
 
 

@@ -1,13 +1,13 @@
 """Oracle: concatenation-smoothness weight optimisation (reference
-ddsp_prematch_dataset.py:574-680 ``compute_wavlm_weight`` and :807-924
-``compute_extended_weight``).  Test infrastructure only."""
+ddsp_prematch_dataset.py:574-680 ``compute_wavlm_weight``, :807-924
+``compute_extended_weight`` and :684-804 ``compute_weight_with_amp``).  Test infrastructure only."""
 from __future__ import annotations
 
 import torch
 
 
 def smooth_weights(idx: torch.Tensor, pool: torch.Tensor, scale: float, max_iter: int = 100000,
-                   return_iters: bool = False):
+                   return_iters: bool = False, row_scale: torch.Tensor | None = None):
     """theta in R^{N x k} from 0; w = softmax(theta); E_s[t] = sum_k w[t,k] pool[clamp(idx[t,k]+s)]
     for s in {-1,0,+1}; loss = mean_t scale*MSE(E_-1[t+1], E_0[t]) + mean_t scale*MSE(E_0[t+1], E_+1[t]).
     Adam(lr .1, betas .9/.999, eps 1e-8, amsgrad).  Every iteration: remember the best theta;
@@ -16,12 +16,18 @@ def smooth_weights(idx: torch.Tensor, pool: torch.Tensor, scale: float, max_iter
 
     scale = 0.1 for WavLM features (wavlm_phase_mae, :460-461), 1000 for harmonics
     (phase_mae, :449-457).  The harmonic variant's extra tanh scaling branch is the
-    identity because scaling_max == scaling_min == 1 (:836-837, 862)."""
+    identity because scaling_max == scaling_min == 1 (:836-837, 862).
+
+    ``row_scale`` [N,k] is compute_weight_with_amp's amp_ratio (:684-713): every gathered row
+    (shift -1, 0, +1) of candidate k of frame t is multiplied by row_scale[t,k] first; that
+    function uses phase_mae, i.e. scale = 1000 (:744-754)."""
     n_pool = len(pool)
     gathered = {}
     for s in (-1, 0, 1):
         j = torch.clamp(idx + s, 0, n_pool - 1)
         gathered[s] = pool[j.reshape(-1)].reshape(idx.shape[0], idx.shape[1], pool.shape[-1])
+        if row_scale is not None:
+            gathered[s] = gathered[s] * row_scale[:, :, None]
     theta = torch.zeros(idx.shape, dtype=torch.float32, requires_grad=True)
     opt = torch.optim.Adam([theta], lr=1e-1, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=True)
     min_loss = 20000

@@ -30,7 +30,7 @@ REF = "/root/reference"
 OUT = ROOT / "tests" / "golden"
 
 from knn_svc_amd import audio_io, config as C, synthetic as S   # noqa: E402
-from oracle import knn_ref, pipeline_ref, select_ref, smooth_ref, synth_ref, vocoder_ref, wavlm_ref  # noqa: E402
+from oracle import knn_ref, pipeline_ref, prematch_ref, select_ref, smooth_ref, synth_ref, vocoder_ref, wavlm_ref  # noqa: E402
 
 
 # ---------------------------------------------------------------- reference import
@@ -377,10 +377,75 @@ def gen_e2e():
     save("g11_e2e", src_seed=81, pool_seed0=82, f0_scale=1.25, duration_limit=7, **res)
 
 
+def gen_prematch():
+    """G12: the reference's per_spk_extract on a two-speaker toy dataset (tiny WavLM).  As committed the function
+    hands (ls_path, device) to get_complete_spk_pool's (device, duration_limit) parameters
+    (ddsp_prematch_dataset.py:1490 vs :301) and raises at the first `.to(device)`; the call is mapped back here
+    and nothing else is touched."""
+    import pickle
+    print("G12 per_spk_extract (prematch) through the reference")
+    cfg = C.WAVLM_TINY
+    sdw = S.seeded_state(S.wavlm_param_spec(cfg), seed=11)
+    m = ref_wavlm(cfg, sdw)
+    tmp = Path(tempfile.mkdtemp())
+    ls, out = tmp / "data", tmp / "cached"
+    spk = {"spkA": [(2 * 16000 + 300, 301), (16000 + 4000, 302), (3 * 16000 + 11, 303)],
+           "spkB": [(2 * 16000 + 64, 311), (2 * 16000 + 900, 312)]}
+    for name, utts in spk.items():
+        (ls / name).mkdir(parents=True)
+        for i, (n, seed) in enumerate(utts):
+            w, f = S.synth_clip(n, seed=seed)
+            audio_io.write_wav_pcm16(str(ls / name / f"u{i}.wav"), w, 16000)
+            np.save(ls / name / f"u{i}_f0.npy", f)
+    onehot = torch.zeros(cfg["encoder_layers"] + 1); onehot[2] = 1
+    weights = onehot[:, None]
+    real_pool = R_dp.get_complete_spk_pool
+
+    def repaired(path, wavlm, match_weights, synth_weights, ls_path_in_device_slot, device_in_limit_slot):
+        return real_pool(path, wavlm, match_weights, synth_weights, device_in_limit_slot)
+    R_dp.get_complete_spk_pool = repaired
+    try:
+        with quiet():
+            R_dp.per_spk_extract(m, "cpu", ls, out, weights, weights, save_pool_only=False)
+    finally:
+        R_dp.get_complete_spk_pool = real_pool
+    res = {}
+    for name, utts in spk.items():
+        files = sorted((ls / name).glob("*.wav"))
+        feats = []
+        for pth in files:
+            w = torch.from_numpy(audio_io.read_wav(str(pth))[0][0])
+            f = torch.from_numpy(np.load(str(pth)[:-4] + "_f0.npy"))
+            feats.append(pipeline_ref.utterance_features(sdw, cfg, w, f, n_layers=2))
+        mine = prematch_ref.extract_speaker(feats)
+        pool = np.load(out / name / "pool.npy")
+        harm = np.load(out / name / "pool_harmonics.npy")
+        eq(pool, mine["pool"], f"{name} pool.npy", tol=2e-3)          # fp16-rounded: one fp16 ulp at |x| < 4 is 2e-3
+        assert float(np.mean(pool != mine["pool"].numpy())) < 1e-3, "pool.npy: fp16 rounding flips should be rare"
+        eq(harm, mine["pool_harmonics"], f"{name} pool_harmonics.npy", tol=1e-6)
+        for i, pth in enumerate(files):
+            with open(out / name / (pth.stem + ".pt"), "rb") as fh:
+                d = pickle.load(fh)
+            it = mine["items"][i]
+            assert tuple(d["slice"]) == it["slice"], (d["slice"], it["slice"])
+            eq(d["nearest_nbrs"], it["nearest_nbrs"], f"{name}/{pth.stem} nearest_nbrs")
+            eq(d["nearest_nbrs_f0_priority"], it["nearest_nbrs_f0_priority"], f"{name}/{pth.stem} f0 priority")
+            eq(d["amp_ratio"], it["amp_ratio"], f"{name}/{pth.stem} amp_ratio", tol=1e-5)
+            eq(d["harmonics_best_weight_para"], it["harmonics_best_weight_para"], f"{name}/{pth.stem} weights", tol=2e-5)
+            for k in ("nearest_nbrs", "nearest_nbrs_f0_priority", "amp_ratio", "harmonics_best_weight_para"):
+                res[f"{name}__{pth.stem}__{k}"] = d[k]
+            res[f"{name}__{pth.stem}__slice"] = np.asarray(d["slice"])
+        res[f"{name}__pool_f16"] = pool.astype(np.float16)            # exact: the values are fp16-representable
+        res[f"{name}__pool_harmonics"] = harm
+        print(f"     {name}: pool {pool.shape}, {len(files)} utterances")
+    save("g12_prematch", speakers=np.array(sorted(spk)), layout=np.array(
+        [f"{n}:{','.join(f'{a}/{b}' for a, b in u)}" for n, u in sorted(spk.items())]), **res)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "select", "smooth", "synth", "vocoder", "e2e"]
+    which = sys.argv[1:] or ["wavlm", "knn", "select", "smooth", "synth", "vocoder", "e2e", "prematch"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

@@ -407,3 +407,69 @@ def test_stft_and_harmonics(golden):
     assert _err(spec, _t(g["spec"]))[0] < 2e-4
     harm = ops.harmonic_amps(_t(g["spec"]).to(DEV), _t(g["f0w"]).to(DEV))
     assert _err(harm, _t(g["harm"]))[0] < 1e-6
+
+
+# ------------------------------------------------------------------ prematch kernels (per_spk_extract)
+@pytest.mark.parametrize("mode", ["f16x2", "fp32"])
+@pytest.mark.parametrize("nq,npool,lo,hi", [(50, 100, 20, 95), (130, 3000, 1000, 1130), (33, 700, 0, 33)])
+def test_knn_self_mask(nq, npool, lo, hi, mode, monkeypatch):
+    """dists[:, start:end] = 1 before topk (ddsp_prematch_dataset.py:1606-1607): masked rows compete at exactly 1;
+    with a pool this small they must show up, in ascending index order (the build's tie rule)."""
+    from oracle import knn_ref
+    monkeypatch.setenv("KNNSVC_KNN", mode)
+    ops = _ops()
+    p = S.clustered_features(npool, 64, 5, n_centres=12)
+    q = p[lo:lo + nq].clone() if hi - lo >= nq else S.clustered_features(nq, 64, 6, n_centres=12)
+    idx, dist = ops.knn_topk(q.to(DEV), p.to(DEV), 32, mask=(lo, hi))
+    idx, dist = idx.cpu(), dist.cpu()
+    d = knn_ref.cosine_dist_all(q, p)
+    d[:, lo:hi] = 1
+    ref = d.topk(k=32, dim=-1, largest=False)
+    assert float((dist - ref.values).abs().max()) < 5e-6
+    masked = (idx >= lo) & (idx < hi)
+    assert bool((dist[masked] == 1.0).all())
+    exact = knn_ref.cosine_dist_f64(q, p)
+    exact[:, lo:hi] = 1.0
+    st = knn_ref.topk_agreement(ref.indices, idx, exact, tau=5e-7)
+    assert st["unexplained"] == 0, st
+    for r in range(nq):                      # ties at exactly 1: lower pool index first
+        m = idx[r][masked[r]]
+        assert bool((m[1:] > m[:-1]).all())
+    if npool == 100:
+        assert int(masked.sum()) > 0          # 5 unmasked rows only: the mask region must fill the list
+
+
+def test_round_f16_and_amp_ratio():
+    from oracle import prematch_ref
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1003, 37, generator=g) * torch.logspace(-9, 5, 37)[None]      # subnormal-fp16 .. overflow range
+    got = ops.round_f16(x.to(DEV)).cpu()
+    assert torch.equal(got, x.half().float())
+    spec_q = torch.rand(211, 200, generator=g) * 3
+    spec_p = torch.rand(1500, 200, generator=g) * 3
+    spec_p[7] = 0                                                                 # silent frame: ratio = L1 / 1e-5
+    idx = torch.randint(0, 1500, (211, 4), generator=g)
+    idx[0, 0] = 7
+    got = ops.amp_ratio(spec_q.to(DEV), spec_p.to(DEV), idx.to(DEV)).cpu()
+    ref = prematch_ref.amp_ratio(spec_q, spec_p, idx)
+    assert float(((got - ref).abs() / ref.abs()).max()) < 2e-6
+
+
+def test_smooth_weights_with_amp_ratio():
+    """compute_weight_with_amp (ddsp_prematch_dataset.py:684-804): the row scale enters the Gram matrices."""
+    from oracle import smooth_ref
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    pool = torch.rand(900, 49, generator=g) * 0.02
+    pool = (pool + torch.roll(pool, 1, 0) + torch.roll(pool, 2, 0)) / 3
+    idx = torch.randint(0, 900, (120, 4), generator=g)
+    idx[5] = torch.tensor([0, 899, 1, 898])                                       # clamped +-1 neighbours
+    ar = torch.rand(120, 4, generator=g) * 2 + 0.3
+    ref, it_ref = smooth_ref.smooth_weights(idx, pool, 1000.0, return_iters=True, row_scale=ar)
+    w, it = ops.smooth_weights(idx.to(DEV), pool.to(DEV), 1000.0, return_iters=True, row_scale=ar.to(DEV))
+    e = _err(w, ref)[0]
+    print("amp-scaled weights max|d|", e, "iters", int(it), "ref", it_ref)
+    assert e < 5e-3 and abs(int(it) - it_ref) <= 100
+    plain = ops.smooth_weights(idx.to(DEV), pool.to(DEV), 1000.0)
+    assert float((plain - w).abs().max()) > 1e-3                                  # the scale is not ignored

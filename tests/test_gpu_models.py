@@ -253,3 +253,49 @@ def test_lane_pipeline_matches_sequential_order():
     torch.cuda.synchronize()
     for (a0, a1, a2), (b0, b1, b2) in zip(seq, par):
         assert torch.equal(a0 * 2.0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
+
+
+def test_prematch_files_match_reference(golden, tmp_path):
+    """per_spk_extract on the GPU writes the reference's files (g12: pool.npy, pool_harmonics.npy, per-utterance
+    pickles with slice / nearest_nbrs / nearest_nbrs_f0_priority / amp_ratio / harmonics_best_weight_para)."""
+    import pickle
+    from knn_svc_amd import prematch
+    from knn_svc_amd.wavlm import WavLMEncoder
+    from tests.prematch_common import write_dataset
+    g = golden("g12_prematch")
+    cfg = C.WAVLM_TINY
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+    lay = write_dataset(tmp_path / "data", g)
+    with torch.inference_mode():
+        prematch.per_spk_extract(enc, DEV, tmp_path / "data", tmp_path / "cached")
+        prematch.per_spk_extract(enc, DEV, tmp_path / "data", tmp_path / "cached")     # second run: existing pickles, same slices
+    rows = same = 0
+    for name, utts in lay.items():
+        pool = np.load(tmp_path / "cached" / name / "pool.npy")
+        ref_pool = g[f"{name}__pool_f16"].astype(np.float32)
+        assert pool.dtype == np.float32 and pool.shape == ref_pool.shape
+        assert np.array_equal(pool, pool.astype(np.float16).astype(np.float32))            # fp16-representable
+        assert float(np.mean(pool != ref_pool)) < 0.02 and float(np.abs(pool - ref_pool).max()) <= 4e-3
+        harm = np.load(tmp_path / "cached" / name / "pool_harmonics.npy")
+        assert float(np.abs(harm - g[f"{name}__pool_harmonics"]).max()) < 1e-5
+        for i in range(len(utts)):
+            with open(tmp_path / "cached" / name / f"u{i}.pt", "rb") as fh:
+                d = pickle.load(fh)
+            assert set(d) == {"slice", "nearest_nbrs", "nearest_nbrs_f0_priority", "harmonics_best_weight_para", "amp_ratio"}
+            assert tuple(d["slice"]) == tuple(g[f"{name}__u{i}__slice"])
+            nn, ref_nn = d["nearest_nbrs"], g[f"{name}__u{i}__nearest_nbrs"]
+            assert nn.dtype == np.int64 and nn.shape == ref_nn.shape
+            s, e = d["slice"]
+            assert not np.any((nn >= s) & (nn < e)), "own-utterance rows must lose against the rest of the pool here"
+            ok = np.all(nn[:, :4] == ref_nn[:, :4], axis=1) & \
+                np.all(d["nearest_nbrs_f0_priority"][:, :4] == g[f"{name}__u{i}__nearest_nbrs_f0_priority"][:, :4], axis=1)
+            rows += len(ok); same += int(ok.sum())
+            assert float(np.mean([set(a) == set(b) for a, b in zip(nn, ref_nn)])) > 0.9
+            ar, ref_ar = d["amp_ratio"], g[f"{name}__u{i}__amp_ratio"]
+            assert float(np.abs(ar[ok] - ref_ar[ok]).max() / np.abs(ref_ar).max()) < 1e-4
+            w = d["harmonics_best_weight_para"]
+            assert w.shape == ref_ar.shape and abs(float(w.sum(1).mean()) - 1) < 1e-5
+            if ok.all():
+                assert float(np.abs(w - g[f"{name}__u{i}__harmonics_best_weight_para"]).max()) < 5e-3
+    print(f"prematch: {same}/{rows} frames with identical first-4 neighbours (plain and f0-priority)")
+    assert same >= 0.97 * rows
