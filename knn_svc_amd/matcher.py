@@ -48,11 +48,19 @@ class KNeighborsVC:
             outs.append(self.hifigan.forward(c[b].to(self.device).float(), f0[b].reshape(-1).to(self.device).float(),
                                              None if harm is None else harm.to(self.device).float()))
         wav = torch.stack(outs, 0)
+        self._check_finite(wav)
+        return wav
+
+    @staticmethod
+    def _check_finite(wav):
         # the emulated-fp32 GEMMs turn an out-of-range activation into NaN instead of a wrong sample: surface it
         if not bool(torch.isfinite(wav).all()):
             raise ops.KnnSvcError("vocode: non-finite waveform (activation outside the f16x2 range, or non-finite input); "
                                   "re-run with KNNSVC_GEMM=bf16x3")
-        return wav
+
+    def _vocode_async(self, c, f0, harm=None):
+        """One utterance, enqueue only (no host sync): the tail stage of the dataset-mode pipeline."""
+        return self.hifigan.forward(c.float(), f0.reshape(-1).float(), None if harm is None else harm.float())
 
     @torch.inference_mode()
     def special_match(self, src_wav_file, ref_wav_file, topk: int = 4, device=None, prioritize_f0=True,
@@ -107,16 +115,18 @@ class KNeighborsVC:
                 common = dict(topk=topk, device=self.device, prioritize_f0=prioritize_f0, ckpt_type=ckpt_type,
                               src_dataset_path=src_dataset_path, tgt_dataset_path=tgt_dataset_path,
                               required_subset=required, duration_limit=duration_limit)
+                # the generator of every utterance is the tail stage of the match pipeline (same kernels and inputs as
+                # `vocode` after the fact, ddsp_matcher.py:1114-1128, but enqueued under the next utterances' matching);
+                # one finiteness check per speaker pair instead of one host sync per utterance
                 preds = {}
                 if not f0only:
-                    of, hw, _a, sf0 = match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting,
-                                                              post_opt=post_opt, **common)
-                    for k in of:
-                        preds[k] = self.vocode(of[k][None], sf0[k][None, :, None], hw[k][None]).squeeze()
+                    match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting, post_opt=post_opt,
+                                            vocode_fn=self._vocode_async, waves_out=preds, **common)
                 else:
-                    of, _a, sf0 = match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting, **common)
-                    for k in of:
-                        preds[k] = self.vocode(of[k][None], sf0[k][None, :, None]).squeeze()
+                    match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting,
+                                            vocode_fn=lambda c, f0, _h: self._vocode_async(c, f0), waves_out=preds, **common)
+                if preds:      # max |x| of a waveform is NaN / inf iff the waveform holds one
+                    self._check_finite(torch.stack([p.abs().max() for p in preds.values()]))
                 for k, pred in preds.items():
                     out = os.path.join(converted_audio_dir, os.path.basename(s), os.path.basename(k).split(".")[0],
                                        os.path.basename(t) + "." + os.path.basename(k).split(".")[-1])

@@ -222,10 +222,15 @@ def _layer_of(weights) -> int:
 def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, match_weights=None, synth_weights=None,
                             topk: int = 4, device="cuda", prioritize_f0=False, ckpt_type="wavlm_only",
                             src_dataset_path=None, tgt_dataset_path=None, cache_dir=None, required_subset=None,
-                            post_opt="no_post_opt", duration_limit=None):
+                            post_opt="no_post_opt", duration_limit=None, vocode_fn=None, waves_out=None):
     """Same contract as the reference function (ddsp_prematch_dataset.py:1074).  ``topk`` is accepted and
     ignored (k = 32 -> 4 is hard-coded upstream, :1203,1246,1398); ``cache_dir`` is ignored (the reference
-    force-disables it, :1086-1087)."""
+    force-disables it, :1086-1087).
+
+    Build extension (BASELINE cfg 5, many sources against one pool): ``vocode_fn(out_feats, shifted_f0, harm)`` is
+    enqueued as the pipeline's tail stage right behind each item's match body and its waveform stored in
+    ``waves_out[item]`` — the generator of item i then runs underneath the kNN / recurrences of items i+1.., instead
+    of after all of them.  It must not synchronise with the host."""
     assert prioritize_f0, "prioritize_f0=False is unsupported by the reference (ddsp_prematch_dataset.py:1375)"
     if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type and "mix" not in ckpt_type:
         raise NotImplementedError(ckpt_type)
@@ -255,7 +260,15 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
                                        harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep)
     lanes = min(3, len(items))
-    results = pipeline.LanePipeline(matching_list.device, lanes).run(items, body) if lanes > 1 else [body(i) for i in items]
+    if vocode_fn is not None and len(items) > 0:
+        assert waves_out is not None
+        tail = lambda item, r: r + (vocode_fn(r[0], r[2], r[1]),)
+        results = pipeline.LanePipeline(matching_list.device, max(1, lanes)).run(items, body, tail)
+        for item, r in zip(items, results):
+            waves_out[item] = r[3]
+        results = [r[:3] for r in results]
+    else:
+        results = pipeline.LanePipeline(matching_list.device, lanes).run(items, body) if lanes > 1 else [body(i) for i in items]
     for f in flags:
         ops.raise_if_nan(f)
     for item, (of, hw, sf0) in zip(items, results):

@@ -299,3 +299,39 @@ def test_prematch_files_match_reference(golden, tmp_path):
                 assert float(np.abs(w - g[f"{name}__u{i}__harmonics_best_weight_para"]).max()) < 5e-3
     print(f"prematch: {same}/{rows} frames with identical first-4 neighbours (plain and f0-priority)")
     assert same >= 0.97 * rows
+
+
+def test_bulk_match_pipelined_vocoder_equals_sequential(tmp_path, monkeypatch):
+    """Dataset mode with several utterances per speaker: the pipelined order (match bodies on lanes, generator as the
+    tail stage, one pool preparation per pair) writes the same bytes as running every stage of every utterance in
+    sequence on one stream."""
+    from knn_svc_amd import matching, pipeline, pool_cache
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+    knn = KNeighborsVC(enc, Vocoder(S.seeded_state(S.generator_param_spec(h, "mix"), 63), h, "mix", DEV), h, DEV)
+    root = tmp_path / "data"
+    for s, spk in enumerate(("spkA", "spkB")):
+        (root / spk).mkdir(parents=True)
+        for u in range(4):
+            w, f = S.synth_clip(16000 + 320 * (3 * s + u), seed=400 + 10 * s + u)
+            audio_io.write_wav_pcm16(str(root / spk / f"u{u}.wav"), w, 16000)
+            np.save(root / spk / f"u{u}_f0.npy", f)
+    matching._POOL_CACHE = pool_cache.PoolCache()
+    w1 = knn.bulk_match(str(root), str(root), str(tmp_path / "o1"), ckpt_type="mix", post_opt="post_opt_0.2")
+    assert len(w1) == 8
+
+    def sequential(self, items, head, tail=None):
+        out = []
+        for it in items:
+            r = head(it)
+            out.append(tail(it, r) if tail is not None else r)
+        return out
+    monkeypatch.setattr(pipeline.LanePipeline, "run", sequential)
+    w2 = knn.bulk_match(str(root), str(root), str(tmp_path / "o2"), ckpt_type="mix", post_opt="post_opt_0.2")
+    for a, b in zip(sorted(w1), sorted(w2)):
+        xa, _ = audio_io.read_wav(a); xb, _ = audio_io.read_wav(b)
+        assert xa.shape == xb.shape and np.array_equal(xa, xb)
+    matching._POOL_CACHE = None
