@@ -53,7 +53,8 @@ class GemmTimer:
         self.records = []
         self.enabled = False
         self.all_variants = False
-        self.dominant = {"f16x2": "F128", "bf16x3": "H128", "fp32": "G128v8"}[ops.gemm_mode()]
+        # both instantiations of conv_gemm2_kernel<Gemm2Tile<128,128,...>> (A fp32 / A pre-split) count as the dominant kernel
+        self.dominant = {"f16x2": ("F128", "F128a2"), "bf16x3": ("H128",), "fp32": ("G128v8",)}[ops.gemm_mode()]
         self.dom_bytes = 0
         self._orig = ops.conv_gemm
 
@@ -61,40 +62,27 @@ class GemmTimer:
         orig = self._orig
 
         def wrapped(x, w, out, **kw):
-            vec4 = kw["cin"] % 4 == 0 and (kw.get("ldx") or kw["cin"]) % 4 == 0
-            big = kw["n"] > 64 and vec4 and kw["cin"] % 32 == 0
-            if not (self.enabled and (big or self.all_variants)):
+            if not self.enabled:
                 return orig(x, w, out, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(x, w, out, **kw)
             e1.record()
-            flop = 2.0 * kw["m"] * kw["n"] * kw["cin"] * kw.get("taps", 1) * kw.get("batches", 1) * kw.get("groups", 1)
-            ldx = kw.get("ldx") or kw["cin"]
-            t_in = kw.get("t_in") or kw["m"]
+            var = ops.last_conv_kernel()          # the library says which kernel it dispatched (F128a2, W64, G128v8, ...)
+            if not (var in self.dominant or self.all_variants):
+                return r
+            z = kw.get("batches", 1) * kw.get("groups", 1)
             K = kw["cin"] * kw.get("taps", 1)
-            fast = vec4 and kw["cin"] % 32 == 0 and t_in * ldx * 4 < 2 ** 30 and kw["n"] * K * 4 < 2 ** 30 \
-                and kw["m"] * kw.get("stride", 1) * ldx * 4 < 2 ** 30
-            tile = "128" if kw["n"] > 64 else "64" if kw["n"] > 32 else "32"
-            if fast and getattr(w, "_w2", None) is not None:
-                var = "F" + tile                      # conv_gemm2_kernel: fp32 emulated with three fp16 MFMAs
-                z = kw.get("batches", 1) * kw.get("groups", 1)
-                kmin = os.environ.get("KNNSVC_F256_KMIN")
-                if kmin and kw["n"] % 256 == 0 and K >= max(2048, int(kmin)) and -(-kw["m"] // 256) * (kw["n"] // 256) * z >= 384:
-                    var = "F256"                      # opt-in conv_gemm2big_kernel (see conv_gemm.hip)
-            elif fast and getattr(w, "_w3", None) is not None:
-                var = "H" + tile                      # conv_gemm3_kernel: fp32 emulated with six bf16 MFMAs
-            else:
-                var = "G" + tile + ("v8" if fast else "v4" if vec4 else "v1")
-            self.records.append((e0, e1, flop, (kw["m"], kw["n"], kw["cin"] * kw.get("taps", 1), kw.get("batches", 1) * kw.get("groups", 1)), var))
-            if var == self.dominant:      # algorithmic floats moved: A read once (not im2col-expanded) + W + output
-                z = kw.get("batches", 1) * kw.get("groups", 1)
+            flop = 2.0 * kw["m"] * kw["n"] * K * z
+            t_in = kw.get("t_in") or kw["m"]
+            self.records.append((e0, e1, flop, (kw["m"], kw["n"], K, z), var))
+            if var in self.dominant:      # algorithmic floats moved: A read once (not im2col-expanded) + W + output
                 self.dom_bytes += z * (t_in * kw["cin"] + kw["n"] * K + kw["m"] * kw["n"])
             return r
         ops.conv_gemm = wrapped
 
     def summary(self):
-        dom = [r for r in self.records if r[4] == self.dominant]
+        dom = [r for r in self.records if r[4] in self.dominant]
         ms = sum(r[0].elapsed_time(r[1]) for r in dom)
         fl = sum(r[2] for r in dom)
         return len(dom), ms, fl
@@ -340,7 +328,7 @@ def main():
             "F128": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2_kernel<Gemm2Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 3 fp16 MFMAs)"),
             "H128": (BF16X3_PEAK_TFLOPS, 6, "conv_gemm3_kernel<Gemm3Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 6 bf16 MFMAs)"),
             "G128v8": (FP32_MFMA_PEAK_TFLOPS, 1, "conv_gemm_kernel<GemmTile<128,128,2,2,2,2>, 8> (implicit GEMM on v_mfma_f32_32x32x2_f32)"),
-        }[timer.dominant]
+        }[timer.dominant[0]]
         line = {
             "metric": "audio-sec converted/sec (xRT) end-to-end, cold target pool",
             "value": round(value, 3), "unit": "x real-time", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,

@@ -35,6 +35,9 @@ extern "C" {
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
+/* Short tag of the kernel the calling thread's last knnsvc_conv_gemm dispatched to ("F128a2", "W64", "G128v8", ...):
+ * measurement hook (bench.py attributes HIP-event times to kernels with it); "" before the first call. */
+const char* knnsvc_conv_gemm_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer on fp32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -7,6 +7,8 @@
 
 namespace {
 
+thread_local const char* g_last_kernel = "";      // which kernel the last knnsvc_conv_gemm of this thread launched
+
 struct ConvArgs {
     const float* x; long x_bstride, x_gstride; int ldx, t_in, cin, taps, stride, dil, pad; float a_slope;
     const float* w; long w_gstride; int n;
@@ -282,7 +284,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
                 if (rz) v += rv[r];
                 if (a.accumulate) v += av[r];
                 if (a.div != 1.0f) v = v / a.div;
+#ifdef KN_WHATIF_NOSTORE
+                if (v == 123456.789f) oz[orow * a.ldo + col] = v;      // timing-only build: keeps the value live, stores nothing
+#else
                 oz[orow * a.ldo + col] = v;
+#endif
             }
         }
     }
@@ -376,6 +382,57 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     conv_epilogue<G>(a, acc, m0, n0, b, g);
 }
 
+// stride-1 multi-tap convolutions: one window of BM + HALO input rows per 32-channel slab, every tap reads it shifted
+// (gemm2_core.h, Gemm2Win)
+template <class G, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm2win_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
+    const int gx8 = (int)gridDim.x / gy;
+    constexpr int CW = 8;
+    int L = blockIdx.x;
+    const int full = (gy / CW) * CW * gx8;
+    int c0, cw;
+    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
+    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
+    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
+    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
+    if (m0 >= a.m) return;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
+
+    typename G::acc_t acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < G::NR; ++r) acc[i][j][r] = 0.f;
+    Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
+    const int tid = threadIdx.x;
+    const int w_off0 = ((m0 - a.pad + (tid >> 3)) * a.ldx + (tid & 7) * 4) * 4;
+    G::mainloop(lds, a.cin / 32, a.taps, a.dil, w_off0, a.ldx * 4, bl, acc, FastALoader<1>::desc(a, xz),
+                Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale, a.a_slope);
+    conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G, int MINB>
+int launch2win(const ConvArgs& a, int batches, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm2win_kernel<G, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
+    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2win_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm2win");
+}
+
 // A2 activations + split weights, both by LDS-DMA (gemm2_core.h, Gemm2Dma)
 template <class G>
 __global__ __launch_bounds__(256, 2) void conv_gemm2dma_kernel(ConvArgs a) {
@@ -430,6 +487,62 @@ int launch2dma(const ConvArgs& a, int batches, hipStream_t st) {
     dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm2dma_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2dma");
+}
+
+// A2 activations + split weights by LDS-DMA through a ring of half-slab stages (gemm2_core.h, Gemm2Ring)
+template <class G, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm2ring_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
+    const int gx8 = (int)gridDim.x / gy;
+    constexpr int CW = 8;
+    int L = blockIdx.x;
+    const int full = (gy / CW) * CW * gx8;
+    int c0, cw;
+    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
+    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
+    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
+    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
+    if (m0 >= a.m) return;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
+    auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
+    // wave-uniform walk over (tap, channel): 128 bytes per slab inside a tap, then on to the next tap's first channel
+    int c_in_tap = 0, uoff = 0;
+    const int cin = a.cin, step_tap = (a.dil * a.ldx - a.cin) * 4;
+    auto step = [&](int kt) -> int {
+        if (kt > 0) { c_in_tap += 32; uoff += 128; if (c_in_tap == cin) { c_in_tap = 0; uoff += step_tap; } }
+        return uoff;
+    };
+    G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
+                a.n, a.K, m0, n0, acc);
+    conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
+template <class G, int MINB>
+int launch2ring(const ConvArgs& a, int batches, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm2ring_kernel<G, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
+    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2ring_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm2ring");
 }
 
 template <class G>
@@ -562,6 +675,12 @@ using F64 = Gemm2Tile<256, 64, 4, 1, 2, 2>;
 using F32 = Gemm2Tile<256, 32, 4, 1, 2, 1>;
 using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
 using D128 = Gemm2Dma<128, 128, 2, 2, 2, 2>;
+using R128 = Gemm2Ring<128, 128, 2, 2, 2, 2>;
+using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
+using W64 = Gemm2Win<256, 64, 4, 1, 2, 2, 64>;        // 320 rows (45 KB) + 9 KB
+using W32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // 320 rows + 4.5 KB
+using W64P = Gemm2Win<256, 64, 4, 1, 2, 2, 128>;      // k = 128 positional conv: 384 rows (54 KB) + 9 KB
+
 
 template <class G>
 int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
@@ -649,28 +768,48 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         if (d->n >= 256 && d->n % 256 == 0 && a.K >= 2048) {
             const char* e = getenv("KNNSVC_F256_KMIN");
             if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
-                return launch2big<F256>(a, d->batches, st);
+                { g_last_kernel = "F256"; return launch2big<F256>(a, d->batches, st); }
         }
         if (d->n > 64 && a.x_split) {
             // Opt-in (KNNSVC_DMA=1): both operands by LDS-DMA, double-buffered, 2 blocks/CU.  Measured 252 vs 275 TFLOP/s
             // for the register-staged A2 kernel on FFN1: with one slab of prefetch the vmcnt(0) + barrier at the end
             // of every slab exposes the DMA latency; it needs a 3-stage ring (1 block/CU) to pay.
             const char* e = getenv("KNNSVC_DMA");
-            if (e && e[0] == '1') return launch2dma<D128>(a, d->batches, st);
+            if (e && e[0] == '1') { g_last_kernel = "D128"; return launch2dma<D128>(a, d->batches, st); }
+            const char* r = getenv("KNNSVC_RING");
+            if (r && r[0] == '1') { g_last_kernel = "R128"; return launch2ring<R128, 3>(a, d->batches, st); }
+
         }
+        // stride-1 multi-tap convolutions on fp32 input: windowed kernel (A staged once per channel slab, not once per tap)
+        if (!a.x_split && !d->convt_u && d->stride == 1 && d->taps >= 3 && d->dil >= 1 && d->ldx % 4 == 0) {
+            static const bool win_on = [] { const char* e = getenv("KNNSVC_WIN"); return !(e && e[0] == '0'); }();
+            const int halo = (d->taps - 1) * d->dil;
+            if (win_on && halo <= 64) {
+                if (d->n > 64) { g_last_kernel = "W128"; return launch2win<W128, 3>(a, d->batches, st); }
+                if (d->n > 32) { g_last_kernel = "W64"; return launch2win<W64, 2>(a, d->batches, st); }
+                g_last_kernel = "W32";
+                return launch2win<W32, 3>(a, d->batches, st);
+            }
+            if (win_on && halo <= 128 && d->n > 32 && d->n <= 64) { g_last_kernel = "W64P"; return launch2win<W64P, 2>(a, d->batches, st); }
+        }
+        g_last_kernel = d->n > 64 ? (a.x_split ? "F128a2" : "F128") : d->n > 32 ? "F64" : "F32";
         if (d->n > 64) return launch2<F128>(a, d->batches, st);
         if (d->n > 32) return launch2<F64>(a, d->batches, st);
         return launch2<F32>(a, d->batches, st);
     }
     if (fast && a.w3) {        // fp32 emulated on the bf16 matrix cores (gemm3_core.h)
+        g_last_kernel = d->n > 64 ? "H128" : d->n > 32 ? "H64" : "H32";
         if (d->n > 64) return launch3<H128>(a, d->batches, st);
         if (d->n > 32) return launch3<H64>(a, d->batches, st);
         return launch3<H32>(a, d->batches, st);
     }
+    g_last_kernel = d->n > 64 ? (fast ? "G128v8" : vec4 ? "G128v4" : "G128v1") : d->n > 32 ? (fast ? "G64v8" : vec4 ? "G64v4" : "G64v1") : (fast ? "G32v8" : vec4 ? "G32v4" : "G32v1");
     if (d->n > 64) return fast ? launch<G128, 8>(a, d->batches, st) : vec4 ? launch<G128, 4>(a, d->batches, st) : launch<G128, 1>(a, d->batches, st);
     if (d->n > 32) return fast ? launch<G64, 8>(a, d->batches, st) : vec4 ? launch<G64, 4>(a, d->batches, st) : launch<G64, 1>(a, d->batches, st);
     return fast ? launch<G32, 8>(a, d->batches, st) : vec4 ? launch<G32, 4>(a, d->batches, st) : launch<G32, 1>(a, d->batches, st);
 }
+
+extern "C" const char* knnsvc_conv_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* out, void* stream) {
     KN_REQUIRE(w && out && rows > 0 && K > 0 && K % 32 == 0, "split_weight: K must be a positive multiple of 32");

@@ -479,3 +479,265 @@ struct Gemm2Dma {
         return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
     }
 };
+
+// -------------------------------------------------------------------------------------------------
+// Ring variant of the DMA-fed kernel: K advances in HALF slabs of 16 (64 bytes per operand row: 32 B of the hi
+// plane + 32 B of the lo plane), staged in a ring of STAGES buffers with TWO half-slabs of prefetch.  At 128x128 a
+// stage is 16 KB and the ring 48 KB, so three blocks still fit a CU (the double-buffered 32-wide Gemm2Dma holds two
+// and exposes its DMA latency at the end of every slab).  One barrier per half slab, 12 MFMAs per wave between two.
+//   image: row r = 64 bytes = 4 pieces of 16 B (hi k 0-7, hi k 8-15, lo k 0-7, lo k 8-15); piece q sits in slot
+//   q ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then cover
+//   all 64 banks exactly once.  DMA instruction c of a stage fills rows 16c..16c+15 (lane L -> row 16c + L/4,
+//   slot L%4) and applies the swizzle through its per-lane SOURCE offset.
+//   schedule: iteration s issues the DMA of half slab s+2 into the stage that was read in iteration s-1 (every wave
+//   is past that iteration's barrier), computes half slab s, waits with vmcnt(#pieces of s+2) for its own pieces of
+//   s+1, barrier.
+// -------------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_, int STAGES_ = 3>
+struct Gemm2Ring {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_, STAGES = STAGES_;
+    static constexpr int BK = 16, ROW = 64, NW = WM * WN, THREADS = 64 * NW;
+    static_assert(NW == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    static constexpr int A_DMA = BM * ROW / 1024 / NW;         // LDS-DMA instructions per wave per half slab
+    static constexpr int B_DMA = BN * ROW / 1024 / NW;
+    static_assert(A_DMA * 1024 * NW == BM * ROW && B_DMA * 1024 * NW == BN * ROW, "whole DMA pieces");
+    static constexpr int PER = A_DMA + B_DMA;
+    static_assert(PER < 16, "vmcnt immediate");
+    static constexpr int BOFF = BM * ROW;
+    static constexpr int STAGE = (BM + BN) * ROW;
+    static constexpr int LDS_BYTES = STAGES * STAGE;
+    static constexpr int OOB_OFF = 0x40000000;
+
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) void lds_v;
+    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
+
+    // a_row_off(m): byte offset of row m's first channel in the A buffer resource, or OOB_OFF; a_step(kt): wave-uniform
+    // byte offset of the 32-channel slab kt (stateful: called once per kt, in order)
+    template <class RowOff, class Step, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
+                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 31, lh = lane >> 5;
+        const int swz = (li >> 2) & 3;
+        const int a_row = (wm * TM * 32 + li) * ROW;
+        const int b_row = BOFF + (wn * TN * 32 + li) * ROW;
+        int x_off[2];                                              // [plane]: swizzled slot of this lane's k-half
+#pragma unroll
+        for (int p = 0; p < 2; ++p) x_off[p] = ((p * 2 + lh) ^ swz) * 16;
+        int a_src[A_DMA], b_src[B_DMA];
+        const int row_bytes = (K / 32) * 128;
+#pragma unroll
+        for (int t = 0; t < A_DMA; ++t) {
+            const int row = (wave * A_DMA + t) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((row >> 2) & 3);
+            const int ro = a_row_off(m0 + row);
+            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (q >> 1) * 64 + (q & 1) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < B_DMA; ++t) {
+            const int row = (wave * B_DMA + t) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((row >> 2) & 3);
+            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (q >> 1) * 64 + (q & 1) * 16 : OOB_OFF;
+        }
+        const int ns = 2 * nk;
+        int u_cur = 0;                                             // byte offset of the 32-channel slab being issued
+        int issued = 0;                                            // half slabs issued so far
+        // the slab offset of A travels in the VGPR offset (the range check ignores soffset and conv padding relies on it)
+#define KN_ISSUE(STG)                                                                                                     \
+    {                                                                                                                     \
+        if ((issued & 1) == 0) u_cur = a_step(issued >> 1);                                                               \
+        const int ua = u_cur + (issued & 1) * 32, ub = (issued >> 1) * 128 + (issued & 1) * 32;                           \
+        _Pragma("unroll") for (int t = 0; t < A_DMA; ++t)                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_desc, (lds_v*)(lds + (STG) + (wave * A_DMA + t) * 1024), 16, a_src[t] + ua, 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < B_DMA; ++t)                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + (STG) + BOFF + (wave * B_DMA + t) * 1024), 16, b_src[t], ub, 0, 0); \
+        ++issued;                                                                                                         \
+    }
+        int st_cur = 0, st_n1 = STAGE, st_n2 = 2 * STAGE;
+        KN_ISSUE(st_cur)
+        if (ns > 1) { KN_ISSUE(st_n1) }
+        if (ns > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        for (int s = 0; s < ns; ++s) {
+            if (s + 2 < ns) { KN_ISSUE(st_n2) }
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 fa[TM][2], fb[TN][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    fa[i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + st_cur + a_row + i * 32 * ROW + x_off[p]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    fb[j][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + st_cur + b_row + j * 32 * ROW + x_off[p]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], c, 0, 0, 0);   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < ns) {                 // this wave's pieces of half slab s+1 have landed (those of s+2 may still fly)
+                if (s + 2 < ns) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            __syncthreads();
+            const int t = st_cur; st_cur = st_n1; st_n1 = st_n2; st_n2 = t;
+        }
+#undef KN_ISSUE
+    }
+
+    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
+        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
+        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
+    }
+};
+
+// -------------------------------------------------------------------------------------------------
+// Windowed variant for stride-1 convolutions with several taps (HiFi-GAN ResBlock convs k = 3/7/11 with dilation,
+// WavLM's k = 128 positional conv).  The implicit-GEMM kernels above walk K tap-major and re-stage, for every tap, the
+// same input rows shifted by `dil` (a what-if build without A staging ran the generator in 7.6 instead of 10.0 ms).
+// Here K is walked CHANNEL-SLAB-major: for each slab of 32 input channels the block stages ONE window of
+// BM + HALO input rows (fp32 -> f16x2 split, 144-byte pitch as Gemm2Tile) and every tap reads its A fragments from
+// that window at a row offset of tap * dil — A is staged once instead of `taps` times and only the weights stream.
+// The next slab's window travels in registers during the tap loop (W_F4 float4 per thread).  Sums over K are taken in
+// a different order than in Gemm2Tile (slab-major instead of tap-major): equal up to fp32 rounding of the accumulation.
+// -------------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_, int HALO_>
+struct Gemm2Win {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_, HALO = HALO_;
+    static constexpr int BK = 32, PITCH = 144, THREADS = 256;
+    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN && HALO % 32 == 0, "tile shape");
+    static constexpr int WR = BM + HALO;                       // window rows
+    static constexpr int W_F4 = WR / 32;                       // fp32 float4 per thread per window
+    static constexpr int B_PIECES = BN * 8;
+    static constexpr int B_P = (B_PIECES + 255) / 256;
+    static constexpr int BOFF = WR * PITCH;
+    static constexpr int LDS_BYTES = (WR + BN) * PITCH;
+
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
+    typedef __attribute__((address_space(3))) g2_u32x2 lds_u2;
+
+    // w_off0: this thread's byte offset of (window row tid>>3, channel (tid&7)*4) in the A buffer resource (may be
+    // "negative": conv padding rows fall outside the resource and read as zeros); row_bytes = ldx * 4.
+    // bload: Split2BLoader; slab index of (tap, cs) in the tap-major weight image = tap * ncs + cs.
+    template <class BLoad, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int ncs, int taps, int dil, int w_off0, int row_bytes,
+                                                    BLoad& bload, f32x16 (&acc)[TM][TN], RA ra_desc, RB rb_desc,
+                                                    float a_scale, float a_slope) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int w_st = (tid >> 3) * PITCH + (tid & 7) * 8;
+        const int li = lane & 31, lh = lane >> 5;
+        const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
+        const int b_frag = BOFF + (wn * TN * 32 + li) * PITCH + lh * 16;
+        const int tap_step = dil * PITCH;
+
+        f32x4 rw[W_F4];
+        g2_u32x4 rb[B_P];
+#define KN_LOAD_W(CS)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < W_F4; ++j)                                                          \
+        rw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_desc, w_off0 + j * 32 * row_bytes + (CS) * 128, 0, 0));
+#define KN_STAGE_W()                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < W_F4; ++j) {                                                        \
+        f32x4 v = rw[j];                                                                                      \
+        if (a_slope != 1.0f) { _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a_slope; } \
+        g2_u32x2 hi, lo;                                                                                      \
+        f16x2_split4(v, a_scale, hi, lo);                                                                     \
+        *(lds_u2*)(lds + w_st + 32 * j * PITCH) = hi;                                                         \
+        *(lds_u2*)(lds + w_st + 32 * j * PITCH + 64) = lo;                                                    \
+    }
+#define KN_LOAD_B(SLAB)                                                                                        \
+    { bload.begin(SLAB); _Pragma("unroll") for (int j = 0; j < B_P; ++j) rb[j] = bload(SLAB, j, rb_desc); }
+#define KN_STAGE_B()                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < B_P; ++j) {                                                         \
+        const int q = tid + 256 * j;                                                                          \
+        if (B_PIECES % 256 == 0 || q < B_PIECES) *(lds_u4*)(lds + BOFF + (q >> 3) * PITCH + (q & 7) * 16) = rb[j]; \
+    }
+#ifdef KN_WIN_ROT
+        const int rot = (int)(blockIdx.x % (unsigned)ncs);
+#define KN_CS(I) (((I) + rot) % ncs)
+#else
+#define KN_CS(I) (I)
+#endif
+        KN_LOAD_W(KN_CS(0))
+        KN_LOAD_B(KN_CS(0))
+        KN_STAGE_W()
+        KN_STAGE_B()
+        __syncthreads();
+        for (int ci = 0; ci < ncs; ++ci) {
+            const bool more_cs = ci + 1 < ncs;
+            const int cs = KN_CS(ci);
+            if (more_cs) { KN_LOAD_W(KN_CS(ci + 1)) }
+            int tap_off = 0;
+            for (int tap = 0; tap < taps; ++tap, tap_off += tap_step) {
+                const bool last_tap = tap + 1 == taps;
+                const bool more = !last_tap || more_cs;
+                if (more) {
+                    const int slab = last_tap ? KN_CS(ci + 1) : ((tap + 1) * ncs + cs);
+                    KN_LOAD_B(slab)
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    f16x8 fa[TM][2], fb[TN][2];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            fa[i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + a_frag + tap_off + i * 32 * PITCH + p * 64 + ks * 32));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            fb[j][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + b_frag + j * 32 * PITCH + p * 64 + ks * 32));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            f32x16 c = acc[i][j];
+#ifdef KN_WHATIF_NOMFMA
+                            c[0] += (float)fa[i][1][0] * (float)fb[j][0][0] + (float)fa[i][0][1] * (float)fb[j][1][1];
+#else
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], c, 0, 0, 0);   // small terms first
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], c, 0, 0, 0);
+#endif
+                            acc[i][j] = c;
+                        }
+                }
+                __syncthreads();                 // every wave is done with this weight slab (and, on the last tap, the window)
+                if (more) { KN_STAGE_B() }
+                if (last_tap && more_cs) { KN_STAGE_W() }
+                __syncthreads();
+            }
+        }
+#undef KN_CS
+#undef KN_LOAD_W
+#undef KN_STAGE_W
+#undef KN_LOAD_B
+#undef KN_STAGE_B
+    }
+
+    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
+        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
+        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
+    }
+};
