@@ -90,12 +90,16 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     files = list_audio(path)
     cache = _pool_cache()
     tag = (wavlm.uid, wavlm.n_layers)
+    dtag = (wavlm.weights_fingerprint(), wavlm.n_layers) if cache.disk_dir else None     # on-disk tier: content identity
+    dkeys = {}
     kept, keys, Ts = [], [], []
     loaded = {}                       # index -> (wav on device, f0 host) for files that miss the cache
     dur = 0.0
     for i, pth in enumerate(files):
         key = pool_cache.file_key(pth, tag)
-        ent = cache.get(key)
+        if dtag is not None:
+            dkeys[key] = pool_cache.file_key(pth, dtag)
+        ent = cache.get(key, dkeys.get(key), dev)
         if ent is not None:
             T = ent["feats"].shape[0]
         else:
@@ -111,7 +115,7 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     for i, ft in zip(miss, feats):
         assert ft.shape[0] == Ts[i]
         f0, harm, spec = side_features(loaded[i][0], loaded[i][1], Ts[i])
-        cache.put(keys[i], dict(feats=ft, f0=f0, harm=harm, spec=spec))
+        cache.put(keys[i], dict(feats=ft, f0=f0, harm=harm, spec=spec), dkeys.get(keys[i]))
         loaded[i] = dict(feats=ft, f0=f0, harm=harm, spec=spec)
     matching, synth, audio, specs, f0p, harmp = {}, {}, {}, {}, {}, {}
     for i, key in enumerate(kept):

@@ -8,11 +8,20 @@ one entry per audio file, keyed by the file's identity (absolute path, size, mti
 that produced it, evicted least-recently-used beyond a byte budget.
 
     KNNSVC_POOL_CACHE_GB   budget in GiB (default 64, 0 disables the store)
+    KNNSVC_POOL_CACHE_DIR  optional on-disk tier: one uncompressed ``<sha1>.npz`` per audio file (feats, f0, harm, spec
+                           as float32), keyed by the file's identity and a fingerprint of the encoder WEIGHTS, so a
+                           second process (or a second run) encodes nothing it has seen before.  This is the cache the
+                           reference sketched and force-disabled (ddsp_prematch_dataset.py:1086-1134: a pickle of the
+                           whole pool per path); entries here are per file, written atomically, and never trusted
+                           across a change of the audio, its f0 track, the weights or the exit layer.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 from collections import OrderedDict
+
+FIELDS = ("feats", "f0", "harm", "spec")
 
 
 def file_key(path, encoder_tag) -> tuple:
@@ -24,10 +33,12 @@ def file_key(path, encoder_tag) -> tuple:
 
 
 class PoolCache:
-    def __init__(self, budget_bytes: int | None = None):
+    def __init__(self, budget_bytes: int | None = None, disk_dir: str | None = None):
         if budget_bytes is None:
             budget_bytes = int(float(os.environ.get("KNNSVC_POOL_CACHE_GB", "64")) * (1 << 30))
         self.budget = budget_bytes
+        self.disk_dir = disk_dir if disk_dir is not None else (os.environ.get("KNNSVC_POOL_CACHE_DIR") or None)
+        self.disk_hits = self.disk_writes = 0
         self.used = 0
         self.entries: "OrderedDict[tuple, tuple]" = OrderedDict()
         self.hits = self.misses = 0
@@ -36,16 +47,46 @@ class PoolCache:
     def _nbytes(value) -> int:
         return sum(t.numel() * t.element_size() for t in value.values() if t is not None)
 
-    def get(self, key):
-        e = self.entries.get(key)
-        if e is None:
-            self.misses += 1
-            return None
-        self.entries.move_to_end(key)
-        self.hits += 1
-        return e[0]
+    def _disk_path(self, disk_key) -> str:
+        return os.path.join(self.disk_dir, hashlib.sha1(repr(disk_key).encode()).hexdigest() + ".npz")
 
-    def put(self, key, value: dict) -> None:
+    def get(self, key, disk_key=None, device=None):
+        """Device-resident entry, else (with ``disk_key`` and a configured directory) the on-disk one, moved to
+        ``device`` and promoted into the device tier."""
+        e = self.entries.get(key)
+        if e is not None:
+            self.entries.move_to_end(key)
+            self.hits += 1
+            return e[0]
+        if disk_key is not None and self.disk_dir:
+            pth = self._disk_path(disk_key)
+            if os.path.isfile(pth):
+                import numpy as np
+                import torch
+                try:
+                    with np.load(pth) as z:
+                        value = {f: torch.from_numpy(np.ascontiguousarray(z[f])) for f in FIELDS}
+                except (OSError, ValueError, KeyError):
+                    value = None                   # truncated / foreign file: treat as a miss, it is rewritten below
+                if value is not None:
+                    if device is not None:
+                        value = {f: t.to(device) for f, t in value.items()}
+                    self.disk_hits += 1
+                    self.put(key, value)
+                    return value
+        self.misses += 1
+        return None
+
+    def put(self, key, value: dict, disk_key=None) -> None:
+        if disk_key is not None and self.disk_dir:
+            import numpy as np
+            os.makedirs(self.disk_dir, exist_ok=True)
+            pth = self._disk_path(disk_key)
+            tmp = pth + f".tmp{os.getpid()}"
+            with open(tmp, "wb") as fh:
+                np.savez(fh, **{f: value[f].detach().cpu().numpy() for f in FIELDS})
+            os.replace(tmp, pth)                   # atomic: a concurrent reader sees the old file or the new one
+            self.disk_writes += 1
         if self.budget <= 0:
             return
         n = self._nbytes(value)

@@ -55,12 +55,28 @@ class WavLMEncoder:
     """Packed WavLM weights on one GPU + forward schedule."""
     _uids = 0
 
+    def weights_fingerprint(self) -> str:
+        """Content identity of the packed weights (for the on-disk pool store): sha1 over shape, sum and |sum| (float64)
+        of every packed GEMM weight and LayerNorm vector that shapes the output.  Bookkeeping, not path arithmetic."""
+        if self._fingerprint is None:
+            import hashlib
+            ts = [c["w"] for c in self.conv] + [c["g"] for c in self.conv] + [self.ln_g, self.proj_w, self.pos_w]
+            for L in self.layers:
+                ts += [L["wqkv"], L["wo"], L["w1"], L["w2"], L["ln1_g"], L["ln2_g"], L["grep_a"]]
+            h = hashlib.sha1()
+            for t in ts:
+                d = t.double()
+                h.update(repr((tuple(t.shape), float(d.sum()), float(d.abs().sum()))).encode())
+            self._fingerprint = h.hexdigest()
+        return self._fingerprint
+
     def __init__(self, state: dict, cfg: dict, device="cuda", n_layers: int = C.MATCH_LAYER):
         self.cfg = cfg
         self.device = torch.device(device)
         self.n_layers = n_layers
         WavLMEncoder._uids += 1
         self.uid = WavLMEncoder._uids          # identity of this weight set in the pool-feature store
+        self._fingerprint = None
         assert n_layers <= cfg["encoder_layers"]
         self.E = cfg["encoder_embed_dim"]
         self.H = cfg["encoder_attention_heads"]

@@ -116,3 +116,30 @@ def test_pool_cache_lru_and_keys(tmp_path):
     off = pool_cache.PoolCache(budget_bytes=0)
     off.put(("f", 0), ent(0))
     assert off.get(("f", 0)) is None
+
+
+def test_pool_store_disk_tier(tmp_path):
+    """On-disk tier of the pool-feature store: written atomically per file, found again by a fresh store,
+    invalidated by any change of the key, and a damaged file is a miss, not an error."""
+    import numpy as np
+    import torch
+    from knn_svc_amd import pool_cache
+    wav = tmp_path / "a.wav"; wav.write_bytes(b"RIFF" + bytes(100))
+    np.save(tmp_path / "a_f0.npy", np.zeros(3, np.float32))
+    key = pool_cache.file_key(wav, ("uid1", 6))
+    dkey = pool_cache.file_key(wav, ("abcdef", 6))
+    val = {f: torch.arange(12, dtype=torch.float32).reshape(3, 4) + i for i, f in enumerate(pool_cache.FIELDS)}
+    c1 = pool_cache.PoolCache(budget_bytes=1 << 20, disk_dir=str(tmp_path / "store"))
+    assert c1.get(key, dkey) is None and c1.misses == 1
+    c1.put(key, val, dkey)
+    assert c1.disk_writes == 1 and len(list((tmp_path / "store").glob("*.npz"))) == 1
+    c2 = pool_cache.PoolCache(budget_bytes=1 << 20, disk_dir=str(tmp_path / "store"))      # "another process"
+    got = c2.get(pool_cache.file_key(wav, ("uid7", 6)), dkey)
+    assert got is not None and c2.disk_hits == 1 and all(torch.equal(got[f], val[f]) for f in pool_cache.FIELDS)
+    assert c2.get(pool_cache.file_key(wav, ("uid7", 6))) is got                          # promoted to the resident tier
+    assert c2.get(("x",), pool_cache.file_key(wav, ("other-weights", 6))) is None         # other weights: miss
+    np.save(tmp_path / "a_f0.npy", np.zeros(4, np.float32))                               # f0 track changed: miss
+    assert c2.get(("y",), pool_cache.file_key(wav, ("abcdef", 6))) is None
+    pth = next((tmp_path / "store").glob("*.npz")); pth.write_bytes(b"garbage")
+    c3 = pool_cache.PoolCache(budget_bytes=0, disk_dir=str(tmp_path / "store"))
+    assert c3.get(("z",), dkey) is None

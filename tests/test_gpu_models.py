@@ -335,3 +335,41 @@ def test_bulk_match_pipelined_vocoder_equals_sequential(tmp_path, monkeypatch):
         xa, _ = audio_io.read_wav(a); xb, _ = audio_io.read_wav(b)
         assert xa.shape == xb.shape and np.array_equal(xa, xb)
     matching._POOL_CACHE = None
+
+
+def test_pool_store_disk_tier_skips_encoding(tmp_path):
+    """A fresh process (fresh resident store, fresh encoder object with the same weights) finds every file of a previous
+    dataset-mode run in the on-disk tier: nothing is encoded and the converted files are byte-identical."""
+    from knn_svc_amd import matching, pool_cache
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    root = tmp_path / "data"
+    for s, spk in enumerate(("spkA", "spkB")):
+        (root / spk).mkdir(parents=True)
+        for u in range(2):
+            w, f = S.synth_clip(16000 + 320 * (s + 2 * u), seed=500 + 10 * s + u)
+            audio_io.write_wav_pcm16(str(root / spk / f"u{u}.wav"), w, 16000)
+            np.save(root / spk / f"u{u}_f0.npy", f)
+    outs, encoded = [], []
+    for run in range(2):
+        enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+        knn = KNeighborsVC(enc, Vocoder(S.seeded_state(S.generator_param_spec(h, "mix"), 63), h, "mix", DEV), h, DEV)
+        matching._POOL_CACHE = pool_cache.PoolCache(disk_dir=str(tmp_path / "store"))
+        n = {"n": 0}
+        orig = enc.encode_many
+        def counted(wavs, _o=orig, _n=n, **kw):
+            _n["n"] += len(wavs)
+            return _o(wavs, **kw)
+        enc.encode_many = counted
+        outs.append(sorted(knn.bulk_match(str(root), str(root), str(tmp_path / f"o{run}"), ckpt_type="mix", post_opt="post_opt_0.2")))
+        encoded.append(n["n"])
+        assert matching._POOL_CACHE.disk_writes == (4 if run == 0 else 0)
+    assert encoded == [4, 0], encoded
+    other = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=12), cfg, DEV, n_layers=2)
+    assert other.weights_fingerprint() != enc.weights_fingerprint()
+    for a, b in zip(*outs):
+        xa, _ = audio_io.read_wav(a); xb, _ = audio_io.read_wav(b)
+        assert np.array_equal(xa, xb)
+    matching._POOL_CACHE = None
