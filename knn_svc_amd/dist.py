@@ -66,3 +66,21 @@ def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, lo
     idx_all = all_gather_rows(idx[None])
     mine = slice(rank * nq, (rank + 1) * nq)
     return merge(dist_all[:, mine].contiguous(), idx_all[:, mine].contiguous())
+
+
+def my_share(items):
+    """Independent work units (speaker folders in prematch, (source speaker, target speaker) pairs in dataset mode,
+    source clips in BASELINE cfg 5) are dealt round-robin over the ranks — the per-utterance / per-speaker stages of
+    SURVEY.md §8e shard with no collective at all.  Every rank must call this with the same, identically ordered list."""
+    rank, ws = world()
+    return [it for i, it in enumerate(items) if i % ws == rank]
+
+
+def gather_paths(paths):
+    """All ranks' lists of written files, concatenated in rank order (host objects; one small all_gather_object)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(paths)
+    _rank, ws = world()
+    out = [None] * ws
+    dist.all_gather_object(out, list(paths))
+    return [p for part in out for p in part]

@@ -16,7 +16,7 @@ from pathlib import Path
 
 import torch
 
-from . import audio_io, config as C, ops
+from . import audio_io, config as C, dist as kdist, ops
 from .matching import match_at_inference_time
 from .vocoder import Vocoder
 from .wavlm import WavLMEncoder
@@ -107,32 +107,33 @@ class KNeighborsVC:
             required = [r[2] for i, r in enumerate(rows) if i != 0 and r[-1] == "0"]
         f0only = "wavlm_only" in ckpt_type or "no_harm_no_amp" in ckpt_type
         written = []
-        for i, s in enumerate(src_spk):
-            for j, t in enumerate(tgt_spk):
-                if src_dataset_path == tgt_dataset_path and i == j:
-                    continue
-                print(f"{s} -> {t}")
-                common = dict(topk=topk, device=self.device, prioritize_f0=prioritize_f0, ckpt_type=ckpt_type,
-                              src_dataset_path=src_dataset_path, tgt_dataset_path=tgt_dataset_path,
-                              required_subset=required, duration_limit=duration_limit)
-                # the generator of every utterance is the tail stage of the match pipeline (same kernels and inputs as
-                # `vocode` after the fact, ddsp_matcher.py:1114-1128, but enqueued under the next utterances' matching);
-                # one finiteness check per speaker pair instead of one host sync per utterance
-                preds = {}
-                if not f0only:
-                    match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting, post_opt=post_opt,
-                                            vocode_fn=self._vocode_async, waves_out=preds, **common)
-                else:
-                    match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting,
-                                            vocode_fn=lambda c, f0, _h: self._vocode_async(c, f0), waves_out=preds, **common)
-                if preds:      # max |x| of a waveform is NaN / inf iff the waveform holds one
-                    self._check_finite(torch.stack([p.abs().max() for p in preds.values()]))
-                for k, pred in preds.items():
-                    out = os.path.join(converted_audio_dir, os.path.basename(s), os.path.basename(k).split(".")[0],
-                                       os.path.basename(t) + "." + os.path.basename(k).split(".")[-1])
-                    Path(out).parent.mkdir(parents=True, exist_ok=True)
-                    assert pred.dim() == 1
-                    audio_io.save_audio(out, pred[None, :].cpu().numpy(), sample_rate=self.sr)
-                    written.append(out)
-                print(f"{os.path.basename(s)}, {os.path.basename(t)} -> {converted_audio_dir}")
-        return written
+        pairs = [(s, t) for i, s in enumerate(src_spk) for j, t in enumerate(tgt_spk)
+                 if not (src_dataset_path == tgt_dataset_path and i == j)]
+        # one process per GPU: speaker pairs are independent (clip-DP) and are dealt round-robin over the
+        # ranks; a single process (no process group) gets them all, in the reference's order
+        for s, t in kdist.my_share(pairs):
+            print(f"{s} -> {t}")
+            common = dict(topk=topk, device=self.device, prioritize_f0=prioritize_f0, ckpt_type=ckpt_type,
+                          src_dataset_path=src_dataset_path, tgt_dataset_path=tgt_dataset_path,
+                          required_subset=required, duration_limit=duration_limit)
+            # the generator of every utterance is the tail stage of the match pipeline (same kernels and inputs as
+            # `vocode` after the fact, ddsp_matcher.py:1114-1128, but enqueued under the next utterances' matching);
+            # one finiteness check per speaker pair instead of one host sync per utterance
+            preds = {}
+            if not f0only:
+                match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting, post_opt=post_opt,
+                                        vocode_fn=self._vocode_async, waves_out=preds, **common)
+            else:
+                match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting,
+                                        vocode_fn=lambda c, f0, _h: self._vocode_async(c, f0), waves_out=preds, **common)
+            if preds:      # max |x| of a waveform is NaN / inf iff the waveform holds one
+                self._check_finite(torch.stack([p.abs().max() for p in preds.values()]))
+            for k, pred in preds.items():
+                out = os.path.join(converted_audio_dir, os.path.basename(s), os.path.basename(k).split(".")[0],
+                                   os.path.basename(t) + "." + os.path.basename(k).split(".")[-1])
+                Path(out).parent.mkdir(parents=True, exist_ok=True)
+                assert pred.dim() == 1
+                audio_io.save_audio(out, pred[None, :].cpu().numpy(), sample_rate=self.sr)
+                written.append(out)
+            print(f"{os.path.basename(s)}, {os.path.basename(t)} -> {converted_audio_dir}")
+        return kdist.gather_paths(written)

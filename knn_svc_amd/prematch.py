@@ -14,6 +14,7 @@ Differences from the reference, all deliberate:
 * speaker folders are visited in sorted order (the reference iterates a ``set``);
 * the gathers whose results the reference throws away (``out_feats``, ``audio_out_feats``, the weighted
   harmonic sum, :1637-1674) are not computed; ``audio_synth_pool`` is therefore never built;
+* under ``torch.distributed`` (one process per GPU) the speaker folders are dealt round-robin over the ranks;
 * every utterance of a speaker is a kNN launch against the speaker's pool whose split image (f16x2 operand of
   the matrix-core GEMM) is built once per speaker, utterances run on the stream scheduler's lanes, and the
   Adam loop runs on the device without host round trips.
@@ -28,7 +29,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import config as C, ops, pipeline
+from . import config as C, dist as kdist, ops, pipeline
 from .matching import get_complete_spk_pool
 
 
@@ -80,7 +81,8 @@ def match_speaker(matching_pool: dict, spec_pool: dict, f0_pool: dict, harm_pool
 def per_spk_extract(wavlm, device, ls_path, out_path, synth_weights=None, match_weights=None, save_pool_only=False):
     """Same contract as the reference function (:1464)."""
     ls_path, out_path = Path(ls_path), Path(out_path)
-    folders = speaker_folders(ls_path)
+    all_folders = speaker_folders(ls_path)
+    folders = kdist.my_share(all_folders)          # one process per GPU: speakers are independent (SURVEY §8e), no collective
     for i, folder in enumerate(folders):
         matching_pool, _synth, _audio, spec_pool, f0_pool, harm_pool = get_complete_spk_pool(
             folder, wavlm, match_weights, synth_weights, device)

@@ -66,3 +66,39 @@ def test_single_process_passthrough():
     idx, d = kd.sharded_knn(q, p, 8, _cpu_local_topk, _cpu_merge)
     ref_i, ref_d = _cpu_local_topk(q, p, 8, 0)
     assert torch.equal(idx, ref_i) and torch.equal(d, ref_d)
+
+
+def _share_worker(rank, ws, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from knn_svc_amd import dist as kd
+    pairs = [(f"s{i}", f"t{j}") for i in range(3) for j in range(3) if i != j]      # bulk_match's pair list
+    mine = kd.my_share(pairs)
+    out[rank] = (mine, kd.gather_paths([f"/o/{a}/{b}.wav" for a, b in mine]))
+    dist.destroy_process_group()
+
+
+def test_work_sharing_gloo_world2():
+    """Dataset mode / prematch shard their independent units (speaker pairs, speaker folders) round-robin over ranks with
+    no data-path collective: the shares partition the list, and every rank ends up with the full list of written files."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_share_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (m0, g0), (m1, g1) = out[0], out[1]
+    pairs = [(f"s{i}", f"t{j}") for i in range(3) for j in range(3) if i != j]
+    assert sorted(m0 + m1) == sorted(pairs) and not set(m0) & set(m1) and abs(len(m0) - len(m1)) <= 1
+    assert m0 == pairs[0::2] and m1 == pairs[1::2]
+    assert g0 == g1 and len(g0) == len(pairs) and g0[:len(m0)] == [f"/o/{a}/{b}.wav" for a, b in m0]
+
+
+def test_work_sharing_single_process():
+    sys.path.insert(0, ROOT)
+    from knn_svc_amd import dist as kd
+    assert kd.my_share([1, 2, 3]) == [1, 2, 3] and kd.gather_paths(["a"]) == ["a"]
