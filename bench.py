@@ -299,7 +299,7 @@ def main():
         # once more eagerly with an event pair around every launch of the dominant kernel, on its own stream.
         enc.use_graphs = voc.use_graphs = False
         timer.enabled = True
-        stage.on = a.stages
+        stage.on = True                     # five event pairs per step; the table is printed only with --stages
         for _ in range(a.steps):
             step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
         barrier()
@@ -358,6 +358,26 @@ def main():
                          "kernel_ms_per_step": round(gemm_ms / a.steps, 3)},
         }
         line["config"]["adam_iterations"] = [int(step.last["iters_wavlm"]), int(step.last["iters_harm"])]
+        # BASELINE.json's second metric: kNN query frames/s and its roofline (MFMA-bound once Nq >= ~64).
+        # One kNN stage = every rank's 1500 query frames against the whole pool (each rank searches all ws*1500 queries in
+        # its own 30 000-row shard: row norms, f16x2 split of the shard and the queries, q.p^T GEMM, distance formula +
+        # top-32, then the all-gather merge).  HIP events around the stage in the eager pass, rank 0's stream.
+        if STAGES.get("knn"):
+            kms = [x.elapsed_time(y_) for x, y_ in STAGES["knn"]]
+            kms = sum(kms) / len(kms)
+            nq_all, np_shard, D = ws * 1500, 30000, 1024
+            flop = 2.0 * nq_all * np_shard * D                     # per rank
+            tfl = flop / (kms * 1e-3) / 1e12
+            min_bytes = 4.0 * D * (nq_all + np_shard) + 8 * 32 * nq_all
+            line["knn"] = {"query_frames_per_s": round(nq_all / (kms * 1e-3), 0), "ms": round(kms, 4),
+                           "nq_per_rank": 1500, "nq_searched_per_rank": nq_all, "np_shard": np_shard, "np_total": ws * np_shard, "k": 32,
+                           "tflops_fp32_equiv_per_gpu": round(tfl, 1),
+                           "bound": "mfma", "frac_f16x2_ceiling_833": round(tfl / F16X2_PEAK_TFLOPS, 4),
+                           "frac_fp32_mfma_peak_157.3": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "t_mfma_floor_ms": round(flop / (F16X2_PEAK_TFLOPS * 1e12) * 1e3, 4),
+                           "t_hbm_floor_ms": round(min_bytes / 8e12 * 1e3, 4),
+                           "note": "whole stage incl. norms, operand splits, top-32 selection and the RCCL all-gather merge; "
+                                   "query_frames_per_s counts every rank's frames resolved against the whole pool"}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.isfile(pmc):      # measured offline with rocprofv3 --pmc (tools/pmc_traffic.py); bench.py cannot read PMCs itself
             t = json.load(open(pmc))

@@ -8,6 +8,7 @@
 // row's sorted list (LDS) by a 64-lane bitonic sort.  Per-split lists are merged by a second
 // small kernel.  Keys are (order-preserving bits of the f32 distance) << 32 | pool index, so
 // ties resolve to the lower pool index on every device count.
+#include <stdlib.h>
 #include "gemm_core.h"
 
 namespace {
@@ -41,6 +42,22 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long v, 
         }
     }
     return v;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {      // l wave-uniform
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Sorted list of k <= 32 keys held one per lane (lanes >= k hold KEY_INF): insert one key that is known to be smaller
+// than the current k-th.  One ballot + popcount finds the slot, one lane shift makes room — a few instructions where
+// the bitonic merge costs 21 compare-exchange stages (keys are unique: the pool index sits in their low half).
+__device__ __forceinline__ void list_insert(unsigned long long& mine, unsigned long long key, int lane, int k) {
+    const int pos = __popcll(__ballot(mine < key));
+    const unsigned long long up = __shfl_up(mine, 1, 64);
+    if (lane == pos) mine = key;
+    else if (lane > pos) mine = up;
+    if (lane >= k) mine = KEY_INF;
 }
 
 // the reference's operation sequence on top of dot = sum_k q_k p_k :
@@ -174,6 +191,7 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
 // conv_gemm.hip, 3-4x the rate of the fp32 MFMA tile above; this kernel replays the reference's distance formula on it
 // and selects).  One block per query row, 4 waves; wave w scans pool columns [128 w + 512 t, +128) with the same
 // threshold filter + 64-lane bitonic merge as knn_tile_kernel, wave 0 then folds the four sorted lists.
+template <bool SCREEN>
 __global__ __launch_bounds__(256) void knn_select_kernel(
     const float* __restrict__ dots, long ld, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
     const float* __restrict__ pn, const float* __restrict__ psq, long np, int k, long idx_offset,
@@ -184,43 +202,88 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
     const long row = blockIdx.x;
     const float* drow = dots + row * ld;
     const float v_qn = qn[row], v_qsq = qsq[row];
-    unsigned long long* lst = lists[wave];
     unsigned long long* my_scratch = scratch[wave];
-    if (lane < KMAX) lst[lane] = KEY_INF;
-    __builtin_amdgcn_wave_barrier();
-    bool saw_nan = false;
-    for (long base = (long)wave * 128; base < np; base += 512) {
-        const long p0 = base + lane, p1 = base + 64 + lane;
-        float d0 = __builtin_inff(), d1 = __builtin_inff();
-        if (p0 < np) { d0 = ref_distance(drow[p0], v_qsq, psq[p0], v_qn, pn[p0]); if (d0 != d0) saw_nan = true; }
-        if (p1 < np) { d1 = ref_distance(drow[p1], v_qsq, psq[p1], v_qn, pn[p1]); if (d1 != d1) saw_nan = true; }
-        // self-matching (ddsp_prematch_dataset.py:1606-1607): the query's own utterance competes at distance exactly 1,
-        // after the NaN check (fast_cosine_dist exits on NaN before the caller overwrites anything)
-        if (p0 >= mask_lo && p0 < mask_hi) d0 = 1.f;
-        if (p1 >= mask_lo && p1 < mask_hi) d1 = 1.f;
-        const unsigned long long thr = lst[k - 1];
-        // NaN / +inf never enter: their sortable bits are >= those of +inf
-        const unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)p0;
-        const unsigned long long k1 = ((unsigned long long)sortable(d1) << 32) | (unsigned)p1;
-        const bool f0 = (d0 < __builtin_inff()) && k0 < thr;
-        const bool f1 = (d1 < __builtin_inff()) && k1 < thr;
-        const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
-        if ((b0 | b1) == 0ull) continue;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const int c0 = __popcll(b0), total = c0 + __popcll(b1);
-        if (f0) my_scratch[__popcll(b0 & lt)] = k0;
-        if (f1) my_scratch[c0 + __popcll(b1 & lt)] = k1;
-        __builtin_amdgcn_wave_barrier();
-        for (int b = 0; b < total; b += 32) {
-            unsigned long long v;
-            if (lane < 32) v = lane < k ? lst[lane] : KEY_INF;
-            else v = (b + lane - 32) < total ? my_scratch[b + lane - 32] : KEY_INF;
-            v = wave_sort64(v, lane);
-            if (lane < k) lst[lane] = v;
-            __builtin_amdgcn_wave_barrier();
+    // the wave's sorted top-k lives in registers, one key per lane (lanes >= k: KEY_INF).  After the first tiles a
+    // surviving candidate is rare and single: it is inserted with list_insert; only bursts (the warm-up, when everything
+    // beats an empty list) go through the scratch buffer and the 64-lane bitonic merge.
+    unsigned long long mine = KEY_INF, thr = KEY_INF;
+    bool saw_nan = false, has_thr = false;      // has_thr: the list holds k real entries, thr_d is its largest distance
+    float thr_d = 0.f;
+    const float v_rq = __builtin_amdgcn_rcpf(v_qn);
+    constexpr int U = 4;               // sub-chunks of 128 columns per wave and iteration, all loads issued up front
+    for (long base0 = (long)wave * (128 * U); base0 < np; base0 += 512 * U) {
+        float dv[2 * U], sv[2 * U], nv[2 * U];
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u) {
+            const long p = base0 + u * 64 + lane;
+            const bool in = p < np;
+            dv[u] = in ? drow[p] : 0.f; sv[u] = in ? psq[p] : 0.f; nv[u] = in ? pn[p] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long base = base0 + u * 128;
+            if (base >= np) break;
+            const long p0 = base + lane, p1 = base + 64 + lane;
+            // Screen: the reference formula costs a correctly rounded sqrt and two divisions per element, and almost no
+            // element can beat the current k-th distance.  approx = 1 - dot / (|q||p|) in three instructions; the formula's
+            // own rounding (r = -2 dot + |q|^2 + |p|^2 cancels to ~2 dot) keeps |reference - exact| below
+            // ~3 eps (|q|/|p| + |p|/|q| + 2), the approximation adds a few eps: a margin of 64 eps (1 + ratio) is > 10x that.
+            // Any NaN / inf in the inputs turns approx or the margin into NaN, and a NaN comparison sends the sub-chunk
+            // down the exact path — so NaN detection and the result are those of evaluating the formula everywhere.
+            if (SCREEN && has_thr) {
+                const float c0s = v_rq * __builtin_amdgcn_rcpf(nv[2 * u]), c1s = v_rq * __builtin_amdgcn_rcpf(nv[2 * u + 1]);
+                const float a0 = 1.0f - dv[2 * u] * c0s, a1 = 1.0f - dv[2 * u + 1] * c1s;
+                const float g0 = fmaf((v_qsq + sv[2 * u]) * c0s, 3.8e-6f, 3.8e-6f), g1 = fmaf((v_qsq + sv[2 * u + 1]) * c1s, 3.8e-6f, 3.8e-6f);
+                bool need = (p0 < np && !(a0 >= thr_d + g0)) || (p1 < np && !(a1 >= thr_d + g1));
+                if (mask_lo < mask_hi) need = need || (p0 >= mask_lo && p0 < mask_hi) || (p1 >= mask_lo && p1 < mask_hi);
+                if (__ballot(need) == 0ull) continue;
+            }
+            float d0 = __builtin_inff(), d1 = __builtin_inff();
+            if (p0 < np) { d0 = ref_distance(dv[2 * u], v_qsq, sv[2 * u], v_qn, nv[2 * u]); if (d0 != d0) saw_nan = true; }
+            if (p1 < np) { d1 = ref_distance(dv[2 * u + 1], v_qsq, sv[2 * u + 1], v_qn, nv[2 * u + 1]); if (d1 != d1) saw_nan = true; }
+            // self-matching (ddsp_prematch_dataset.py:1606-1607): the query's own utterance competes at distance exactly 1,
+            // after the NaN check (fast_cosine_dist exits on NaN before the caller overwrites anything)
+            if (p0 >= mask_lo && p0 < mask_hi) d0 = 1.f;
+            if (p1 >= mask_lo && p1 < mask_hi) d1 = 1.f;
+            // NaN / +inf never enter: their sortable bits are >= those of +inf
+            const unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)p0;
+            const unsigned long long k1 = ((unsigned long long)sortable(d1) << 32) | (unsigned)p1;
+            const bool f0 = (d0 < __builtin_inff()) && k0 < thr;
+            const bool f1 = (d1 < __builtin_inff()) && k1 < thr;
+            unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+            if ((b0 | b1) == 0ull) continue;
+            const int c0 = __popcll(b0), total = c0 + __popcll(b1);
+            if (total <= 8) {
+                while (b0) {
+                    const int l = __builtin_ctzll(b0); b0 &= b0 - 1;
+                    const unsigned long long key = readlane64(k0, l);
+                    if (key < thr) { list_insert(mine, key, lane, k); thr = readlane64(mine, k - 1); }
+                }
+                while (b1) {
+                    const int l = __builtin_ctzll(b1); b1 &= b1 - 1;
+                    const unsigned long long key = readlane64(k1, l);
+                    if (key < thr) { list_insert(mine, key, lane, k); thr = readlane64(mine, k - 1); }
+                }
+            } else {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                if (f0) my_scratch[__popcll(b0 & lt)] = k0;
+                if (f1) my_scratch[c0 + __popcll(b1 & lt)] = k1;
+                __builtin_amdgcn_wave_barrier();
+                for (int b = 0; b < total; b += 32) {
+                    unsigned long long v = mine;                       // lanes < 32: the list (KEY_INF beyond k)
+                    if (lane >= 32) v = (b + lane - 32) < total ? my_scratch[b + lane - 32] : KEY_INF;
+                    v = wave_sort64(v, lane);
+                    mine = lane < k ? v : KEY_INF;
+                }
+                __builtin_amdgcn_wave_barrier();
+                thr = readlane64(mine, k - 1);
+            }
+            has_thr = thr != KEY_INF;
+            thr_d = unsortable((unsigned)(thr >> 32));
         }
     }
     if (saw_nan) atomicOr(nan_flag, 1);
+    if (lane < KMAX) lists[wave][lane] = mine;
     __syncthreads();
     if (wave == 0) {
         unsigned long long best = lane < k ? lists[0][lane] : KEY_INF;
@@ -381,7 +444,13 @@ extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_n
     KN_REQUIRE(k >= 1 && k <= KMAX, "knn_select: k must be in 1..32");
     KN_REQUIRE(np >= k, "knn_select: pool smaller than k (the reference's topk would raise)");
     KN_REQUIRE(np < (1ll << 32) && nq <= 0x7FFFFFFFll, "knn_select: pool rows must fit 32 bits");
-    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
-                       (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi, (long*)out_idx, out_dist, nan_flag);
+    // KNNSVC_KNN_SCREEN=0 evaluates the reference formula on every element (A/B and equivalence tests); read per call
+    const char* e = getenv("KNNSVC_KNN_SCREEN");
+    if (e && e[0] == '0')
+        hipLaunchKernelGGL(knn_select_kernel<false>, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
+                           (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi, (long*)out_idx, out_dist, nan_flag);
+    else
+        hipLaunchKernelGGL(knn_select_kernel<true>, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
+                           (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi, (long*)out_idx, out_dist, nan_flag);
     return knnsvc_check_launch("knn_select");
 }

@@ -281,16 +281,24 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
     dev = q.device
     q_rows_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
     parts_i, parts_d = [], []
+    # the queries are split once into the A2 layout (the weight-split kernel writes exactly that image at scale 16) and
+    # every column tile of the GEMM stages them with plain copies instead of re-splitting them
+    q2 = None
+    import os
+    if KNN_FEATURE_SCALE == 16.0 and nq >= 128 and os.environ.get("KNNSVC_KNN_A2", "1") != "0":
+        q2 = torch.empty(nq, dim, device=dev, dtype=torch.float32)
+        check(lib.knnsvc_split_weight_f16x2(_p(q), nq, dim, KNN_FEATURE_SCALE, _p(q2), _stream()), "split_queries")
     for p0, pc, p2 in (prepared if prepared is not None else prepare_knn_pool(pool, k)):
         npc = pc.shape[0]
         idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
         dist = torch.empty(nq, k, device=dev, dtype=torch.float32)
         q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npc, 1) // 128 * 128))
         for q0 in range(0, nq, q_rows):
-            qc = q[q0:q0 + q_rows]
+            qc = (q2 if q2 is not None else q)[q0:q0 + q_rows]
             m = qc.shape[0]
             dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
-            conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, a_scale=KNN_FEATURE_SCALE, w2=p2, w2_scale=KNN_FEATURE_SCALE)
+            conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, a_scale=KNN_FEATURE_SCALE, w2=p2, w2_scale=KNN_FEATURE_SCALE,
+                      x_split=q2 is not None)
             check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
                                         idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
                                         _stream()), "knn_select")

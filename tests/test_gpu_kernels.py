@@ -473,3 +473,31 @@ def test_smooth_weights_with_amp_ratio():
     assert e < 5e-3 and abs(int(it) - it_ref) <= 100
     plain = ops.smooth_weights(idx.to(DEV), pool.to(DEV), 1000.0)
     assert float((plain - w).abs().max()) > 1e-3                                  # the scale is not ignored
+
+
+@pytest.mark.parametrize("scale_q,scale_p", [(1.0, 1.0), (0.01, 30.0), (200.0, 0.05)])
+def test_knn_screen_is_exact(scale_q, scale_p, monkeypatch):
+    """The approximate-distance screen of knnsvc_knn_select only skips work: indices and distances are bit-identical to
+    evaluating the reference formula on every element, also with badly unbalanced norms, near-duplicate pool rows and a
+    self-mask; a NaN in a pool row is still reported."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    p = S.clustered_features(6000, 1024, 31, n_centres=20) * scale_p
+    p[100:140] = p[50:90] * (1 + 1e-6 * torch.randn(40, 1, generator=g))          # near-ties
+    p[2000:2100] *= torch.logspace(-3, 3, 100)[:, None]                           # wildly different row norms
+    q = S.clustered_features(300, 1024, 32, n_centres=20) * scale_q
+    q[:40] = p[50:90] / scale_p * scale_q
+    outs = {}
+    for screen in ("1", "0"):
+        monkeypatch.setenv("KNNSVC_KNN_SCREEN", screen)
+        outs[screen] = [t.cpu() for t in ops.knn_topk(q.to(DEV), p.to(DEV), 32, mask=(50, 70))]
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    monkeypatch.setenv("KNNSVC_KNN_SCREEN", "1")
+    pb = p.clone(); pb[4321, 7] = float("nan")
+    with pytest.raises(ops.KnnSvcError):
+        ops.knn_topk(q.to(DEV), pb.to(DEV), 32)
+    pz = p.clone(); pz[777] = 0                                                  # zero row: the formula gives +-inf or NaN there
+    a = ops.knn_topk(q.to(DEV), pz.to(DEV), 32, check_nan=False)
+    monkeypatch.setenv("KNNSVC_KNN_SCREEN", "0")
+    b = ops.knn_topk(q.to(DEV), pz.to(DEV), 32, check_nan=False)
+    assert torch.equal(a[0], b[0])
