@@ -676,6 +676,7 @@ using F32 = Gemm2Tile<256, 32, 4, 1, 2, 1>;
 using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
 using D128 = Gemm2Dma<128, 128, 2, 2, 2, 2>;
 using R128 = Gemm2Ring<128, 128, 2, 2, 2, 2>;
+using R128x2 = Gemm2Ring<128, 128, 2, 2, 2, 2, 2>;     // 2-stage ring: 32 KB, four blocks per CU
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
 using W64 = Gemm2Win<256, 64, 4, 1, 2, 2, 64>;        // 320 rows (45 KB) + 9 KB
 using W32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // 320 rows + 4.5 KB
@@ -778,6 +779,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             if (e && e[0] == '1') { g_last_kernel = "D128"; return launch2dma<D128>(a, d->batches, st); }
             const char* r = getenv("KNNSVC_RING");
             if (r && r[0] == '1') { g_last_kernel = "R128"; return launch2ring<R128, 3>(a, d->batches, st); }
+            if (r && r[0] == '2') { g_last_kernel = "R128x2"; return launch2ring<R128x2, 4>(a, d->batches, st); }
 
         }
         // stride-1 multi-tap convolutions on fp32 input: windowed kernel (A staged once per channel slab, not once per tap)

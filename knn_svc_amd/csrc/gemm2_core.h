@@ -558,14 +558,21 @@ struct Gemm2Ring {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + (STG) + BOFF + (wave * B_DMA + t) * 1024), 16, b_src[t], ub, 0, 0); \
         ++issued;                                                                                                         \
     }
-        int st_cur = 0, st_n1 = STAGE, st_n2 = 2 * STAGE;
-        KN_ISSUE(st_cur)
-        if (ns > 1) { KN_ISSUE(st_n1) }
-        if (ns > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
+        // ring of STAGES buffers, PF = STAGES - 1 half slabs of prefetch (STAGES = 2: 32 KB at 128x128, four blocks per CU;
+        // STAGES = 3: 48 KB, three blocks)
+        constexpr int PF = STAGES - 1;
+        static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+        int c_cur = 0, c_iss = 0;                          // ring slot of the half slab being computed / issued next
+#pragma unroll
+        for (int t = 0; t < PF; ++t)
+            if (t < ns) { KN_ISSUE(c_iss * STAGE) c_iss = c_iss + 1 == STAGES ? 0 : c_iss + 1; }
+        // wait for half slab 0: everything but the (issued - 1) younger half slabs
+        if (PF == 2 && ns > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         for (int s = 0; s < ns; ++s) {
-            if (s + 2 < ns) { KN_ISSUE(st_n2) }
+            if (s + PF < ns) { KN_ISSUE(c_iss * STAGE) c_iss = c_iss + 1 == STAGES ? 0 : c_iss + 1; }
             __builtin_amdgcn_sched_barrier(0);
+            const int st_cur = c_cur * STAGE;
             f16x8 fa[TM][2], fb[TN][2];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -588,11 +595,11 @@ struct Gemm2Ring {
                     acc[i][j] = c;
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < ns) {                 // this wave's pieces of half slab s+1 have landed (those of s+2 may still fly)
-                if (s + 2 < ns) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (s + 1 < ns) {                 // this wave's pieces of half slab s+1 have landed (a younger one may still fly)
+                if (PF == 2 && s + 2 < ns) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
             }
             __syncthreads();
-            const int t = st_cur; st_cur = st_n1; st_n1 = st_n2; st_n2 = t;
+            c_cur = c_cur + 1 == STAGES ? 0 : c_cur + 1;
         }
 #undef KN_ISSUE
     }
