@@ -442,10 +442,58 @@ def gen_prematch():
         [f"{n}:{','.join(f'{a}/{b}' for a, b in u)}" for n, u in sorted(spk.items())]), **res)
 
 
+def gen_sample():
+    """G13: BASELINE cfg 1/2's own input pair (sample_content: Danakil -> Tiken, 16 kHz PCM_16 + the harvest f0 caches
+    shipped next to them), 6-second excerpts, through the reference's single-file path with the tiny seeded models.
+    The excerpts (data, not code) are committed under tests/golden/sample_content/ so that the GPU box can read them."""
+    print("G13 sample_content excerpts through the reference's single-file special_match path")
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    sdw = S.seeded_state(S.wavlm_param_spec(cfg), seed=11)
+    m = ref_wavlm(cfg, sdw)
+    fx = OUT / "sample_content"
+    fx.mkdir(parents=True, exist_ok=True)
+    start_frame, n_frames = 500, 300
+    names = {"src": "Danakil-voice_resampled_16000_cut", "tgt": "Tiken_lead_07_resampled_16000_cut"}
+    for key, stem in names.items():
+        x, sr = audio_io.read_wav(f"{REF}/sample_content/{stem}.wav")
+        assert sr == 16000 and x.shape[0] == 1
+        f0 = np.load(f"{REF}/sample_content/{stem}_f0.npy")
+        seg = x[0, start_frame * 320:(start_frame + n_frames) * 320]
+        audio_io.write_wav_pcm16(str(fx / f"{key}.wav"), seg, 16000)
+        np.save(fx / f"{key}_f0.npy", np.asarray(f0[start_frame:start_frame + n_frames + 1], dtype=np.float32))
+    src_w = torch.from_numpy(audio_io.read_wav(str(fx / "src.wav"))[0][0])
+    tgt_w = torch.from_numpy(audio_io.read_wav(str(fx / "tgt.wav"))[0][0])
+    src_f = torch.from_numpy(np.load(fx / "src_f0.npy")); tgt_f = torch.from_numpy(np.load(fx / "tgt_f0.npy"))
+    onehot = torch.zeros(cfg["encoder_layers"] + 1); onehot[2] = 1
+    weights = onehot[:, None]
+    res = {}
+    for kind, ckpt, post_opt, seed in (("mix", "mix", "post_opt_0.2", 63), ("f0", "wavlm_only", "no_post_opt", 64)):
+        sdg = S.seeded_state(S.generator_param_spec(h, kind), seed)
+        gen = ref_generator(h, kind, sdg)
+        knn = R_m.KNeighborsVC(m, gen, AttrDict(dict(h)), "cpu")
+        knn.weighting = weights
+        srcp = str(fx / "src.wav")
+        with quiet():
+            if kind == "mix":
+                of, hf, _, sf0 = R_dp.match_at_inference_time(Path(srcp), fx / "tgt.wav", m, weights, weights, device="cpu",
+                                                               prioritize_f0=True, ckpt_type=ckpt, post_opt=post_opt)
+                y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None], hf[srcp][None]).squeeze()
+            else:
+                of, _, sf0 = R_dp.match_at_inference_time(Path(srcp), fx / "tgt.wav", m, weights, weights, device="cpu",
+                                                          prioritize_f0=True, ckpt_type=ckpt)
+                y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None]).squeeze()
+        mine = pipeline_ref.convert(sdw, cfg, sdg, h, kind, src_w, src_f, [tgt_w], [tgt_f], ckpt, post_opt, n_layers=2)
+        eq(y, mine, f"sample {ckpt} {post_opt}", tol=2e-5)
+        res[f"{ckpt}__{post_opt}"] = y.numpy()
+        res[f"{ckpt}__shifted_f0"] = sf0[srcp].numpy()
+        print(f"     {ckpt} {post_opt}: {tuple(y.shape)} rms {y.pow(2).mean().sqrt():.4f}, voiced {int((src_f != 0).sum())}/{len(src_f)}")
+    save("g13_sample", start_frame=start_frame, n_frames=n_frames, **res)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "select", "smooth", "synth", "vocoder", "e2e", "prematch"]
+    which = sys.argv[1:] or ["wavlm", "knn", "select", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

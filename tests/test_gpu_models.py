@@ -373,3 +373,31 @@ def test_pool_store_disk_tier_skips_encoding(tmp_path):
         xa, _ = audio_io.read_wav(a); xb, _ = audio_io.read_wav(b)
         assert np.array_equal(xa, xb)
     matching._POOL_CACHE = None
+
+
+def test_sample_content_single_file_cli_path(golden, tmp_path):
+    """BASELINE cfg 1/2's input pair (6 s excerpts + their harvest f0 caches, tests/golden/sample_content) through the
+    file-based single-file path (special_match: load, encode, match, vocode, PCM_32 write) against the reference's
+    waveform for the same files (g13)."""
+    import shutil
+    from pathlib import Path
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g13_sample")
+    fx = Path(__file__).parent / "golden" / "sample_content"
+    for f in fx.iterdir():
+        shutil.copy(f, tmp_path / f.name)
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+    for kind, ckpt, post_opt, seed in (("mix", "mix", "post_opt_0.2", 63), ("f0", "wavlm_only", "no_post_opt", 64)):
+        knn = KNeighborsVC(enc, Vocoder(S.seeded_state(S.generator_param_spec(h, kind), seed), h, kind, DEV), h, DEV)
+        y = knn.special_match(str(tmp_path / "src.wav"), str(tmp_path / "tgt.wav"), ckpt_type=ckpt, post_opt=post_opt)
+        ref = g[f"{ckpt}__{post_opt}"]
+        r = _rms(y, ref)
+        print(f"sample_content {ckpt} {post_opt}: rms error {r:.2e} (signal rms {float(np.sqrt((ref ** 2).mean())):.3f})")
+        assert y.shape == ref.shape and r < 1e-4
+        out = tmp_path / f"src_to_tgt_knn_{ckpt}_{post_opt}.wav"
+        assert out.is_file()
+        x, sr = audio_io.read_wav(str(out))
+        assert sr == 16000 and x.shape[1] == ref.shape[0]
