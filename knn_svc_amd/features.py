@@ -51,3 +51,50 @@ def stft_mag(wav_1d: torch.Tensor, n_fft: int = 400, hop: int = 320) -> torch.Te
     reim = torch.empty(T, n_fft, device=wav_1d.device, dtype=torch.float32)
     ops.conv_gemm(xp, basis, reim, m=T, n=n_fft, cin=kp, taps=1, stride=1, pad=0, t_in=T, ldx=hop, a_scale=X_SCALE)
     return ops.complex_mag(reim, n_fft // 2)
+
+
+_RESAMPLE_CACHE = {}
+
+
+def _resample_kernel(orig: int, new: int, lowpass_filter_width: int, rolloff: float, device):
+    """torchaudio's sinc_interp_hann filter bank (``_get_sinc_resample_kernel``): [new, 2*width + orig] in fp64 -> fp32,
+    K zero-padded to a multiple of 32 and pre-split for the matrix-core GEMM.  Weight preparation, done once per rate."""
+    key = (orig, new, lowpass_filter_width, rolloff, str(device), ops.gemm_mode())
+    if key not in _RESAMPLE_CACHE:
+        base = min(orig, new) * rolloff
+        width = math.ceil(lowpass_filter_width * orig / base)
+        idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+        t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base
+        t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+        window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+        t = t * math.pi
+        with np.errstate(invalid="ignore", divide="ignore"):
+            kern = np.where(t == 0, 1.0, np.sin(t) / t) * window * (base / orig)
+        k = kern.shape[1]
+        kp = -(-k // K_PAD) * K_PAD
+        padded = np.zeros((new, kp), np.float32)
+        padded[:, :k] = kern.astype(np.float32)
+        _RESAMPLE_CACHE[key] = (ops.attach_split(torch.from_numpy(padded).to(device).contiguous()), width, k)
+    return _RESAMPLE_CACHE[key]
+
+
+def resample(wav_1d: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+             rolloff: float = 0.99) -> torch.Tensor:
+    """torchaudio.functional.resample with its defaults (the call at ddsp_prematch_dataset.py:338-341) on the GPU: the
+    polyphase FIR is a strided convolution, i.e. one GEMM over the framed view of the zero-padded signal (row m =
+    xp[m*orig .. m*orig + K), as in stft_mag) against the [new, K] filter bank; the channel-last output [frames, new] IS the
+    interleaved output stream.  torchaudio is absent offline: PARITY UNPINNED against the library itself, checked against
+    the restatement in oracle/audio_ref.py."""
+    if orig_freq == new_freq:
+        return wav_1d
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    kern, width, k = _resample_kernel(orig, new, lowpass_filter_width, rolloff, wav_1d.device)
+    kp = kern.shape[1]
+    n = wav_1d.numel()
+    frames = n // orig + 1                                   # conv1d(pad(x, (width, width + orig)), stride=orig)
+    xp = torch.zeros((frames - 1) * orig + kp, device=wav_1d.device, dtype=torch.float32)
+    xp[width:width + n] = wav_1d
+    out = torch.empty(frames, new, device=wav_1d.device, dtype=torch.float32)
+    ops.conv_gemm(xp, kern, out, m=frames, n=new, cin=kp, taps=1, stride=1, pad=0, t_in=frames, ldx=orig, a_scale=X_SCALE)
+    return out.reshape(-1)[: math.ceil(new * n / orig)]

@@ -49,8 +49,9 @@ def load_utterance(pth):
     x, sr = audio_io.load_audio(str(pth))
     if x.shape[0] > 1:
         x = x.mean(axis=0, keepdims=True)
-    if sr != C.SAMPLE_RATE:
-        x = audio_io.resample(x, sr, C.SAMPLE_RATE)
+    if sr != C.SAMPLE_RATE:      # on the GPU (features.resample); the reference resamples with torchaudio on the host (:338-341)
+        x = features.resample(torch.from_numpy(np.ascontiguousarray(x[0], dtype=np.float32)).cuda(), sr,
+                              C.SAMPLE_RATE).cpu().numpy()[None]
     f0_path = os.path.splitext(str(pth))[0] + "_f0.npy"
     if not os.path.isfile(f0_path):
         raise FileNotFoundError(

@@ -501,3 +501,17 @@ def test_knn_screen_is_exact(scale_q, scale_p, monkeypatch):
     monkeypatch.setenv("KNNSVC_KNN_SCREEN", "0")
     b = ops.knn_topk(q.to(DEV), pz.to(DEV), 32, check_nan=False)
     assert torch.equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("sr,n", [(44100, 44100 + 37), (48000, 30001), (8000, 12345), (22050, 22050), (24000, 7)])
+def test_resample_matches_torchaudio_restatement(sr, n):
+    """features.resample (GPU, one framed-signal GEMM) against the oracle's restatement of torchaudio's sinc_interp_hann
+    resampler: same length law, values within fp32 rounding of the filter sum."""
+    from knn_svc_amd import features
+    from oracle import audio_ref
+    g = np.random.default_rng(sr)
+    x = (0.5 * g.standard_normal(n)).astype(np.float32)
+    ref = audio_ref.resample(x[None], sr, 16000)[0]
+    got = features.resample(torch.from_numpy(x).to(DEV), sr, 16000).cpu().numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert float(np.abs(got - ref).max()) < 2e-6
