@@ -26,6 +26,7 @@ struct ConvArgs {
     int out_split;              // epilogue writes the f16x2 split layout (scale 16) instead of fp32
     float out_scale;            // accumulator -> output factor (1 except on the f16x2 path)
     float a_scale;              // f16x2 path: power-of-two factor applied to activations before the split
+    int lin;                    // plain output below 2 GiB: the buffer-addressed epilogue applies (conv_epilogue_lin)
 };
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
@@ -294,6 +295,79 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
     }
 }
 
+// Lean epilogue for plain (non-transposed) outputs whose byte extent fits 31 bits: rows are addressed through buffer
+// resources sized to the valid rows, so the hardware range check replaces the per-element `m < M` tests (stores past the
+// last row are dropped, loads return 0), offsets are 32-bit (row base + a wave-uniform multiple of the pitch per
+// accumulator element) and nothing is computed in 64 bits.  With 128 accumulator registers live (128x64 wave tiles) the
+// generic epilogue above spills ~350 registers; this one does not.
+template <class G>
+__device__ __forceinline__ void conv_epilogue_lin(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], int m0, int n0, int b, int g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
+    const float* rz = a.resid ? a.resid + b * a.r_bstride + g * a.r_gstride : nullptr;
+    const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
+    const int ldo4 = a.ldo * 4, ldr4 = a.ldr * 4;
+    const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, ((a.m - 1) * a.ldo + a.n) * 4);
+    const __amdgpu_buffer_rsrc_t r_rsrc = uniform_rsrc(rz ? (const void*)rz : (const void*)oz, rz ? ((a.m - 1) * a.ldr + a.n) * 4 : 0);
+    constexpr int NR = G::NR;
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j) {
+        const int n = n0 + G::acc_col(wave, lane, j);
+        const bool nv = n < a.n;
+        const float bv = (bz && nv) ? bz[a.bias_period ? n % a.bias_period : n] : 0.f;
+        const bool odd = (lane & 1) != 0;
+        const int ce = n & ~1;
+        // byte offset of this lane's column inside a row: fp32 element, or its 4-byte slot of the f16x2 split layout
+        const int cpart = a.out_split ? (ce >> 5) * 128 + (ce & 31) * 2 + (odd ? 64 : 0) : n * 4;
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) {
+            const int row0 = m0 + G::acc_row(wave, lane, i, 0);
+            const int bo = nv ? row0 * ldo4 + cpart : OOB;
+            const int br = nv ? row0 * ldr4 + n * 4 : OOB;
+            float rv[NR], av[NR];
+            if (rz) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, br + ((r & 3) + 8 * (r >> 2)) * ldr4, 0, 0));
+            }
+            if (a.accumulate) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_rsrc, bo + ((r & 3) + 8 * (r >> 2)) * ldo4, 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float v = fmaf(acc[i][j][r], a.out_scale, bv);      // out_scale is a power of two: exact
+                if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
+                else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
+                const int off = bo + ((r & 3) + 8 * (r >> 2)) * ldo4;
+                if (a.out_split) {       // see conv_epilogue: lanes n and n^1 exchange halves, one 4-byte store each
+                    const float xs = v * KN_F16X2_A_SCALE;
+                    const _Float16 h = (_Float16)xs;
+                    const _Float16 l = (_Float16)(xs - (float)h);
+                    const unsigned hl = (unsigned)__builtin_bit_cast(unsigned short, h) |
+                                        ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                    const unsigned pr = (unsigned)__builtin_amdgcn_mov_dpp((int)hl, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                    const unsigned ow = odd ? ((pr >> 16) | (hl & 0xFFFF0000u)) : ((hl & 0xFFFFu) | (pr << 16));
+                    __builtin_amdgcn_raw_buffer_store_b32(ow, o_rsrc, off, 0, 0);
+                    continue;
+                }
+                if (rz) v += rv[r];
+                if (a.accumulate) v += av[r];
+                if (a.div != 1.0f) v = v / a.div;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, 0, 0);
+            }
+        }
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void conv_epilogue_any(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], int m0, int n0, int b, int g) {
+    if (a.lin) conv_epilogue_lin<G>(a, acc, m0, n0, b, g);       // wave-uniform
+    else conv_epilogue<G>(a, acc, m0, n0, b, g);
+}
+
 template <class G, int VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -379,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     FastALoader<G::A_F4> al(a, m0, threadIdx.x);
     Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
     G::template mainloop<A2>(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale);
-    conv_epilogue<G>(a, acc, m0, n0, b, g);
+    conv_epilogue_any<G>(a, acc, m0, n0, b, g);
 }
 
 // stride-1 multi-tap convolutions: one window of BM + HALO input rows per 32-channel slab, every tap reads it shifted
@@ -415,7 +489,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm2win_kernel(ConvArgs a) {
     const int w_off0 = ((m0 - a.pad + (tid >> 3)) * a.ldx + (tid & 7) * 4) * 4;
     G::mainloop(lds, a.cin / 32, a.taps, a.dil, w_off0, a.ldx * 4, bl, acc, FastALoader<1>::desc(a, xz),
                 Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale, a.a_slope);
-    conv_epilogue<G>(a, acc, m0, n0, b, g);
+    conv_epilogue_any<G>(a, acc, m0, n0, b, g);
 }
 
 template <class G, int MINB>
@@ -471,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2dma_kernel(ConvArgs a) {
     };
     G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
                 a.n, a.K, m0, n0, acc);
-    conv_epilogue<G>(a, acc, m0, n0, b, g);
+    conv_epilogue_any<G>(a, acc, m0, n0, b, g);
 }
 
 template <class G>
@@ -527,7 +601,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm2ring_kernel(ConvArgs a) {
     };
     G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
                 a.n, a.K, m0, n0, acc);
-    conv_epilogue<G>(a, acc, m0, n0, b, g);
+    conv_epilogue_lin<G>(a, acc, m0, n0, b, g);
 }
 
 template <class G, int MINB>
@@ -676,7 +750,8 @@ using F32 = Gemm2Tile<256, 32, 4, 1, 2, 1>;
 using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
 using D128 = Gemm2Dma<128, 128, 2, 2, 2, 2>;
 using R128 = Gemm2Ring<128, 128, 2, 2, 2, 2>;
-using R128x2 = Gemm2Ring<128, 128, 2, 2, 2, 2, 2>;     // 2-stage ring: 32 KB, four blocks per CU
+using R128x2 = Gemm2Ring<128, 128, 2, 2, 2, 2, 2>;
+using R256 = Gemm2Ring<256, 128, 2, 2, 4, 2, 3>;       // 128x64 wave tiles, 72 KB ring: two blocks per CU     // 2-stage ring: 32 KB, four blocks per CU
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
 using W64 = Gemm2Win<256, 64, 4, 1, 2, 2, 64>;        // 320 rows (45 KB) + 9 KB
 using W32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // 320 rows + 4.5 KB
@@ -740,6 +815,8 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.w2 = (const unsigned short*)d->w_f16x2;
     a.out_scale = 1.0f; a.a_scale = 1.0f;
     a.x_split = d->x_f16x2; a.out_split = d->out_f16x2;
+    a.lin = !d->convt_u && (long)d->m * d->ldo * 4 < (1L << 31) && (!d->resid || (long)d->m * d->ldr * 4 < (1L << 31)) &&
+            !(getenv("KNNSVC_EPILOGUE") && getenv("KNNSVC_EPILOGUE")[0] == 'g');      // KNNSVC_EPILOGUE=g: generic epilogue (A/B)
 
     // 16-byte vector path needs every float4 of A and W to be aligned and inside one tap
     const bool vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
@@ -778,8 +855,10 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             const char* e = getenv("KNNSVC_DMA");
             if (e && e[0] == '1') { g_last_kernel = "D128"; return launch2dma<D128>(a, d->batches, st); }
             const char* r = getenv("KNNSVC_RING");
+            if (d->convt_u || (long)d->m * d->ldo * 4 >= (1L << 31) || (d->resid && (long)d->m * d->ldr * 4 >= (1L << 31))) r = nullptr;
             if (r && r[0] == '1') { g_last_kernel = "R128"; return launch2ring<R128, 3>(a, d->batches, st); }
             if (r && r[0] == '2') { g_last_kernel = "R128x2"; return launch2ring<R128x2, 4>(a, d->batches, st); }
+            if (r && r[0] == '3') { g_last_kernel = "R256"; return launch2ring<R256, 2>(a, d->batches, st); }
 
         }
         // stride-1 multi-tap convolutions on fp32 input: windowed kernel (A staged once per channel slab, not once per tap)
