@@ -745,6 +745,7 @@ using H128 = Gemm3Tile<128, 128, 2, 2, 2, 2>;
 using H64 = Gemm3Tile<256, 64, 4, 1, 2, 2>;     // small-N layers: taller tiles so that a wave still issues 48 / 24
 using H32 = Gemm3Tile<256, 32, 4, 1, 2, 1>;     // MFMAs between the two barriers of a slab
 using F128 = Gemm2Tile<128, 128, 2, 2, 2, 2>;
+using F64S = Gemm2Tile<64, 64, 2, 2, 1, 1>;       // launches that would put < 256 blocks of 128x128 on the chip
 using F64 = Gemm2Tile<256, 64, 4, 1, 2, 2>;
 using F32 = Gemm2Tile<256, 32, 4, 1, 2, 1>;
 using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
@@ -753,6 +754,7 @@ using R128 = Gemm2Ring<128, 128, 2, 2, 2, 2>;
 using R128x2 = Gemm2Ring<128, 128, 2, 2, 2, 2, 2>;
 using R256 = Gemm2Ring<256, 128, 2, 2, 4, 2, 3>;       // 128x64 wave tiles, 72 KB ring: two blocks per CU     // 2-stage ring: 32 KB, four blocks per CU
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
+using W128S = Gemm2Win<64, 128, 2, 2, 1, 2, 64>;      // short time axes (first generator stage): twice the blocks, 37 KB
 using W64 = Gemm2Win<256, 64, 4, 1, 2, 2, 64>;        // 320 rows (45 KB) + 9 KB
 using W32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // 320 rows + 4.5 KB
 using W64P = Gemm2Win<256, 64, 4, 1, 2, 2, 128>;      // k = 128 positional conv: 384 rows (54 KB) + 9 KB
@@ -866,12 +868,23 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             static const bool win_on = [] { const char* e = getenv("KNNSVC_WIN"); return !(e && e[0] == '0'); }();
             const int halo = (d->taps - 1) * d->dil;
             if (win_on && halo <= 64) {
-                if (d->n > 64) { g_last_kernel = "W128"; return launch2win<W128, 3>(a, d->batches, st); }
+                if (d->n > 64) {
+                    // fewer than ~2/3 of the chip's 768 resident slots at 128-row tiles: halve the tile height
+                    static const bool small_on = [] { const char* e = getenv("KNNSVC_WIN_SMALL"); return !(e && e[0] == '0'); }();
+                    if (small_on && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 512) {
+                        g_last_kernel = "W128S"; return launch2win<W128S, 4>(a, d->batches, st);
+                    }
+                    g_last_kernel = "W128"; return launch2win<W128, 3>(a, d->batches, st);
+                }
                 if (d->n > 32) { g_last_kernel = "W64"; return launch2win<W64, 2>(a, d->batches, st); }
                 g_last_kernel = "W32";
                 return launch2win<W32, 3>(a, d->batches, st);
             }
             if (win_on && halo <= 128 && d->n > 32 && d->n <= 64) { g_last_kernel = "W64P"; return launch2win<W64P, 2>(a, d->batches, st); }
+        }
+        if (d->n > 64 && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 256) {
+            static const bool small_on = [] { const char* e = getenv("KNNSVC_GEMM_SMALL"); return !(e && e[0] == '0'); }();
+            if (small_on) { g_last_kernel = "F64S"; return launch2<F64S>(a, d->batches, st); }
         }
         g_last_kernel = d->n > 64 ? (a.x_split ? "F128a2" : "F128") : d->n > 32 ? "F64" : "F32";
         if (d->n > 64) return launch2<F128>(a, d->batches, st);
