@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 5
+#define KNNSVC_ABI_VERSION 6
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -129,8 +129,10 @@ int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head
  * qkv is [batches*T, 3*E] (q | k | v column blocks, E = heads*64), table is [heads][2T-1]
  * (bucket LUT already applied), gate [batches*T, heads], out [batches*T, E].  head_dim must be 64.
  * Nothing of size T x T is ever written to HBM. */
+/* kv_f16x2: the K and V column blocks of `qkv` (columns E..3E) already hold the f16x2 split layout, written by the QKV
+ * projection with knnsvc_conv_desc.out_f16x2 = E (split from column E on); Q stays fp32.  f16x2 kernel only. */
 int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
-                           int32_t T, int32_t heads, float* out, int32_t out_f16x2, void* stream);
+                           int32_t T, int32_t heads, float* out, int32_t out_f16x2, int32_t kv_f16x2, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cosine-distance kNN (lib_ongaku_test.py:148-175 fast_cosine_dist + Tensor.topk(k, largest=False),

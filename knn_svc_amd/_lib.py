@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libknnsvc_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -47,7 +47,7 @@ SIGNATURES = {
     "knnsvc_layernorm": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp]),
     "knnsvc_wavlm_conv0": (i32, [vp, i32, i64, vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
-    "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp]),
+    "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, i32, vp]),
     "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp]),
     "knnsvc_knn_workspace_bytes": (sz, [i64, i64, i32]),
     "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, i64, i64, vp, vp, vp, sz, vp, vp]),

@@ -382,21 +382,22 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
 //   scales : Q' = 16 (log2 e / 8) Q, K' = 16 K  (scores x 256, undone inside the exp2 argument);
 //            P' = 2^14 P (folded into the exp2 argument, cancels in O / l);  V' = 16 V (undone at the end)
 // ---------------------------------------------------------------------------------------------
+typedef short short4v __attribute__((ext_vector_type(4)));
 constexpr int KP2 = 272;
-constexpr int VP2 = 264;
+constexpr int VP2 = 320;          // V image: row = key, [hi 64 d | lo 64 d] + pad; 80 dwords = 16 (mod 64): the four rows of a
+                                  // ds_read_b64_tr_b16 block cover the 64 banks exactly once
 
 __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
                                                            const float* __restrict__ table, int T, int heads,
-                                                           float* __restrict__ out, int out_split) {
+                                                           float* __restrict__ out, int out_split, int kv_split) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef __attribute__((address_space(3))) char lc;
     typedef __attribute__((address_space(3))) au32x4 l_u4;
     typedef __attribute__((address_space(3))) au32x2 l_u2;
-    typedef __attribute__((address_space(3))) unsigned short l_u16;
     typedef __attribute__((address_space(3))) float l_f;
     lc* Ks = (lc*)lds;                       // 64 keys * 272 B
-    lc* Vs = Ks + KT * KP2;                  // 64 d * 264 B
-    l_f* tb = (l_f*)(Vs + HD * VP2);         // [2T-1+64]
+    lc* Vs = Ks + KT * KP2;                  // 64 keys * 320 B, row-major like K (read transposed, see the PV product)
+    l_f* tb = (l_f*)(Vs + KT * VP2);         // [2T-1+64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -430,6 +431,10 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
     }
     const float g_i = qvalid ? gate[((long)b * T + qi) * heads + head] * (L2E * 256.0f) : 0.f;
     const l_f* tbq = tb + (T - 1 - (qvalid ? qi : T - 1)) + 4 * lh;     // tbq[key] = table[key - qi + T - 1]
+    // transposed-read address of this lane inside a 16-key x 32-d block of V: key 4 (lane >> 5) + ((lane & 15) >> 2),
+    // columns 16 ((lane >> 4) & 1) + 4 (lane & 3)
+    const lc* v_tr = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * VP2 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
 
     f32x16 o[2];
 #pragma unroll
@@ -457,6 +462,19 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
     const int ntiles = (T + KT - 1) / KT;
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
+        if (kv_split) {
+            // K and V columns of `qkv` already hold the f16x2 split layout (written by the QKV GEMM's epilogue, scale 16):
+            // the 16 bytes a thread loaded are piece pc = tid & 15 of its key's 256-byte head slice — 8 halves of plane
+            // (pc >> 2) & 1, channels 32 (pc >> 3) + 8 (pc & 3) .. + 7.  Staging is a copy: every query block of a head
+            // (12 at T = 1500) used to redo the same split of the same keys (~110 VALU per thread and tile).
+            const int pc = tid & 15, plane = (pc >> 2) & 1, d0 = (pc >> 3) * 32 + (pc & 3) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = srow + 16 * j;
+                *(l_u4*)(Ks + key * KP2 + plane * 128 + d0 * 2) = __builtin_bit_cast(au32x4, rk[j]);
+                *(l_u4*)(Vs + key * VP2 + plane * 128 + d0 * 2) = __builtin_bit_cast(au32x4, rv[j]);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int key = srow + 16 * j;
@@ -466,12 +484,10 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
             *(l_u2*)(kd) = hi;
             *(l_u2*)(kd + 128) = lo;
             f16x2_split4(rv[j], 16.0f, hi, lo);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                lc* vd = Vs + (scol + e) * VP2 + key * 2;              // transposed: row = d, column = key
-                *(l_u16*)(vd) = (unsigned short)(hi[e >> 1] >> (16 * (e & 1)));
-                *(l_u16*)(vd + 128) = (unsigned short)(lo[e >> 1] >> (16 * (e & 1)));
-            }
+            lc* vd = Vs + key * VP2 + scol * 2;
+            *(l_u2*)(vd) = hi;
+            *(l_u2*)(vd + 128) = lo;
+        }
         }
         __syncthreads();
         if (t + 1 < ntiles) gload((t + 1) * KT);
@@ -530,13 +546,21 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
                 f16x2_split4((f32x4){s[8 * st + 4], s[8 * st + 5], s[8 * st + 6], s[8 * st + 7]}, 1.0f, h1, l1);
                 const f16x8 b0 = __builtin_bit_cast(f16x8, (au32x4){h0[0], h0[1], h1[0], h1[1]});
                 const f16x8 b1 = __builtin_bit_cast(f16x8, (au32x4){l0[0], l0[1], l1[0], l1[1]});
-                // element e of this lane's fragment is key sub*32 + 16 st + 8 (e>>2) + 4 h + (e&3): two runs of four keys
-                const int kcol = (sub * 32 + 16 * st + 4 * lh) * 2;
+                // element e of this lane's fragment is key sub*32 + 16 st + 8 (e>>2) + 4 h + (e&3): two runs of four keys.
+                // V sits row-major in LDS (row = key) and is read TRANSPOSED by the hardware (ds_read_b64_tr_b16): each
+                // 16-lane group fetches a block of 4 keys x 16 d and lane i of the group receives d = base + i of the four
+                // keys; lane 4 q + p supplies the address of key q, columns 4 p .. 4 p + 3 (tools/probe/tr_read_probe.hip).
+                // The transposed 2-byte stores this replaces put 64 lanes on ~4 banks: 48 % of the kernel's LDS cycles
+                // were bank conflicts.  EXEC is full here (no lane-divergent control flow around the reads).
+                const lc* vrow = v_tr + (sub * 32 + 16 * st) * VP2;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const lc* vp = Vs + (dt * 32 + li) * VP2 + kcol;
-                    const au32x2 x0 = *(const l_u2*)(vp), x1 = *(const l_u2*)(vp + 16);
-                    const au32x2 y0 = *(const l_u2*)(vp + 128), y1 = *(const l_u2*)(vp + 128 + 16);
+                    typedef __attribute__((address_space(3))) short4v l_s4;
+                    const lc* vp = vrow + dt * 64;
+                    const au32x2 x0 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp)));
+                    const au32x2 x1 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp + 8 * VP2)));
+                    const au32x2 y0 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp + 128)));
+                    const au32x2 y1 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp + 8 * VP2 + 128)));
                     const f16x8 v0 = __builtin_bit_cast(f16x8, (au32x4){x0[0], x0[1], x1[0], x1[1]});
                     const f16x8 v1 = __builtin_bit_cast(f16x8, (au32x4){y0[0], y0[1], y1[0], y1[1]});
                     f32x16 c = o[dt];
@@ -572,7 +596,7 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
 }  // namespace
 
 extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
-                                      int32_t T, int32_t heads, float* out, int32_t out_f16x2, void* stream) {
+                                      int32_t T, int32_t heads, float* out, int32_t out_f16x2, int32_t kv_f16x2, void* stream) {
     KN_REQUIRE(qkv && gate && table && out, "wavlm_attention: null pointer");
     KN_REQUIRE(batches > 0 && T > 0 && heads > 0 && heads <= 65535 && batches <= 65535, "wavlm_attention: bad sizes");
     KN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "wavlm_attention: 16-byte alignment");
@@ -582,7 +606,7 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
         mode = !e ? 2 : (e[0] == 'b') ? 3 : (e[0] == 'f' && e[1] == 'p') ? 0 : 2;
     }
     if (mode == 2) {
-        const size_t l2 = (size_t)KT * KP2 + (size_t)HD * VP2 + (size_t)(2 * T - 1 + 64) * 4;
+        const size_t l2 = (size_t)KT * KP2 + (size_t)KT * VP2 + (size_t)(2 * T - 1 + 64) * 4;
         KN_REQUIRE(l2 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~16000)");
         static size_t attr2 = 0;
         if (l2 > attr2) {
@@ -591,10 +615,10 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
             attr2 = l2;
         }
         dim3 grid2((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batches);
-        hipLaunchKernelGGL(attention2_kernel, grid2, dim3(256), l2, (hipStream_t)stream, qkv, gate, table, T, heads, out, out_f16x2);
+        hipLaunchKernelGGL(attention2_kernel, grid2, dim3(256), l2, (hipStream_t)stream, qkv, gate, table, T, heads, out, out_f16x2, kv_f16x2);
         return knnsvc_check_launch("wavlm_attention2");
     }
-    KN_REQUIRE(!out_f16x2, "wavlm_attention: split output is only implemented by the f16x2 kernel");
+    KN_REQUIRE(!out_f16x2 && !kv_f16x2, "wavlm_attention: split output / pre-split K,V are only implemented by the f16x2 kernel");
     if (mode == 3) {
         const size_t l3 = (size_t)KT * KP3 + (size_t)HD * VP3 + (size_t)(2 * T - 1 + 64) * 4;
         KN_REQUIRE(l3 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~13000)");

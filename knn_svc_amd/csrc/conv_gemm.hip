@@ -23,7 +23,8 @@ struct ConvArgs {
     const unsigned short* w3;   // weights pre-split into 3 bf16 planes ([n][K/32][3][32]) or null
     const unsigned short* w2;   // weights pre-split into 2 fp16 planes ([n][K/32][2][32], scaled) or null
     int x_split;                // A operand already in the f16x2 split layout (same pitch in bytes)
-    int out_split;              // epilogue writes the f16x2 split layout (scale 16) instead of fp32
+    int out_split;              // epilogue writes the f16x2 split layout (scale 16) instead of fp32 ...
+    int split_from;             // ... for output columns >= split_from (a multiple of 32; 0 = every column)
     float out_scale;            // accumulator -> output factor (1 except on the f16x2 path)
     float a_scale;              // f16x2 path: power-of-two factor applied to activations before the split
     int lin;                    // plain output below 2 GiB: the buffer-addressed epilogue applies (conv_epilogue_lin)
@@ -265,7 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
                 if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
                 else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
-                if (a.out_split) {
+                if (a.out_split && n >= a.split_from) {
                     // f16x2 split layout for the next GEMM's A operand: element (row, c) -> hi at (c/32)*128 + (c%32)*2,
                     // lo 64 bytes further.  Lanes n and n^1 hold neighbouring columns of the same row: the even lane
                     // stores both hi halves, the odd lane both lo halves — one 4-byte store per lane, as in fp32 mode.
@@ -318,7 +319,8 @@ __device__ __forceinline__ void conv_epilogue_lin(const ConvArgs& a, typename G:
         const bool odd = (lane & 1) != 0;
         const int ce = n & ~1;
         // byte offset of this lane's column inside a row: fp32 element, or its 4-byte slot of the f16x2 split layout
-        const int cpart = a.out_split ? (ce >> 5) * 128 + (ce & 31) * 2 + (odd ? 64 : 0) : n * 4;
+        const bool sp = a.out_split && n >= a.split_from;          // uniform per 32-column group
+        const int cpart = sp ? (ce >> 5) * 128 + (ce & 31) * 2 + (odd ? 64 : 0) : n * 4;
 #pragma unroll
         for (int i = 0; i < G::TM; ++i) {
             const int row0 = m0 + G::acc_row(wave, lane, i, 0);
@@ -342,7 +344,7 @@ __device__ __forceinline__ void conv_epilogue_lin(const ConvArgs& a, typename G:
                 else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
                 else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
                 const int off = bo + ((r & 3) + 8 * (r >> 2)) * ldo4;
-                if (a.out_split) {       // see conv_epilogue: lanes n and n^1 exchange halves, one 4-byte store each
+                if (sp) {       // see conv_epilogue: lanes n and n^1 exchange halves, one 4-byte store each
                     const float xs = v * KN_F16X2_A_SCALE;
                     const _Float16 h = (_Float16)xs;
                     const _Float16 l = (_Float16)(xs - (float)h);
@@ -816,7 +818,8 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.w3 = (const unsigned short*)d->w_bf16x3;
     a.w2 = (const unsigned short*)d->w_f16x2;
     a.out_scale = 1.0f; a.a_scale = 1.0f;
-    a.x_split = d->x_f16x2; a.out_split = d->out_f16x2;
+    a.x_split = d->x_f16x2; a.out_split = d->out_f16x2 != 0; a.split_from = d->out_f16x2 > 1 ? d->out_f16x2 : 0;
+    KN_REQUIRE(d->out_f16x2 >= 0 && (d->out_f16x2 <= 1 || d->out_f16x2 % 32 == 0), "conv_gemm: out_f16x2 is 0, 1 or the first split column (a multiple of 32)");
     a.lin = !d->convt_u && (long)d->m * d->ldo * 4 < (1L << 31) && (!d->resid || (long)d->m * d->ldr * 4 < (1L << 31)) &&
             !(getenv("KNNSVC_EPILOGUE") && getenv("KNNSVC_EPILOGUE")[0] == 'g');      // KNNSVC_EPILOGUE=g: generic epilogue (A/B)
 

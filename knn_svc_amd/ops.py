@@ -152,14 +152,16 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.w_f16x2 = w2.data_ptr() if w2 is not None else None
     d.w_f16x2_scale = w2_scale if w2 is not None else 0.0
     d.a_f16x2_scale = a_scale
-    d.x_f16x2 = 1 if x_split else 0; d.out_f16x2 = 1 if out_split else 0
+    d.x_f16x2 = 1 if x_split else 0
+    d.out_f16x2 = int(out_split) if (out_split is not True and out_split is not False) else (1 if out_split else 0)   # True / first split column
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
     return out
 
 
 def linear(x2d, w, bias=None, act=ACT_NONE, resid=None, out=None, x_split=False, out_split=False):
     """out[M,N] = act(x2d[M,K] @ w[N,K]^T + bias) (+ resid).  x_split / out_split: operand / result in the f16x2
-    split layout (include/knnsvc_hip.h, "A2"), carried in float32 tensors of the usual shape."""
+    split layout (include/knnsvc_hip.h, "A2"), carried in float32 tensors of the usual shape; out_split may also be
+    the first split column (a multiple of 32): columns before it stay fp32."""
     _need(x2d, name="linear.x"); _need(w, name="linear.w")
     M, K = x2d.shape
     N = w.shape[0]
@@ -217,10 +219,18 @@ def wavlm_gate(xn2d, heads, w2, b2, grep_a, x_split=False):
     return gate
 
 
-def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False):
+def attention_mode() -> str:
+    """KNNSVC_ATTENTION = f16x2 (default) | bf16x3 | fp32, as knnsvc_wavlm_attention reads it."""
+    import os
+    e = os.environ.get("KNNSVC_ATTENTION", "")
+    return "bf16x3" if e[:1] == "b" else "fp32" if e[:2] == "fp" else "f16x2"
+
+
+def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_split=False):
+    """kv_split: the K and V column blocks of qkv hold the f16x2 split layout (QKV projection run with out_split=E)."""
     out = torch.empty(batches * T, heads * 64, device=qkv.device, dtype=torch.float32)
     check(_lib.load().knnsvc_wavlm_attention(_p(qkv), _p(gate), _p(table), batches, T, heads, _p(out),
-                                             1 if out_split else 0, _stream()), "wavlm_attention")
+                                             1 if out_split else 0, 1 if kv_split else 0, _stream()), "wavlm_attention")
     return out
 
 

@@ -202,8 +202,10 @@ class WavLMEncoder:
         for ly in self.layers:
             xn = ops.layernorm(x, ly["ln1_g"], ly["ln1_b"], out_split=e_sp)
             gate = ops.wavlm_gate(xn, H, ly["gate_w"], ly["gate_b"], ly["grep_a"], x_split=e_sp)
-            qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"], x_split=e_sp)
-            att = ops.wavlm_attention(qkv, gate, table, B, T, H, out_split=e_sp)
+            # K and V leave the projection pre-split (every query block of a head re-split the same keys otherwise); Q stays fp32
+            kv_sp = e_sp and ops.attention_mode() == "f16x2"
+            qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"], x_split=e_sp, out_split=E if kv_sp else False)
+            att = ops.wavlm_attention(qkv, gate, table, B, T, H, out_split=e_sp, kv_split=kv_sp)
             x = ops.linear(att, ly["wo"], ly["bo"], resid=x, x_split=e_sp)
             xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"], out_split=e_sp)
             hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU, x_split=e_sp, out_split=h_sp)

@@ -1,26 +1,24 @@
-"""Time the gated rel-pos attention kernel at the north-star shape (21 x 1500 frames, 16 heads)."""
+"""Attention micro-benchmark (WavLM-Large layer shape: 21 chunks x 1500 frames, 16 heads of 64): fp32 K/V vs K/V
+pre-split to the f16x2 layout by the QKV projection (kv_split)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from knn_svc_amd import ops
-B, T, H = 21, 1500, 16
-torch.manual_seed(0)
-qkv = torch.randn(B, T, 3 * H * 64, device="cuda")
-gate = torch.rand(B, T, H, device="cuda") * 2
-table = torch.randn(H, 2 * T - 1, device="cuda")
-for _ in range(2): y = ops.wavlm_attention(qkv, gate, table, B, T, H)
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(10): y = ops.wavlm_attention(qkv, gate, table, B, T, H)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 10
-fl = 4.0 * B * H * T * T * 64
-print(f"attention {B}x{T}x{H}: {ms:.3f} ms, {fl / ms / 1e9:.1f} TF/s fp32-equivalent")
-# reference check on one batch row in fp64
-q, k, v = qkv[0].double().view(T, 3, H, 64).unbind(1)
-s = torch.einsum("thd,shd->hts", q * 0.125, k)
-idx = torch.arange(T, device="cuda")
-rel = (idx[None, :] - idx[:, None] + T - 1)
-s = s + gate[0].double().t()[:, :, None] * table.double()[:, rel]
-o = torch.einsum("hts,shd->thd", s.softmax(-1), v).reshape(T, H * 64)
-yy = y.view(B, T, H * 64); print("max abs err vs fp64:", (yy[0].double() - o).abs().max().item(), "rms", ((yy[0].double() - o).pow(2).mean().sqrt() / o.pow(2).mean().sqrt()).item())
+B, T, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (21, 1500, 16)))
+E = H * 64
+qkv = torch.randn(B * T, 3 * E, device="cuda") * 0.5
+gate = torch.rand(B * T, H, device="cuda")
+table = torch.randn(H, 2 * T - 1, device="cuda") * 0.1
+qkv2 = qkv.clone()
+qkv2[:, E:] = ops.split_pack(qkv[:, E:].contiguous())
+flop = 4.0 * T * T * 64 * H * B
+for name, x, kv in (("fp32 K/V", qkv, False), ("pre-split K/V", qkv2, True)):
+    for _ in range(2): y = ops.wavlm_attention(x, gate, table, B, T, H, kv_split=kv)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10): y = ops.wavlm_attention(x, gate, table, B, T, H, kv_split=kv)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"{name:14s} B={B} T={T} H={H}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s fp32-equivalent")
+    if kv: print("max |diff| between the two:", float((y - y0).abs().max()))
+    y0 = y
