@@ -74,7 +74,8 @@ typedef struct knnsvc_conv_desc {
     float w_f16x2_scale;               /* the power-of-two scale w_f16x2 was split with                         */
     float a_f16x2_scale;               /* power-of-two activation pre-scale of the f16x2 path; 0 = default 16    */
     int32_t x_f16x2;                   /* 1: x already is in the f16x2 split layout (see below), scale 16           */
-    int32_t out_f16x2;                 /* 1: write out in the f16x2 split layout (scale 16) for the next GEMM       */
+    int32_t out_f16x2;                 /* 1: write out in the f16x2 split layout (scale 16) for the next GEMM;      */
+                                       /* c >= 32 (multiple of 32): only columns >= c are split (QKV: K,V blocks)   */
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
