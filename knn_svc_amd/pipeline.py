@@ -9,6 +9,11 @@ of item i on one tail stream behind an event, so the recurrences of one item run
 work of its neighbours.  Every item still does all of its work; only the order of enqueueing changes, and the
 results are bit-identical to the sequential order (same kernels, same inputs).
 
+Constraint: a captured hipGraph owns its input / output / scratch buffers, so the SAME graph must not be replayed from
+two lanes at once (`WavLMEncoder.encode_batch`, `Vocoder.forward`): heads that encode use one lane (bench.py), heads that
+only match may use several (dataset mode), the generator runs on the single tail stream.  Replaying one encoder graph
+from two lanes aborts the process (observed), it does not merely race.
+
 HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that share a queue
 serialise.  knn_svc_amd/__init__.py raises the default to 8 before the runtime starts.
 """
