@@ -39,6 +39,32 @@ def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def shard_rows(n_local: int, device) -> list:
+    """Row counts of every rank's shard (one tiny all-gather); [n_local] without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(n_local)]
+    _r, ws = world()
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    out = torch.empty(ws, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(v) for v in out.tolist()]
+
+
+def all_gather_rows_var(t: torch.Tensor, counts=None) -> torch.Tensor:
+    """all_gather_rows for shards of DIFFERENT row counts (a real speaker pool rarely divides evenly): every rank pads
+    to the largest shard, one all-gather, the padding rows are dropped.  ``counts`` = shard_rows(...) if already known."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    counts = counts if counts is not None else shard_rows(t.shape[0], t.device)
+    if len(set(counts)) == 1:
+        return all_gather_rows(t)
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    g = all_gather_rows(pad).view((len(counts), mx) + tuple(t.shape[1:]))
+    return torch.cat([g[r, :c] for r, c in enumerate(counts)], 0)
+
+
 def _hip_local_topk(q, pool, k, offset):
     from . import ops
     return ops.knn_topk(q, pool, k, idx_offset=offset, check_nan=False)
@@ -53,15 +79,16 @@ def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, lo
                 merge=_hip_merge):
     """Top-k of every rank's queries against the union of all ranks' pool shards.
 
-    q_local [nq, D] (same nq on every rank), pool_local [np, D] (same np on every rank; global row of
-    local row j on rank r is r*np + j).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's
-    queries."""
+    q_local [nq, D] (same nq on every rank), pool_local [np_r, D]: shards may differ in size (each must hold >= k
+    rows); the global row of local row j on rank r is sum(np_0 .. np_{r-1}) + j, i.e. the row order of
+    all_gather_rows_var(pool_local).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's queries."""
     rank, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
         return local_topk(q_local, pool_local, k, 0)
     nq = q_local.shape[0]                 # (a 1-rank group still walks the collective path: it is the same code)
+    counts = shard_rows(pool_local.shape[0], q_local.device)
     q_all = all_gather_rows(q_local)                                           # [ws*nq, D]
-    idx, dst = local_topk(q_all, pool_local, k, rank * pool_local.shape[0])    # vs my shard, global ids
+    idx, dst = local_topk(q_all, pool_local, k, sum(counts[:rank]))            # vs my shard, global ids
     dist_all = all_gather_rows(dst[None])                                      # [ws, ws*nq, k]
     idx_all = all_gather_rows(idx[None])
     mine = slice(rank * nq, (rank + 1) * nq)

@@ -102,3 +102,35 @@ def test_work_sharing_single_process():
     sys.path.insert(0, ROOT)
     from knn_svc_amd import dist as kd
     assert kd.my_share([1, 2, 3]) == [1, 2, 3] and kd.gather_paths(["a"]) == ["a"]
+
+
+def _uneven_worker(rank, ws, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from knn_svc_amd import dist as kd, synthetic as S
+    pool = S.clustered_features(700, 64, 9, n_centres=12)
+    cut = 437                                               # shards of 437 and 263 rows
+    mine = pool[:cut] if rank == 0 else pool[cut:]
+    q = S.clustered_features(30, 64, 200 + rank, n_centres=12)
+    idx, d = kd.sharded_knn(q, mine.contiguous(), 8, _cpu_local_topk, _cpu_merge)
+    ref_i, ref_d = _cpu_local_topk(q, pool, 8, 0)
+    whole = kd.all_gather_rows_var(mine.contiguous())
+    out[rank] = bool(torch.equal(d, ref_d)) and bool((idx == ref_i).float().mean() > 0.99) and bool(torch.equal(whole, pool)) \
+        and kd.shard_rows(mine.shape[0], mine.device) == [437, 263]
+    dist.destroy_process_group()
+
+
+def test_sharded_knn_uneven_shards_gloo_world2():
+    """BASELINE cfg 4: a real speaker pool does not divide evenly over the ranks — global rows follow the cumulative
+    shard sizes and the row all-gather pads to the largest shard."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out[0] and out[1]
