@@ -76,23 +76,38 @@ def _hip_merge(part_dist, part_idx):
 
 
 def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, local_topk=_hip_local_topk,
-                merge=_hip_merge):
+                merge=_hip_merge, replicated: bool = False):
     """Top-k of every rank's queries against the union of all ranks' pool shards.
 
     q_local [nq, D] (same nq on every rank), pool_local [np_r, D]: shards may differ in size (each must hold >= k
     rows); the global row of local row j on rank r is sum(np_0 .. np_{r-1}) + j, i.e. the row order of
-    all_gather_rows_var(pool_local).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's queries."""
+    all_gather_rows_var(pool_local).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's queries.
+    ``replicated``: every rank holds the SAME queries (one conversion against a sharded pool, BASELINE cfg 4): they
+    are not gathered, each rank searches them once in its shard and every rank ends up with the same merged lists."""
     rank, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
         return local_topk(q_local, pool_local, k, 0)
     nq = q_local.shape[0]                 # (a 1-rank group still walks the collective path: it is the same code)
     counts = shard_rows(pool_local.shape[0], q_local.device)
+    if replicated:
+        idx, dst = local_topk(q_local, pool_local, k, sum(counts[:rank]))
+        return merge(all_gather_rows(dst[None]).contiguous(), all_gather_rows(idx[None]).contiguous())
     q_all = all_gather_rows(q_local)                                           # [ws*nq, D]
     idx, dst = local_topk(q_all, pool_local, k, sum(counts[:rank]))            # vs my shard, global ids
     dist_all = all_gather_rows(dst[None])                                      # [ws, ws*nq, k]
     idx_all = all_gather_rows(idx[None])
     mine = slice(rank * nq, (rank + 1) * nq)
     return merge(dist_all[:, mine].contiguous(), idx_all[:, mine].contiguous())
+
+
+def contiguous_share(n: int):
+    """[lo, hi) of n ordered units for this rank: contiguous, balanced ranges in rank order, so that concatenating the
+    ranks' parts reproduces the single-process order (pool files keep their global row order — the concat cost's
+    "next frame" is row + 1)."""
+    rank, ws = world()
+    base, rem = divmod(n, ws)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
 
 
 def my_share(items):

@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import audio_io, config as C, features, ops, pipeline, pool_cache
+from . import audio_io, config as C, dist as kdist, features, ops, pipeline, pool_cache
 from .wavlm import WavLMEncoder, chunk_plan
 
 AUDIO_EXT = {".flac", ".wav", ".mp3"}
@@ -81,12 +81,14 @@ def side_features(wav_gpu: torch.Tensor, f0_host: np.ndarray, T: int):
 
 
 def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_weights=None, device="cuda",
-                          duration_limit=None, vad_trigger_level=0):
+                          duration_limit=None, vad_trigger_level=0, shard_files=False):
     """Per-file dicts (matching_pool, synth_pool, audio_synth_pool, spec_synth_pool, f0_pool, harmonics_pool),
     like the reference.  matching == synth features (both weightings are the same one-hot on the live path);
     ``audio_synth_pool`` is kept as None values: the live path never reads it (audio_out_feats_weighted = None,
     ddsp_prematch_dataset.py:1368).  Per-file results are kept in the device-resident pool store
-    (knn_svc_amd/pool_cache.py) so that dataset mode encodes every file once instead of once per speaker pair."""
+    (knn_svc_amd/pool_cache.py) so that dataset mode encodes every file once instead of once per speaker pair.
+    ``shard_files`` (one process per GPU): every rank walks the same file list and duration limit, but encodes and
+    returns only its contiguous share of the kept files (dist.contiguous_share) — the pool shard of BASELINE cfg 4."""
     dev = wavlm.device
     files = list_audio(path)
     cache = _pool_cache()
@@ -106,11 +108,13 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
         else:
             w, f0 = load_utterance(pth)
             T = frames_of(len(w), wavlm)
-            loaded[i] = (torch.from_numpy(w).to(dev), f0)
+            loaded[i] = (w, f0)                                   # host arrays: only this rank's share goes to the device
         kept.append(str(pth)); keys.append(key); Ts.append(T)
         dur += T * C.HOP / C.SAMPLE_RATE
         if duration_limit is not None and dur >= duration_limit:
             break
+    lo, hi = kdist.contiguous_share(len(kept)) if shard_files else (0, len(kept))
+    loaded = {i: (torch.from_numpy(v[0]).to(dev), v[1]) for i, v in loaded.items() if lo <= i < hi}
     miss = sorted(loaded)
     feats = wavlm.encode_many([loaded[i][0] for i in miss]) if miss else []
     for i, ft in zip(miss, feats):
@@ -120,6 +124,8 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
         loaded[i] = dict(feats=ft, f0=f0, harm=harm, spec=spec)
     matching, synth, audio, specs, f0p, harmp = {}, {}, {}, {}, {}, {}
     for i, key in enumerate(kept):
+        if not lo <= i < hi:
+            continue
         ent = loaded[i] if i in loaded else cache.get(keys[i])
         matching[key] = ent["feats"]; synth[key] = ent["feats"]; audio[key] = None
         specs[key] = ent["spec"]; f0p[key] = ent["f0"]; harmp[key] = ent["harm"]
@@ -227,7 +233,8 @@ def _layer_of(weights) -> int:
 def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, match_weights=None, synth_weights=None,
                             topk: int = 4, device="cuda", prioritize_f0=False, ckpt_type="wavlm_only",
                             src_dataset_path=None, tgt_dataset_path=None, cache_dir=None, required_subset=None,
-                            post_opt="no_post_opt", duration_limit=None, vocode_fn=None, waves_out=None):
+                            post_opt="no_post_opt", duration_limit=None, vocode_fn=None, waves_out=None,
+                            pool_sharded=None):
     """Same contract as the reference function (ddsp_prematch_dataset.py:1074).  ``topk`` is accepted and
     ignored (k = 32 -> 4 is hard-coded upstream, :1203,1246,1398); ``cache_dir`` is ignored (the reference
     force-disables it, :1086-1087).
@@ -235,7 +242,17 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     Build extension (BASELINE cfg 5, many sources against one pool): ``vocode_fn(out_feats, shifted_f0, harm)`` is
     enqueued as the pipeline's tail stage right behind each item's match body and its waveform stored in
     ``waves_out[item]`` — the generator of item i then runs underneath the kNN / recurrences of items i+1.., instead
-    of after all of them.  It must not synchronise with the host."""
+    of after all of them.  It must not synchronise with the host.
+
+    ``pool_sharded`` (default: environment KNNSVC_POOL_SHARD=1; needs a process group, one process per GPU; BASELINE
+    cfg 4): the target pool's files are encoded in contiguous shares over the ranks, every rank searches the (replicated)
+    query frames in its own shard, the per-shard top-32 lists are merged after one RCCL all-gather, and the pool's
+    features / f0 / harmonics are all-gathered once (rank order = file order, so rows mean what they mean on one GPU).
+    Every rank then holds the same neighbours and runs the same later stages."""
+    import torch.distributed as tdist
+    if pool_sharded is None:         # by environment: only when there is more than one rank to shard over
+        pool_sharded = os.environ.get("KNNSVC_POOL_SHARD") == "1" and kdist.world()[1] > 1
+    pool_sharded = bool(pool_sharded) and tdist.is_available() and tdist.is_initialized()   # explicit True: any group, even 1 rank
     assert prioritize_f0, "prioritize_f0=False is unsupported by the reference (ddsp_prematch_dataset.py:1375)"
     if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type and "mix" not in ckpt_type:
         raise NotImplementedError(ckpt_type)
@@ -248,11 +265,21 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     if tgt_dataset_path is None:
         assert os.path.isfile(ref_wav_file)
     matching_pool, _synth, _audio, _spec, f0_pool, harm_pool = get_complete_spk_pool(
-        ref_wav_file, wavlm, device=device, duration_limit=duration_limit)
+        ref_wav_file, wavlm, device=device, duration_limit=duration_limit, shard_files=pool_sharded)
     keys = list(matching_pool)
-    matching_list = torch.cat([matching_pool[k] for k in keys], 0).contiguous()
-    matching_f0 = torch.cat([f0_pool[k] for k in keys], 0).contiguous()
-    harmonics_list = torch.cat([harm_pool[k] for k in keys], 0).contiguous()
+    E = wavlm.E
+    cat = lambda pool, shape: (torch.cat([pool[k] for k in keys], 0).contiguous() if keys
+                               else torch.empty(shape, device=wavlm.device, dtype=torch.float32))
+    matching_list, matching_f0, harmonics_list = cat(matching_pool, (0, E)), cat(f0_pool, (0,)), cat(harm_pool, (0, C.N_HARM))
+    shard = None
+    if pool_sharded:
+        shard = matching_list                                      # this rank's rows, searched locally
+        counts = kdist.shard_rows(shard.shape[0], shard.device)
+        if min(counts) < C.KNN_K:
+            raise ops.KnnSvcError(f"pool shards {counts}: every rank needs at least {C.KNN_K} pool frames")
+        matching_list = kdist.all_gather_rows_var(shard, counts)
+        matching_f0 = kdist.all_gather_rows_var(matching_f0, counts)
+        harmonics_list = kdist.all_gather_rows_var(harmonics_list, counts)
 
     out_c, harm_c, audio_c, f0_c = {}, {}, {}, {}
     items = [item for item in query_pool
@@ -262,8 +289,12 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
     flags = []
     prep = prepare_pool(matching_list) if len(items) > 1 else None
+    nn = {}
+    if shard is not None:            # collectives first, in item order on every rank; the match bodies then need none
+        for item in items:
+            nn[item] = kdist.sharded_knn(query_pool[item].contiguous(), shard, C.KNN_K, replicated=True)[0]
     body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
-                                       harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep)
+                                       harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
     lanes = min(3, len(items))
     if vocode_fn is not None and len(items) > 0:
         assert waves_out is not None

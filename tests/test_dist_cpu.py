@@ -116,8 +116,17 @@ def _uneven_worker(rank, ws, port, out):
     idx, d = kd.sharded_knn(q, mine.contiguous(), 8, _cpu_local_topk, _cpu_merge)
     ref_i, ref_d = _cpu_local_topk(q, pool, 8, 0)
     whole = kd.all_gather_rows_var(mine.contiguous())
-    out[rank] = bool(torch.equal(d, ref_d)) and bool((idx == ref_i).float().mean() > 0.99) and bool(torch.equal(whole, pool)) \
+    ok = bool(torch.equal(d, ref_d)) and bool((idx == ref_i).float().mean() > 0.99) and bool(torch.equal(whole, pool)) \
         and kd.shard_rows(mine.shape[0], mine.device) == [437, 263]
+    # one conversion against a sharded pool: the SAME queries on every rank, searched once per shard
+    qr = S.clustered_features(25, 64, 777, n_centres=12)
+    ri, rd = kd.sharded_knn(qr, mine.contiguous(), 8, _cpu_local_topk, _cpu_merge, replicated=True)
+    fi, fd = _cpu_local_topk(qr, pool, 8, 0)
+    ok = ok and bool(torch.equal(rd, fd)) and bool((ri == fi).float().mean() > 0.99)
+    # contiguous file shares reproduce the single-process order
+    lo, hi = kd.contiguous_share(11)
+    ok = ok and (lo, hi) == ((0, 6) if rank == 0 else (6, 11))
+    out[rank] = ok
     dist.destroy_process_group()
 
 

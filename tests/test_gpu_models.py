@@ -401,3 +401,32 @@ def test_sample_content_single_file_cli_path(golden, tmp_path):
         assert out.is_file()
         x, sr = audio_io.read_wav(str(out))
         assert sr == 16000 and x.shape[1] == ref.shape[0]
+
+
+def test_pool_sharded_single_file_path_equals_unsharded(golden, tmp_path):
+    """BASELINE cfg 4 orchestration (pool files sharded over ranks, replicated queries, per-shard top-32 merged after an
+    RCCL all-gather, pool side arrays all-gathered) forced through a ONE-rank process group: same waveform as the
+    unsharded path.  The multi-rank arithmetic of the merge is covered by tests/test_dist_cpu.py (gloo, world 2)."""
+    import os
+    import torch.distributed as dist
+    from knn_svc_amd import matching
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    cfg, h = C.WAVLM_TINY, C.HIFIGAN_TINY
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+    knn = KNeighborsVC(enc, Vocoder(S.seeded_state(S.generator_param_spec(h, "mix"), 63), h, "mix", DEV), h, DEV)
+    srcp, poolp = _write_tiny_dataset(tmp_path, golden("g11_e2e"))
+    common = dict(topk=4, device=DEV, prioritize_f0=True, ckpt_type="mix", post_opt="post_opt_0.2", tgt_dataset_path=tmp_path)
+    from pathlib import Path
+    ref = matching.match_at_inference_time(Path(srcp), poolp, enc, knn.weighting, knn.weighting, pool_sharded=False, **common)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        got = matching.match_at_inference_time(Path(srcp), poolp, enc, knn.weighting, knn.weighting, pool_sharded=True, **common)
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(ref, got):
+        for k in a:
+            if a[k] is not None:
+                assert torch.equal(a[k], b[k]), k
