@@ -146,7 +146,8 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
     for t in (qf0, Pf0_loc, Ph_loc):
         t.record_stream(main)
     with stage("knn"):
-        nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K)
+        # equal shards by construction: pass the sizes instead of letting sharded_knn read them back (a host sync)
+        nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K, counts=[P_loc.shape[0]] * kdist.world()[1])
     with stage("gather"):
         P = kdist.all_gather_rows(P_loc)
         Pf0 = kdist.all_gather_rows(Pf0_loc)

@@ -76,19 +76,22 @@ def _hip_merge(part_dist, part_idx):
 
 
 def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, local_topk=_hip_local_topk,
-                merge=_hip_merge, replicated: bool = False):
+                merge=_hip_merge, replicated: bool = False, counts=None):
     """Top-k of every rank's queries against the union of all ranks' pool shards.
 
     q_local [nq, D] (same nq on every rank), pool_local [np_r, D]: shards may differ in size (each must hold >= k
     rows); the global row of local row j on rank r is sum(np_0 .. np_{r-1}) + j, i.e. the row order of
     all_gather_rows_var(pool_local).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's queries.
     ``replicated``: every rank holds the SAME queries (one conversion against a sharded pool, BASELINE cfg 4): they
-    are not gathered, each rank searches them once in its shard and every rank ends up with the same merged lists."""
+    are not gathered, each rank searches them once in its shard and every rank ends up with the same merged lists.
+    ``counts``: the shard sizes if the caller already knows them (shard_rows() reads them back to the host — a
+    synchronisation a stream pipeline must not have inside its steps)."""
     rank, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
         return local_topk(q_local, pool_local, k, 0)
     nq = q_local.shape[0]                 # (a 1-rank group still walks the collective path: it is the same code)
-    counts = shard_rows(pool_local.shape[0], q_local.device)
+    counts = list(counts) if counts is not None else shard_rows(pool_local.shape[0], q_local.device)
+    assert len(counts) == ws and counts[rank] == pool_local.shape[0], (counts, rank, pool_local.shape)
     if replicated:
         idx, dst = local_topk(q_local, pool_local, k, sum(counts[:rank]))
         return merge(all_gather_rows(dst[None]).contiguous(), all_gather_rows(idx[None]).contiguous())
