@@ -145,11 +145,13 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
     main.wait_stream(side)
     for t in (qf0, Pf0_loc, Ph_loc):
         t.record_stream(main)
+    # the pool all-gather (123 MB per rank) starts now and travels under the local kNN search; waited for below
+    P, wait_P = kdist.all_gather_rows_async(P_loc)
     with stage("knn"):
         # equal shards by construction: pass the sizes instead of letting sharded_knn read them back (a host sync)
         nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K, counts=[P_loc.shape[0]] * kdist.world()[1])
     with stage("gather"):
-        P = kdist.all_gather_rows(P_loc)
+        wait_P()
         Pf0 = kdist.all_gather_rows(Pf0_loc)
         Ph = kdist.all_gather_rows(Ph_loc)
     return dict(qf=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, nn32=nn32)

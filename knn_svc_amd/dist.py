@@ -39,6 +39,18 @@ def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def all_gather_rows_async(t: torch.Tensor):
+    """all_gather_rows started now and waited for later: returns (out, wait) where wait() makes the CURRENT stream wait
+    for the collective (no host block).  Kernels enqueued between the two calls run while the bytes travel — the pool
+    all-gather of a step flies under the rank's local kNN search."""
+    _r, ws = world()
+    if not (dist.is_available() and dist.is_initialized()):
+        return t, (lambda: None)
+    out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    work = dist.all_gather_into_tensor(out, t.contiguous(), async_op=True)
+    return out, work.wait
+
+
 def shard_rows(n_local: int, device) -> list:
     """Row counts of every rank's shard (one tiny all-gather); [n_local] without a process group."""
     if not (dist.is_available() and dist.is_initialized()):
