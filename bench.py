@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=32, help="30 s chunks per WavLM batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print per-stage ms to stderr")
+    ap.add_argument("--timed-only", action="store_true", help="tracing aid: stop after the timed region (no latency / roofline passes, no JSON line)")
     ap.add_argument("--pipeline-depth", type=int, default=2, choices=(1, 2),
                     help="2 = overlap match+vocoder of conversion i with the encoder of conversion i+1 (default); 1 = sequential")
     a = ap.parse_args()
@@ -292,6 +293,12 @@ def main():
         y = run_steps(a.steps, a.pipeline_depth, *args)
         barrier()
         dt = time.perf_counter() - t0
+        if a.timed_only:
+            if rank == 0:
+                print(f"timed region only: {dt / a.steps * 1e3:.3f} ms/step", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            return
         # latency of ONE conversion with nothing overlapped (reported next to the throughput figure)
         t1 = time.perf_counter()
         run_steps(a.steps, 1, *args)
