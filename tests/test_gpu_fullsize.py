@@ -150,3 +150,75 @@ def test_edge_cases():
     exc = ops.additive_synth(torch.zeros(4, device=DEV), torch.rand(4, 49, device=DEV), torch.randn(32, 3, device=DEV),
                              torch.zeros(32, device=DEV), cond, 32, want_exc=True)
     assert bool(torch.isfinite(exc).all()) and float(exc.abs().max()) < 1e-3
+
+
+def test_knn_multi_chunk_pool_and_mask_across_chunks():
+    """Pools above 262 144 rows are searched in balanced chunks whose lists are folded by knnsvc_knn_merge (every buffer
+    resource stays below 1 GiB).  300 000 x 1024 (1.2 GB): sampled rows against the oracle, the chunked result equals a
+    search over explicit shards, and a self-mask that straddles the chunk boundary behaves like an unchunked one."""
+    from knn_svc_amd import ops
+    from oracle import knn_ref
+    np_rows = 300_000
+    base = _smooth(S.clustered_features(30_000, 1024, 12, n_centres=120))
+    g = torch.Generator().manual_seed(13)
+    p = torch.cat([base * (1.0 + 0.01 * i) + 0.02 * torch.randn(30_000, 1024, generator=g) for i in range(10)], 0)
+    q = _smooth(S.clustered_features(400, 1024, 14, n_centres=120))
+    pd, qd = p.to(DEV), q.to(DEV)
+    assert len(ops.prepare_knn_pool(pd, 32)) == 2                                # the two-chunk route
+    idx, dist = ops.knn_topk(qd, pd, 32)
+    idx_c, dist_c = idx.cpu(), dist.cpu()
+    assert bool((dist_c[:, 1:] >= dist_c[:, :-1]).all()) and int(idx_c.max()) < np_rows and int(idx_c.min()) >= 0
+    assert int((idx_c >= 150_000).sum()) > 0 and int((idx_c < 150_000).sum()) > 0  # neighbours come from both chunks
+    rows = torch.arange(0, 400, 37)
+    ref_i, ref_d = knn_ref.knn_topk(q[rows], p, 32)
+    st = knn_ref.topk_agreement(ref_i, idx_c[rows], knn_ref.cosine_dist_f64(q[rows], p), tau=5e-7)
+    print("300k-row pool, sampled rows:", st)
+    assert st["unexplained"] == 0 and float((dist_c[rows] - ref_d).abs().max()) < 5e-6
+    # explicit shards at other boundaries give the same merged lists
+    cuts = [0, 70_000, 200_000, np_rows]
+    parts = [ops.knn_topk(qd, pd[a:b].contiguous(), 32, idx_offset=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    mi, md = ops.knn_merge(torch.stack([d for _, d in parts]), torch.stack([i for i, _ in parts]))
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
+    # a mask across the chunk boundary (rows 149 990 .. 150 010 compete at distance exactly 1)
+    lo, hi = 149_990, 150_010
+    qm = p[lo:hi].to(DEV).contiguous()                                          # the masked rows query themselves
+    mi2, md2 = ops.knn_topk(qm, pd, 32, mask=(lo, hi))
+    inside = (mi2 >= lo) & (mi2 < hi)
+    assert bool((md2[inside] == 1.0).all())
+    assert not bool(((mi2[:, 0] >= lo) & (mi2[:, 0] < hi)).any())                # themselves no longer first
+    del pd
+    torch.cuda.empty_cache()
+
+
+def test_prematch_speaker_full_size_properties():
+    """per_spk_extract's per-speaker body at BASELINE pool size (20 utterances x 1500 frames): bookkeeping and the
+    invariants the reference's consumer relies on (hifigan/ddsp_meldataset.py:473-499), plus sampled rows against the
+    oracle's masked search."""
+    from knn_svc_amd import prematch
+    from oracle import prematch_ref
+    n_utt, T = 20, 1500
+    feats = _smooth(S.clustered_features(n_utt * T, 1024, 21, n_centres=90))
+    g = torch.Generator().manual_seed(22)
+    spec = torch.rand(n_utt * T, 200, generator=g) + 0.01
+    _, f0 = S.synth_clip(n_utt * T * 320, 23)
+    f0 = torch.from_numpy(f0[:n_utt * T].copy())
+    harm = torch.rand(n_utt * T, 49, generator=g) * 0.05
+    mk = lambda x: {f"u{i:02d}": x[i * T:(i + 1) * T].contiguous().to(DEV) for i in range(n_utt)}
+    res = prematch.match_speaker(mk(feats), mk(spec), mk(f0), mk(harm))
+    pool_h = res["pool"].cpu()
+    assert torch.equal(pool_h, feats.half().float())                       # fp16-rounded pool, bit for bit
+    assert [it["slice"] for it in res["items"]] == [(i * T, (i + 1) * T) for i in range(n_utt)]
+    for i in (0, 7, 19):
+        it = res["items"][i]
+        nn, nnf, ar, w = (it[k].cpu() for k in ("nearest_nbrs", "nearest_nbrs_f0_priority", "amp_ratio", "harmonics_best_weight_para"))
+        s, e = it["slice"]
+        assert nn.shape == (T, 32) and not bool(((nn >= s) & (nn < e)).any())          # own utterance masked out
+        assert bool((nnf.sort(1).values == nn.sort(1).values).all())                    # the f0 re-sort is a permutation
+        assert bool((ar > 0).all()) and bool(torch.isfinite(ar).all())
+        assert float((w.sum(1) - 1).abs().max()) < 1e-5 and bool((w >= 0).all())
+        rows = torch.arange(0, T, 211)
+        ref = prematch_ref.self_knn(feats[s:e][rows], pool_h, s, e)
+        assert float((ref[:, :4] == nn[rows][:, :4]).float().mean()) > 0.95
+        assert float(np.mean([set(a.tolist()) == set(b.tolist()) for a, b in zip(ref, nn[rows])])) > 0.85
+        ra = prematch_ref.amp_ratio(spec[s:e][rows], spec, nnf[rows][:, :4])
+        assert float(((ra - ar[rows]).abs() / ra).max()) < 2e-6
