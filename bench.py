@@ -248,7 +248,7 @@ def cpu_baseline(snap):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--max-batch", type=int, default=32, help="30 s chunks per WavLM batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")

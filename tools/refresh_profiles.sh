@@ -5,16 +5,16 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/profiles_$tag; mkdir -p $O
 cd $R
-timeout 900 python3 bench.py --steps 5 --warmup 2 --stages > $O/bench.out 2> $O/bench.err
+timeout 900 python3 bench.py --steps 10 --warmup 2 --stages > $O/bench.out 2> $O/bench.err
 tail -1 $O/bench.out > $O/${tag}_bench_n1.json
 grep '^\[stage\]' $O/bench.err > $O/${tag}_bench_n1_stages.txt
 grep '^\[gemm\]' $O/bench.err > $O/${tag}_bench_n1_gemm_shapes.txt
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/${tag}_bench_n1_kernel_stats.csv
 cp $(ls $O/kt/*/*domain_stats.csv | head -1) $O/${tag}_bench_n1_domain_stats.csv
 # the same command with conversions run one at a time: per-kernel durations without cross-conversion overlap
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --pipeline-depth 1 > $O/kts.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --pipeline-depth 1 > $O/kts.log 2>&1
 cp $(ls $O/kts/*/*kernel_stats.csv | head -1) $O/${tag}_bench_n1_sequential_kernel_stats.csv
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmcf.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmcw.log 2>&1
