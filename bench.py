@@ -315,6 +315,7 @@ def main():
         barrier()
         timer.enabled = False
         enc.use_graphs = voc.use_graphs = True
+    kdist.raise_if_any_nan()                                            # the deferred NaN flags of every sharded search of this run
     assert y.numel() == SRC_SECONDS * C.SAMPLE_RATE, y.numel()          # 1500 frames x 320
     assert bool(torch.isfinite(y).all()), "non-finite waveform"
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)

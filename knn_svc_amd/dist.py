@@ -77,9 +77,28 @@ def all_gather_rows_var(t: torch.Tensor, counts=None) -> torch.Tensor:
     return torch.cat([g[r, :c] for r, c in enumerate(counts)], 0)
 
 
+_NAN_FLAGS = []      # device flags of the per-shard searches since the last raise_if_any_nan()
+
+
 def _hip_local_topk(q, pool, k, offset):
     from . import ops
-    return ops.knn_topk(q, pool, k, idx_offset=offset, check_nan=False)
+    idx, d, flag = ops.knn_topk(q, pool, k, idx_offset=offset, check_nan=False, return_flag=True)
+    _NAN_FLAGS.append(flag)          # read later, once (a read here would synchronise every step of a stream pipeline)
+    return idx, d
+
+
+def raise_if_any_nan():
+    """The reference exits when any distance is NaN (lib_ongaku_test.py:166-169).  The sharded searches defer that check:
+    this reads their flags once, takes the maximum over the ranks (so that every rank raises together) and raises."""
+    if not _NAN_FLAGS:
+        return
+    f = torch.stack([x.reshape(()) for x in _NAN_FLAGS]).max().reshape(1)
+    _NAN_FLAGS.clear()
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+    if int(f.item()) != 0:
+        from . import ops
+        raise ops.KnnSvcError("containing nan")
 
 
 def _hip_merge(part_dist, part_idx):

@@ -293,6 +293,7 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     if shard is not None:            # collectives first, in item order on every rank; the match bodies then need none
         for item in items:
             nn[item] = kdist.sharded_knn(query_pool[item].contiguous(), shard, C.KNN_K, replicated=True, counts=counts)[0]
+        kdist.raise_if_any_nan()
     body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
                                        harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
     lanes = min(3, len(items))

@@ -430,3 +430,20 @@ def test_pool_sharded_single_file_path_equals_unsharded(golden, tmp_path):
         for k in a:
             if a[k] is not None:
                 assert torch.equal(a[k], b[k]), k
+
+
+def test_sharded_search_reports_nan_once_agreed():
+    """The per-shard searches defer the reference's NaN exit (lib_ongaku_test.py:166-169): dist.raise_if_any_nan() reads
+    the flags once and raises."""
+    from knn_svc_amd import dist as kd, ops
+    q = S.clustered_features(64, 64, 3, n_centres=5).to(DEV)
+    p = S.clustered_features(500, 64, 4, n_centres=5)
+    kd._NAN_FLAGS.clear()
+    kd._hip_local_topk(q, p.to(DEV), 8, 0)
+    kd.raise_if_any_nan()                                   # clean pool: nothing raised, flags drained
+    assert not kd._NAN_FLAGS
+    p[77, 5] = float("nan")
+    kd._hip_local_topk(q, p.to(DEV), 8, 0)
+    with pytest.raises(ops.KnnSvcError):
+        kd.raise_if_any_nan()
+    assert not kd._NAN_FLAGS
