@@ -621,7 +621,7 @@ int launch2ring(const ConvArgs& a, int batches, hipStream_t st) {
     return knnsvc_check_launch("conv_gemm2ring");
 }
 
-template <class G>
+template <class G, bool A2>
 __global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int z = blockIdx.z;
@@ -647,24 +647,29 @@ __global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     typedef FastALoader<G::A_F4, G::RS> AL;
     AL al(a, m0, threadIdx.x);
-    G::mainloop(lds, a.K / 32, al, acc, AL::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)), a.n, a.K, n0,
+    G::template mainloop<A2>(lds, a.K / 32, al, acc, AL::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)), a.n, a.K, n0,
                 a.a_scale);
-    conv_epilogue<G>(a, acc, m0, n0, b, g);
+    conv_epilogue_lin<G>(a, acc, m0, n0, b, g);      // dispatch guarantees a plain output below 2 GiB (a.lin)
 }
 
-template <class G>
-int launch2big(const ConvArgs& a, int batches, hipStream_t st) {
+template <class G, bool A2>
+int launch2big_v(const ConvArgs& a, int batches, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_gemm2big_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_gemm2big_kernel<G, A2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G::LDS_BYTES) != hipSuccess)
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
     const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;          // row tiles padded to whole groups of 8 (one per XCD)
     dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2big_kernel<G>), grid, dim3(G::THREADS), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_gemm2big_kernel<G, A2>), grid, dim3(G::THREADS), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2big");
+}
+
+template <class G>
+int launch2big(const ConvArgs& a, int batches, hipStream_t st) {
+    return a.x_split ? launch2big_v<G, true>(a, batches, st) : launch2big_v<G, false>(a, batches, st);
 }
 
 template <class G, bool A2>
@@ -848,7 +853,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         // higher sustained clock (1.65 vs 1.39 GHz) — 279 vs 242 TFLOP/s on an isolated long-K GEMM (FFN2), but a lone
         // block per CU cannot hide its prologue/epilogue and loses when other streams share the chip (end-to-end bench:
         // 505 vs 511 xRT), so it is opt-in: KNNSVC_F256_KMIN=<smallest K that takes it> (read per qualifying launch).
-        if (d->n >= 256 && d->n % 256 == 0 && a.K >= 2048) {
+        if (d->n >= 256 && d->n % 256 == 0 && a.K >= 1024 && a.lin) {
             const char* e = getenv("KNNSVC_F256_KMIN");
             if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
                 { g_last_kernel = "F256"; return launch2big<F256>(a, d->batches, st); }

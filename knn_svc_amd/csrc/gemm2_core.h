@@ -207,7 +207,8 @@ struct Gemm2Big {
 
     // aload: fp32 A loader (begin(kt), operator()(kt, j, desc), finish()); rb_desc: buffer resource over the split
     // weights of this group ([N][K/32][2][32] fp16); n0: first weight row of the block
-    template <class ALoad, class RA, class RB>
+    // A2: the activations already are in the f16x2 split layout — staging is a 16-byte copy (as Gemm2Tile's A2 path)
+    template <bool A2 = false, class ALoad, class RA, class RB>
     __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, f32x16 (&acc)[TM][TN],
                                                     RA ra_desc, RB rb_desc, int N, int K, int n0, float a_scale) {
         static_assert(A_F4 < 16, "vmcnt immediate");
@@ -215,7 +216,7 @@ struct Gemm2Big {
         lds_c* lds = (lds_c*)lds_generic;
         const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wm = wave / WN, wn = wave % WN;
-        const int a_st = (tid >> 3) * PITCH + (tid & 7) * 8;
+        const int a_st = (tid >> 3) * PITCH + (tid & 7) * (A2 ? 16 : 8);
         const int li = lane & 31, lh = lane >> 5;
         const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
         const int b_row = BOFF + (wn * TN * 32 + li) * BROW;
@@ -258,10 +259,14 @@ struct Gemm2Big {
 #else
 #define KN_STAGE_A(BUFOFF)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                       \
-        g2_u32x2 hi, lo;                                                                                     \
-        f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                                  \
-        *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = hi;                                             \
-        *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH + 64) = lo;                                        \
+        if constexpr (A2) {                                                                                  \
+            *(lds_u4*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = __builtin_bit_cast(g2_u32x4, ra[j]);        \
+        } else {                                                                                             \
+            g2_u32x2 hi, lo;                                                                                 \
+            f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                              \
+            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = hi;                                         \
+            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH + 64) = lo;                                    \
+        }                                                                                                    \
     }
 #endif
 #define KN_RD_A(BUFOFF, KS, I, SLOT)                                                                          \

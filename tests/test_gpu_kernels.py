@@ -101,6 +101,10 @@ def test_linear_f16x2_big_tile(monkeypatch):
     err = float((o[rows].double() - ref).abs().max())
     print(f"big tile max err {err:.2e}")
     assert err < 2e-5 and bool(torch.isfinite(o).all())
+    # pre-split (A2) activations: staging is a plain copy; this combination produced NaN before the kernel had an A2 path
+    o2 = ops.linear(ops.split_pack(x.to(DEV)), wd, b.to(DEV), act=ops.ACT_GELU, x_split=True).cpu()
+    assert ops.last_conv_kernel() == "F256" and bool(torch.isfinite(o2).all())
+    assert float((o2[rows].double() - ref).abs().max()) < 2e-5
     monkeypatch.delenv("KNNSVC_F256_KMIN")
     o128 = ops.linear(x.to(DEV), wd, b.to(DEV), act=ops.ACT_GELU).cpu()
     assert float((o128 - o).abs().max()) < 2e-5
