@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 6
+#define KNNSVC_ABI_VERSION 7
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -217,6 +217,15 @@ int knnsvc_round_f16(const float* x, int64_t n, float* out, void* stream);
 /* amp_ratio[t,k] = ||spec_q[t,:]||_1 / (||spec_pool[idx[t,k],:]||_1 + 1e-5)   (:1657-1660) */
 int knnsvc_amp_ratio(const float* spec_q, int32_t ld_q, const float* spec_pool, int32_t ld_pool, int64_t np,
                      const int64_t* idx, int64_t nq, int32_t k, int32_t bins, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * f0 front end.  The reference runs pyworld.harvest(f0_floor 65, f0_ceil 1047, frame period 20 ms) and
+ * zeroes values below 80 Hz when no `<stem>_f0.npy` exists (ddsp_prematch_dataset.py:121-128, 376-379).  This is a YIN
+ * estimator with that interface (frame t at sample t*hop, n_frames = L/hop + 1), NOT a restatement of Harvest: parity with
+ * pyworld is unpinned (the library is absent offline).  threshold: YIN's absolute threshold (0.1 .. 0.2).
+ * ------------------------------------------------------------------------------------------ */
+int knnsvc_f0_yin(const float* x, int64_t L, int32_t sample_rate, int32_t hop, float f0_floor, float f0_ceil,
+                  float threshold, float zero_below, float* f0, int64_t n_frames, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pool side features and the additive synthesiser.

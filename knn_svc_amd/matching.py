@@ -54,9 +54,16 @@ def load_utterance(pth):
                               C.SAMPLE_RATE).cpu().numpy()[None]
     f0_path = os.path.splitext(str(pth))[0] + "_f0.npy"
     if not os.path.isfile(f0_path):
-        raise FileNotFoundError(
-            f"{f0_path} not found.  The reference would run pyworld.harvest here (ddsp_prematch_dataset.py:121-128, "
-            "376-379); pyworld is not available in this build — provide the f0 cache next to the audio file.")
+        if os.environ.get("KNNSVC_F0") != "yin":
+            raise FileNotFoundError(
+                f"{f0_path} not found.  The reference would run pyworld.harvest here (ddsp_prematch_dataset.py:121-128, "
+                "376-379); pyworld is not available in this build — provide the f0 cache next to the audio file, or set "
+                "KNNSVC_F0=yin to generate it with the GPU YIN estimator (same interface and cache file; NOT Harvest: "
+                "the track, and with it the conversion, will differ from the reference's).")
+        # same bookkeeping as the reference (:376-379): compute, warn, write the cache next to the audio
+        print(f"WARNING: {f0_path} not exists, generating (GPU YIN estimator, not pyworld.harvest)...")
+        f0_new = ops.f0_yin(torch.from_numpy(np.ascontiguousarray(x[0], dtype=np.float32)).cuda()).cpu().numpy()
+        np.save(f0_path, f0_new)
     f0 = np.asarray(np.load(f0_path, allow_pickle=True), dtype=np.float32)
     return np.ascontiguousarray(x[0], dtype=np.float32), f0
 

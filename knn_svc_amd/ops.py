@@ -457,6 +457,19 @@ def amp_ratio(spec_q, spec_pool, idx):
     return out
 
 
+# ------------------------------------------------------------------ f0 front end
+def f0_yin(wav_1d, sample_rate=16000, hop=320, f0_floor=65.0, f0_ceil=1047.0, threshold=0.15, zero_below=80.0):
+    """YIN f0 track with pyworld.harvest's interface as the reference calls it (ddsp_prematch_dataset.py:121-128):
+    [L] -> [L // hop + 1], 0 = unvoiced, values below 80 Hz zeroed.  Parity with pyworld unpinned."""
+    _need(wav_1d, name="f0_yin.wav")
+    wav_1d = wav_1d.contiguous()
+    n = wav_1d.numel() // hop + 1
+    out = torch.empty(n, device=wav_1d.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_f0_yin(_p(wav_1d), wav_1d.numel(), int(sample_rate), int(hop), float(f0_floor), float(f0_ceil),
+                                    float(threshold), float(zero_below), _p(out), n, _stream()), "f0_yin")
+    return out
+
+
 # ------------------------------------------------------------------ side features + synth
 def reflect_pad(x1d, pad, extra=0):
     """-> [n + 2 pad (+ extra zeros at the end)]"""
