@@ -447,3 +447,38 @@ def test_sharded_search_reports_nan_once_agreed():
     with pytest.raises(ops.KnnSvcError):
         kd.raise_if_any_nan()
     assert not kd._NAN_FLAGS
+
+
+def test_prematch_cli_entry_point(tmp_path, monkeypatch):
+    """`python ddsp_prematch_dataset.py --librispeech_path ... --out_path ... --prematch` (the reference's command line,
+    ddsp_prematch_dataset.py:1815-1831) end to end with seeded WavLM-Large weights: files of both speakers appear with the
+    reference's names and keys, a second invocation with --save_pool_only adds the pool_f0 / pool_spec arrays."""
+    import pickle
+    from knn_svc_amd import matching, pool_cache, prematch
+    monkeypatch.setenv("KNNSVC_SEEDED_WEIGHTS", "1")
+    matching._POOL_CACHE = pool_cache.PoolCache()
+    root = tmp_path / "train"
+    for s, spk in enumerate(("singerA", "singerB")):
+        (root / spk).mkdir(parents=True)
+        for u in range(3):
+            w, f = S.synth_clip(16000 + 640 * (s + u), seed=700 + 10 * s + u)
+            audio_io.write_wav_pcm16(str(root / spk / f"u{u}.wav"), w, 16000)
+            np.save(root / spk / f"u{u}_f0.npy", f)
+    out = tmp_path / "cached"
+    assert prematch.main(["--librispeech_path", str(root), "--out_path", str(out), "--topk", "4", "--matching_layer", "6",
+                          "--synthesis_layer", "6", "--prematch"]) == 0
+    for spk in ("singerA", "singerB"):
+        pool = np.load(out / spk / "pool.npy")
+        harm = np.load(out / spk / "pool_harmonics.npy")
+        assert pool.shape[1] == 1024 and harm.shape == (pool.shape[0], 49)
+        end = 0
+        for u in range(3):
+            with open(out / spk / f"u{u}.pt", "rb") as fh:
+                d = pickle.load(fh)
+            assert d["slice"][0] == end and d["nearest_nbrs"].shape == (d["slice"][1] - d["slice"][0], 32)
+            assert d["amp_ratio"].shape == d["harmonics_best_weight_para"].shape == (d["nearest_nbrs"].shape[0], 4)
+            end = d["slice"][1]
+        assert end == pool.shape[0]
+    assert prematch.main(["--librispeech_path", str(root), "--out_path", str(out), "--save_pool_only"]) == 0
+    assert (out / "singerA" / "pool_f0.npy").is_file() and np.load(out / "singerB" / "pool_spec.npy").shape[1] == 200
+    matching._POOL_CACHE = None
