@@ -91,10 +91,18 @@ class GemmTimer:
         return len(dom), ms, fl
 
 
+STRONG = False                         # --scaling strong: ONE 10-minute pool split over the ranks, one replicated source
+
+
 def make_inputs(rank, dev):
     n = SRC_SECONDS * C.SAMPLE_RATE
-    src, sf0 = S.synth_clip(n, seed=1000 + rank)
-    pool = [S.synth_clip(30 * C.SAMPLE_RATE, seed=2000 + 100 * rank + i) for i in range(POOL_CLIPS)]
+    if STRONG:                         # same source everywhere; rank r holds its contiguous share of the SAME 20 pool clips
+        src, sf0 = S.synth_clip(n, seed=1000)
+        lo, hi = kdist.contiguous_share(POOL_CLIPS)
+        pool = [S.synth_clip(30 * C.SAMPLE_RATE, seed=2000 + i) for i in range(lo, hi)]
+    else:
+        src, sf0 = S.synth_clip(n, seed=1000 + rank)
+        pool = [S.synth_clip(30 * C.SAMPLE_RATE, seed=2000 + 100 * rank + i) for i in range(POOL_CLIPS)]
     g = lambda a: torch.from_numpy(a).to(dev)
     return g(src), g(sf0 * 1.3), [g(w) for w, _ in pool], [g(f) for _, f in pool]      # audio AND f0 tracks resident in HBM
 
@@ -145,6 +153,19 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
     main.wait_stream(side)
     for t in (qf0, Pf0_loc, Ph_loc):
         t.record_stream(main)
+    if STRONG:
+        # fixed pool, row-sharded in file order (uneven: 20 clips do not divide by 8); the replicated source is searched
+        # once per shard and every rank needs the merged lists -> all-gather merge (dist.sharded_knn(replicated=True))
+        rank, ws = kdist.world()
+        base, rem = divmod(POOL_CLIPS, ws)
+        counts = [1500 * (base + (1 if r < rem else 0)) for r in range(ws)]
+        with stage("knn"):
+            nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K, replicated=True, counts=counts)
+        with stage("gather"):
+            P = kdist.all_gather_rows_var(P_loc, counts)
+            Pf0 = kdist.all_gather_rows_var(Pf0_loc, counts)
+            Ph = kdist.all_gather_rows_var(Ph_loc, counts)
+        return dict(qf=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, nn32=nn32)
     # the pool all-gather (123 MB per rank) starts now and travels under the local kNN search; waited for below
     P, wait_P = kdist.all_gather_rows_async(P_loc)
     with stage("knn"):
@@ -254,6 +275,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print per-stage ms to stderr")
     ap.add_argument("--timed-only", action="store_true", help="tracing aid: stop after the timed region (no latency / roofline passes, no JSON line)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): one 30 s source + one 10-min pool shard PER RANK (pool and kNN work grow with N); "
+                         "strong: ONE 30 s source against ONE 10-min pool whose 20 clips are split over the ranks "
+                         "(north_star's pool-shard scaling of a fixed pool; match + vocoder run replicated)")
     ap.add_argument("--pipeline-depth", type=int, default=2, choices=(1, 2),
                     help="2 = overlap match+vocoder of conversion i with the encoder of conversion i+1 (default); 1 = sequential")
     a = ap.parse_args()
@@ -269,6 +294,10 @@ def main():
     if ws > 1 or launched:
         dist.init_process_group("nccl", device_id=dev)
     assert a.gpus == ws, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    global STRONG
+    STRONG = a.scaling == "strong"
+    if STRONG and ws > POOL_CLIPS:
+        raise SystemExit(f"--scaling strong splits {POOL_CLIPS} pool clips: at most {POOL_CLIPS} ranks")
 
     enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(C.WAVLM_LARGE, 6), seed=1), C.WAVLM_LARGE, dev, 6)
     voc = Vocoder(S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, "mix"), seed=2), C.HIFIGAN_V1, "mix", dev)
@@ -336,7 +365,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
-        value = ws * SRC_SECONDS * a.steps / dt
+        value = (1 if STRONG else ws) * SRC_SECONDS * a.steps / dt      # strong: ONE conversion per step, all ranks on it
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak, mfmas, kernel_name = {
             "F128": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2_kernel<Gemm2Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 3 fp16 MFMAs)"),
@@ -346,12 +375,16 @@ def main():
         line = {
             "metric": "audio-sec converted/sec (xRT) end-to-end, cold target pool",
             "value": round(value, 3), "unit": "x real-time", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "north-star point per rank: 30 s source vs 10 min target pool (20 x 30 s), "
+            "config": {"workload": ("north-star point, ONE conversion per step: 30 s source vs ONE 10 min target pool (20 x 30 s) "
+                                    f"split over the {ws} rank(s), " if STRONG else
+                                    "north-star point per rank: 30 s source vs 10 min target pool (20 x 30 s), ") +
                                    "ckpt_type=mix, post_opt_0.2, cold (pool encoded inside the step); seeded random "
                                    "weights of WavLM-Large (6 layers executed) and the 22.9 M-param generator",
-                       "nq": 1500, "np_per_rank": 30000, "pool_sharding": f"rows over {ws} rank(s), RCCL all-gather merge",
+                       "nq": 1500, "np_per_rank": (30000 // ws if STRONG else 30000),
+                       "pool_sharding": (f"one pool, rows over {ws} rank(s) in file order, replicated queries, RCCL all-gather merge"
+                                         if STRONG else f"rows over {ws} rank(s), RCCL all-to-all merge"),
                        "wavlm_batch_chunks": a.max_batch,
                        "pipeline_depth": a.pipeline_depth,
                        "pipeline": ("match + vocoder of conversion i run on a second stream under the encoder of conversion i+1"
@@ -376,12 +409,12 @@ def main():
         if STAGES.get("knn"):
             kms = [x.elapsed_time(y_) for x, y_ in STAGES["knn"]]
             kms = sum(kms) / len(kms)
-            nq_all, np_shard, D = ws * 1500, 30000, 1024
+            nq_all, np_shard, D = (1500, 1500 * -(-POOL_CLIPS // ws), 1024) if STRONG else (ws * 1500, 30000, 1024)
             flop = 2.0 * nq_all * np_shard * D                     # per rank
             tfl = flop / (kms * 1e-3) / 1e12
             min_bytes = 4.0 * D * (nq_all + np_shard) + 8 * 32 * nq_all
             line["knn"] = {"query_frames_per_s": round(nq_all / (kms * 1e-3), 0), "ms": round(kms, 4),
-                           "nq_per_rank": 1500, "nq_searched_per_rank": nq_all, "np_shard": np_shard, "np_total": ws * np_shard, "k": 32,
+                           "nq_per_rank": 1500, "nq_searched_per_rank": nq_all, "np_shard": np_shard, "np_total": (30000 if STRONG else ws * np_shard), "k": 32,
                            "tflops_fp32_equiv_per_gpu": round(tfl, 1),
                            "bound": "mfma", "frac_f16x2_ceiling_833": round(tfl / F16X2_PEAK_TFLOPS, 4),
                            "frac_fp32_mfma_peak_157.3": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -114,10 +114,26 @@ def write_wav_pcm16(path: str, wave: np.ndarray, sr: int) -> None:
         f.write(hdr + raw)
 
 
-def save_audio(filename: str, waveform, sample_rate: int) -> None:
-    """lib_ongaku_test.py:89-143 for the formats this build can encode: PCM_32 .wav."""
+def save_audio(filename: str, waveform, sample_rate: int) -> str:
+    """lib_ongaku_test.py:89-143: PCM_32 .wav natively; .flac through soundfile when it is importable.  The reference
+    encodes .mp3 / .flac through pydub + ffmpeg; without an encoder for the requested container (dataset mode names
+    its outputs after the source file's extension, ddsp_matcher.py:1133) the audio is written as PCM_32 .wav next to
+    the requested name, with a warning, instead of losing a finished conversion.  Returns the path written."""
     wave = np.asarray(waveform)
     if filename.endswith(".wav"):
         write_wav_pcm32(filename, wave, sample_rate)
-        return
-    raise RuntimeError(f"{filename}: only .wav output is supported without pydub/ffmpeg (reference: mp3/flac via pydub)")
+        return filename
+    if filename.endswith(".flac"):
+        try:
+            import soundfile as sf
+            pcm = to_pcm32(wave)
+            sf.write(filename, pcm.T if pcm.ndim == 2 else pcm, sample_rate, subtype="PCM_24")
+            return filename
+        except ImportError:
+            pass
+    alt = os.path.splitext(filename)[0] + ".wav"
+    import warnings
+    warnings.warn(f"{filename}: no encoder for this container in this environment (the reference uses pydub/ffmpeg); "
+                  f"writing PCM_32 WAV to {alt} instead")
+    write_wav_pcm32(alt, wave, sample_rate)
+    return alt

@@ -6,14 +6,15 @@ backend "nccl" == RCCL over xGMI) owns a contiguous range of pool rows:
   1. queries of all ranks are all-gathered (Nq x 4 KB each — small);
   2. each rank runs the fused distance/top-k kernel against ITS shard only and reports
      (distance, global row) lists — no pool bytes cross the fabric for the search;
-  3. one all-gather of the [Nq_total, 32] lists (8 B per entry), then an 8-way merge with the
-     same (distance, lower index) ordering as the single-GPU kernel, so results do not depend
-     on the number of devices;
+  3. one all-to-all of the [Nq_total, 32] lists (8 B per entry: every rank receives only the lists
+     of ITS queries, one block per shard), then an 8-way merge with the same (distance, lower
+     index) ordering as the single-GPU kernel, so results do not depend on the number of devices
+     (replicated queries whose result every rank needs use an all-gather instead);
   4. the rows the later stages read (selected neighbours and their +/-1 neighbours) are served
      from an all-gathered copy of the pool features / f0 / harmonics (<= ~200 MB per speaker).
 
-xGMI is point to point (7 links per GPU), so the collectives are plain all-gathers whose
-per-peer messages travel on their own link; there is no ring or tree to tune.
+xGMI is point to point (7 links per GPU), so the collectives are plain all-gathers / all-to-alls
+whose per-peer messages travel on their own link; there is no ring or tree to tune.
 The local top-k and the merge are injectable so that the sharding logic is testable on CPU
 with gloo (tests/test_dist_cpu.py) — the product path always uses the HIP kernels.
 """
@@ -106,17 +107,58 @@ def _hip_merge(part_dist, part_idx):
     return ops.knn_merge(part_dist, part_idx)
 
 
-def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, local_topk=_hip_local_topk,
-                merge=_hip_merge, replicated: bool = False, counts=None):
+def all_to_all_rows(t: torch.Tensor, send_rows, recv_rows) -> torch.Tensor:
+    """Rows of ``t`` [sum(send_rows), ...] are dealt out in rank order (send_rows[r] rows go to rank r); returns the
+    rows received, [sum(recv_rows), ...], grouped by sender in rank order.  One ``all_to_all_single`` (RCCL: every
+    peer pair uses its own xGMI link), so a rank receives only what it asked for."""
+    out = torch.empty((int(sum(recv_rows)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_to_all_single(out, t.contiguous(), output_split_sizes=[int(r) for r in recv_rows],
+                           input_split_sizes=[int(r) for r in send_rows])
+    return out
+
+
+def sharded_knn_owned(q_all: torch.Tensor, owner_rows, pool_local: torch.Tensor, k: int = 32, local_topk=None, merge=None,
+                      counts=None):
+    """Replicated queries with OWNERS: ``q_all`` [sum(owner_rows), D] is the same on every rank and ordered rank-major
+    (the first owner_rows[0] rows belong to rank 0, ...).  Every rank searches all of them in its own pool shard; the
+    [., k] (distance, global row) lists are then exchanged with ONE all-to-all so that each rank receives, from every
+    shard, only the lists of the rows it owns (ws x fewer bytes than all-gathering every list to every rank: BASELINE
+    cfg 5 moves 98 MB instead of 786 MB per rank), and merges them.  Returns (idx, dist) for this rank's own rows."""
+    local_topk = local_topk or _hip_local_topk
+    merge = merge or _hip_merge
+    rank, ws = world()
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_topk(q_all, pool_local, k, 0)
+    owner_rows = [int(r) for r in owner_rows]
+    assert len(owner_rows) == ws and sum(owner_rows) == q_all.shape[0], (owner_rows, q_all.shape)
+    counts = list(counts) if counts is not None else shard_rows(pool_local.shape[0], q_all.device)
+    assert len(counts) == ws and counts[rank] == pool_local.shape[0], (counts, rank, pool_local.shape)
+    idx, dst = local_topk(q_all, pool_local, k, sum(counts[:rank]))            # every row vs my shard, global ids
+    mine = owner_rows[rank]
+    recv = [mine] * ws                                                         # my rows' lists, one block per shard
+    d_parts = all_to_all_rows(dst, owner_rows, recv).view(ws, mine, k)
+    i_parts = all_to_all_rows(idx, owner_rows, recv).view(ws, mine, k)
+    if mine == 0:
+        return idx[:0], dst[:0]
+    return merge(d_parts.contiguous(), i_parts.contiguous())
+
+
+def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, local_topk=None,
+                merge=None, replicated: bool = False, counts=None):
     """Top-k of every rank's queries against the union of all ranks' pool shards.
 
     q_local [nq, D] (same nq on every rank), pool_local [np_r, D]: shards may differ in size (each must hold >= k
     rows); the global row of local row j on rank r is sum(np_0 .. np_{r-1}) + j, i.e. the row order of
-    all_gather_rows_var(pool_local).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's queries.
-    ``replicated``: every rank holds the SAME queries (one conversion against a sharded pool, BASELINE cfg 4): they
-    are not gathered, each rank searches them once in its shard and every rank ends up with the same merged lists.
+    all_gather_rows_var(pool_local).  Returns (idx [nq, k] global rows, dist [nq, k]) for THIS rank's queries: the
+    queries are all-gathered (KBs), searched in every shard, and the lists come back through one all-to-all
+    (``sharded_knn_owned``) — each rank receives only its own queries' lists.
+    ``replicated``: every rank holds the SAME queries and every rank needs the merged result (one conversion against a
+    sharded pool, BASELINE cfg 4 single file): they are not gathered, each rank searches them once in its shard, the
+    lists are all-gathered and every rank ends up with the same merged lists.
     ``counts``: the shard sizes if the caller already knows them (shard_rows() reads them back to the host — a
     synchronisation a stream pipeline must not have inside its steps)."""
+    local_topk = local_topk or _hip_local_topk
+    merge = merge or _hip_merge
     rank, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
         return local_topk(q_local, pool_local, k, 0)
@@ -126,12 +168,8 @@ def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, lo
     if replicated:
         idx, dst = local_topk(q_local, pool_local, k, sum(counts[:rank]))
         return merge(all_gather_rows(dst[None]).contiguous(), all_gather_rows(idx[None]).contiguous())
-    q_all = all_gather_rows(q_local)                                           # [ws*nq, D]
-    idx, dst = local_topk(q_all, pool_local, k, sum(counts[:rank]))            # vs my shard, global ids
-    dist_all = all_gather_rows(dst[None])                                      # [ws, ws*nq, k]
-    idx_all = all_gather_rows(idx[None])
-    mine = slice(rank * nq, (rank + 1) * nq)
-    return merge(dist_all[:, mine].contiguous(), idx_all[:, mine].contiguous())
+    q_all = all_gather_rows(q_local)                                           # [ws*nq, D], rank-major
+    return sharded_knn_owned(q_all, [nq] * ws, pool_local, k, local_topk, merge, counts)
 
 
 def contiguous_share(n: int):

@@ -109,13 +109,21 @@ class KNeighborsVC:
         written = []
         pairs = [(s, t) for i, s in enumerate(src_spk) for j, t in enumerate(tgt_spk)
                  if not (src_dataset_path == tgt_dataset_path and i == j)]
-        # one process per GPU: speaker pairs are independent (clip-DP) and are dealt round-robin over the
-        # ranks; a single process (no process group) gets them all, in the reference's order
-        for s, t in kdist.my_share(pairs):
+        # One process per GPU, two ways to share a dataset run, never both at once:
+        #   * default: speaker pairs are independent (clip-DP) and are dealt round-robin over the ranks, every rank
+        #     handles ITS pairs alone (pool_sharded=False: no collective may run, the other ranks are on other pairs);
+        #   * KNNSVC_POOL_SHARD=1 (BASELINE cfg 4, pools too large / too slow for one GPU): EVERY rank walks EVERY pair
+        #     in the same order, each pair's target pool and source files are encoded in shares over the ranks, the kNN
+        #     is searched per shard, and the utterances of the pair are dealt over the ranks for matching + vocoding.
+        rank, ws = kdist.world()
+        shard = os.environ.get("KNNSVC_POOL_SHARD") == "1" and ws > 1
+        my_pairs = pairs if shard else kdist.my_share(pairs)
+        for s, t in my_pairs:
             print(f"{s} -> {t}")
             common = dict(topk=topk, device=self.device, prioritize_f0=prioritize_f0, ckpt_type=ckpt_type,
                           src_dataset_path=src_dataset_path, tgt_dataset_path=tgt_dataset_path,
-                          required_subset=required, duration_limit=duration_limit)
+                          required_subset=required, duration_limit=duration_limit,
+                          pool_sharded=shard, share_items=shard)
             # the generator of every utterance is the tail stage of the match pipeline (same kernels and inputs as
             # `vocode` after the fact, ddsp_matcher.py:1114-1128, but enqueued under the next utterances' matching);
             # one finiteness check per speaker pair instead of one host sync per utterance
@@ -133,7 +141,7 @@ class KNeighborsVC:
                                    os.path.basename(t) + "." + os.path.basename(k).split(".")[-1])
                 Path(out).parent.mkdir(parents=True, exist_ok=True)
                 assert pred.dim() == 1
-                audio_io.save_audio(out, pred[None, :].cpu().numpy(), sample_rate=self.sr)
+                out = audio_io.save_audio(out, pred[None, :].cpu().numpy(), sample_rate=self.sr)
                 written.append(out)
             print(f"{os.path.basename(s)}, {os.path.basename(t)} -> {converted_audio_dir}")
         return kdist.gather_paths(written)

@@ -88,14 +88,16 @@ def side_features(wav_gpu: torch.Tensor, f0_host: np.ndarray, T: int):
 
 
 def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_weights=None, device="cuda",
-                          duration_limit=None, vad_trigger_level=0, shard_files=False):
+                          duration_limit=None, vad_trigger_level=0, shard_files=False, gather=False):
     """Per-file dicts (matching_pool, synth_pool, audio_synth_pool, spec_synth_pool, f0_pool, harmonics_pool),
     like the reference.  matching == synth features (both weightings are the same one-hot on the live path);
     ``audio_synth_pool`` is kept as None values: the live path never reads it (audio_out_feats_weighted = None,
     ddsp_prematch_dataset.py:1368).  Per-file results are kept in the device-resident pool store
     (knn_svc_amd/pool_cache.py) so that dataset mode encodes every file once instead of once per speaker pair.
     ``shard_files`` (one process per GPU): every rank walks the same file list and duration limit, but encodes and
-    returns only its contiguous share of the kept files (dist.contiguous_share) — the pool shard of BASELINE cfg 4."""
+    returns only its contiguous share of the kept files (dist.contiguous_share) — the pool shard of BASELINE cfg 4.
+    ``gather`` (with shard_files): the shares are all-gathered afterwards (features and f0 only — what a QUERY pool
+    needs), so every rank returns the complete per-file dicts although it encoded only its share."""
     dev = wavlm.device
     files = list_audio(path)
     cache = _pool_cache()
@@ -103,7 +105,8 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     dtag = (wavlm.weights_fingerprint(), wavlm.n_layers) if cache.disk_dir else None     # on-disk tier: content identity
     dkeys = {}
     kept, keys, Ts = [], [], []
-    loaded = {}                       # index -> (wav on device, f0 host) for files that miss the cache
+    loaded = {}                       # index -> (wav host, f0 host) for files that miss the cache
+    hits = {}                         # index -> cache entry: held here, a later put() may evict it from the store
     dur = 0.0
     for i, pth in enumerate(files):
         key = pool_cache.file_key(pth, tag)
@@ -112,8 +115,12 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
         ent = cache.get(key, dkeys.get(key), dev)
         if ent is not None:
             T = ent["feats"].shape[0]
+            hits[i] = ent
         else:
             w, f0 = load_utterance(pth)
+            key = pool_cache.file_key(pth, tag)                   # load_utterance may have just written <stem>_f0.npy,
+            if dtag is not None:                                  # which is part of the file's identity
+                dkeys[key] = pool_cache.file_key(pth, dtag)
             T = frames_of(len(w), wavlm)
             loaded[i] = (w, f0)                                   # host arrays: only this rank's share goes to the device
         kept.append(str(pth)); keys.append(key); Ts.append(T)
@@ -127,13 +134,29 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     for i, ft in zip(miss, feats):
         assert ft.shape[0] == Ts[i]
         f0, harm, spec = side_features(loaded[i][0], loaded[i][1], Ts[i])
-        cache.put(keys[i], dict(feats=ft, f0=f0, harm=harm, spec=spec), dkeys.get(keys[i]))
-        loaded[i] = dict(feats=ft, f0=f0, harm=harm, spec=spec)
+        hits[i] = dict(feats=ft, f0=f0, harm=harm, spec=spec)
+        cache.put(keys[i], hits[i], dkeys.get(keys[i]))
     matching, synth, audio, specs, f0p, harmp = {}, {}, {}, {}, {}, {}
+    if shard_files and gather and kdist.world()[1] > 1:
+        # query pool: every rank needs every file's features and f0 (replicated kNN queries); rank order = file order
+        mine = [hits[i] for i in range(lo, hi)]
+        E = wavlm.E
+        cat = lambda k, shape: (torch.cat([e[k] for e in mine], 0).contiguous() if mine
+                                else torch.empty(shape, device=dev, dtype=torch.float32))
+        counts = kdist.shard_rows(sum(Ts[lo:hi]), dev)
+        all_f = kdist.all_gather_rows_var(cat("feats", (0, E)), counts)
+        all_f0 = kdist.all_gather_rows_var(cat("f0", (0,)), counts)
+        r0 = 0
+        for key, T in zip(kept, Ts):
+            matching[key] = synth[key] = all_f[r0:r0 + T]
+            f0p[key] = all_f0[r0:r0 + T]
+            audio[key] = specs[key] = harmp[key] = None
+            r0 += T
+        return matching, synth, audio, specs, f0p, harmp
     for i, key in enumerate(kept):
         if not lo <= i < hi:
             continue
-        ent = loaded[i] if i in loaded else cache.get(keys[i])
+        ent = hits[i]
         matching[key] = ent["feats"]; synth[key] = ent["feats"]; audio[key] = None
         specs[key] = ent["spec"]; f0p[key] = ent["f0"]; harmp[key] = ent["harm"]
     return matching, synth, audio, specs, f0p, harmp
@@ -162,11 +185,12 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
-def prepare_pool(matching_list):
+def prepare_pool(matching_list, split=True):
     """Per-pool quantities that do not depend on the query (row norms, the split image the kNN GEMM reads): computed
-    once per target pool in dataset mode instead of once per utterance."""
+    once per target pool in dataset mode instead of once per utterance.  ``split=False``: norms only (the neighbours
+    come from the pool-sharded search)."""
     P = matching_list
-    return dict(stats=ops.row_norms(P), split=ops.prepare_knn_pool(P, C.KNN_K))
+    return dict(stats=ops.row_norms(P), split=ops.prepare_knn_pool(P, C.KNN_K) if split else None)
 
 
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
@@ -241,7 +265,7 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
                             topk: int = 4, device="cuda", prioritize_f0=False, ckpt_type="wavlm_only",
                             src_dataset_path=None, tgt_dataset_path=None, cache_dir=None, required_subset=None,
                             post_opt="no_post_opt", duration_limit=None, vocode_fn=None, waves_out=None,
-                            pool_sharded=None):
+                            pool_sharded=None, share_items=False):
     """Same contract as the reference function (ddsp_prematch_dataset.py:1074).  ``topk`` is accepted and
     ignored (k = 32 -> 4 is hard-coded upstream, :1203,1246,1398); ``cache_dir`` is ignored (the reference
     force-disables it, :1086-1087).
@@ -252,14 +276,20 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     of after all of them.  It must not synchronise with the host.
 
     ``pool_sharded`` (default: environment KNNSVC_POOL_SHARD=1; needs a process group, one process per GPU; BASELINE
-    cfg 4): the target pool's files are encoded in contiguous shares over the ranks, every rank searches the (replicated)
-    query frames in its own shard, the per-shard top-32 lists are merged after one RCCL all-gather, and the pool's
-    features / f0 / harmonics are all-gathered once (rank order = file order, so rows mean what they mean on one GPU).
-    Every rank then holds the same neighbours and runs the same later stages."""
+    cfg 4): EVERY rank must make this call with the same arguments.  The target pool's files are encoded in contiguous
+    shares over the ranks, every rank searches the (replicated) query frames in its own shard and the pool's features /
+    f0 / harmonics are all-gathered once (rank order = file order, so rows mean what they mean on one GPU).
+      * ``share_items=False`` (single file): the per-shard top-32 lists are all-gathered and merged on every rank; every
+        rank then holds the same neighbours, runs the same later stages and returns the same dicts.
+      * ``share_items=True`` (dataset mode, ``bulk_match``): the source speaker's files are encoded in contiguous shares
+        too (features all-gathered), the query items are dealt round-robin over the ranks, ONE all-to-all hands each
+        rank the per-shard lists of its own items only, and each rank runs the match bodies (and ``vocode_fn``) of its
+        own items: the returned dicts hold this rank's items."""
     import torch.distributed as tdist
     if pool_sharded is None:         # by environment: only when there is more than one rank to shard over
         pool_sharded = os.environ.get("KNNSVC_POOL_SHARD") == "1" and kdist.world()[1] > 1
     pool_sharded = bool(pool_sharded) and tdist.is_available() and tdist.is_initialized()   # explicit True: any group, even 1 rank
+    share_items = bool(share_items) and pool_sharded
     assert prioritize_f0, "prioritize_f0=False is unsupported by the reference (ddsp_prematch_dataset.py:1375)"
     if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type and "mix" not in ckpt_type:
         raise NotImplementedError(ckpt_type)
@@ -268,7 +298,8 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
             raise NotImplementedError("layer weighting does not match the encoder's exit layer")
     if src_dataset_path is None:
         assert os.path.isfile(src_wav_file)
-    query_pool, _, _, _, query_f0_pool, _ = get_complete_spk_pool(src_wav_file, wavlm, device=device)
+    query_pool, _, _, _, query_f0_pool, _ = get_complete_spk_pool(src_wav_file, wavlm, device=device,
+                                                                  shard_files=share_items, gather=share_items)
     if tgt_dataset_path is None:
         assert os.path.isfile(ref_wav_file)
     matching_pool, _synth, _audio, _spec, f0_pool, harm_pool = get_complete_spk_pool(
@@ -292,22 +323,41 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     items = [item for item in query_pool
              if required_subset is None or
              os.path.basename(item).split(".")[0] + "/" + os.path.basename(ref_wav_file) in required_subset]
-    # the per-item bodies are independent chains of mostly single-workgroup kernels: three at a time, each on
-    # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
-    flags = []
-    prep = prepare_pool(matching_list) if len(items) > 1 else None
     nn = {}
-    if shard is not None:            # collectives first, in item order on every rank; the match bodies then need none
+    if shard is not None and share_items:
+        # one search of ALL items' frames in every shard, one all-to-all: each rank gets the lists of its own items
+        rank, ws = kdist.world()
+        owned = [[it for j, it in enumerate(items) if j % ws == r] for r in range(ws)]      # == dist.my_share, per rank
+        order = [it for part in owned for it in part]
+        if order:
+            q_all = torch.cat([query_pool[it] for it in order], 0).contiguous()
+            rows = [sum(query_pool[it].shape[0] for it in part) for part in owned]
+            mine_idx = kdist.sharded_knn_owned(q_all, rows, shard, C.KNN_K, counts=counts)[0]
+            r0 = 0
+            for it in owned[rank]:
+                n = query_pool[it].shape[0]
+                nn[it] = mine_idx[r0:r0 + n].contiguous()
+                r0 += n
+        kdist.raise_if_any_nan()
+        items = owned[rank]
+    elif shard is not None:          # collectives first, in item order on every rank; the match bodies then need none
         for item in items:
             nn[item] = kdist.sharded_knn(query_pool[item].contiguous(), shard, C.KNN_K, replicated=True, counts=counts)[0]
         kdist.raise_if_any_nan()
+    # the per-item bodies are independent chains of mostly single-workgroup kernels: three at a time, each on
+    # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
+    flags = []
+    prep = prepare_pool(matching_list, split=shard is None) if len(items) > 1 else None
     body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
                                        harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
-    lanes = min(3, len(items))
+    lanes = min(3, len(items)) if matching_list.is_cuda else 1        # (CPU tensors: injected kernels in the gloo tests)
     if vocode_fn is not None and len(items) > 0:
         assert waves_out is not None
         tail = lambda item, r: r + (vocode_fn(r[0], r[2], r[1]),)
-        results = pipeline.LanePipeline(matching_list.device, max(1, lanes)).run(items, body, tail)
+        if matching_list.is_cuda:
+            results = pipeline.LanePipeline(matching_list.device, max(1, lanes)).run(items, body, tail)
+        else:
+            results = [tail(i, body(i)) for i in items]
         for item, r in zip(items, results):
             waves_out[item] = r[3]
         results = [r[:3] for r in results]
