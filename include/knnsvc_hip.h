@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 7
+#define KNNSVC_ABI_VERSION 8
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -73,9 +73,21 @@ typedef struct knnsvc_conv_desc {
     const void* w_f16x2;               /* optional: w pre-split by knnsvc_split_weight_f16x2; wins over w_bf16x3 */
     float w_f16x2_scale;               /* the power-of-two scale w_f16x2 was split with                         */
     float a_f16x2_scale;               /* power-of-two activation pre-scale of the f16x2 path; 0 = default 16    */
-    int32_t x_f16x2;                   /* 1: x already is in the f16x2 split layout (see below), scale 16           */
+    int32_t x_f16x2;                   /* 1: x already is in the f16x2 split layout (see below), split with            */
+                                       /*    a_f16x2_scale (0 = 16) or with the scale x_absmax implies               */
     int32_t out_f16x2;                 /* 1: write out in the f16x2 split layout (scale 16) for the next GEMM;      */
                                        /* c >= 32 (multiple of 32): only columns >= c are split (QKV: K,V blocks)   */
+    /* Range of the f16x2 path without host round trips (all optional, NULL / 0 = off; ignored by the fp32 / bf16x3 paths):
+     *   x_absmax / w_absmax: DEVICE floats holding an upper bound of |x| over the A operand / of |w| over the split
+     *     weights; the kernel then derives the operand's power-of-two scale itself — the largest s with bound * s < 2^15
+     *     (knnsvc_split_f16x2_dyn splits with the same rule, so a pre-split operand and its consumer agree by sharing a
+     *     slot) — instead of a_f16x2_scale / w_f16x2_scale.  No activation range can overflow fp16 this way, and tiny
+     *     tensors are lifted into the range instead of losing bits.
+     *   out_absmax: DEVICE float; the epilogue folds max|out| over everything this launch stores into it with atomicMax
+     *     (on the bit pattern: a NaN output makes the slot NaN).  The caller zeroes it; it is the next launch's x_absmax.
+     *   out_f16x2_scale: scale of the split layout written under out_f16x2 (0 = 16); the consumer passes the same value
+     *     as its a_f16x2_scale. */
+    const float* x_absmax; const float* w_absmax; float* out_absmax; float out_f16x2_scale;
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
@@ -94,6 +106,15 @@ int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* ou
  * (default scale 16: |x| < 4094) or the output turns NaN (never silently wrong); activations whose rms is
  * below ~0.2 / a_f16x2_scale lose relative accuracy (absolute floor 3e-8 / a_f16x2_scale per element). */
 int knnsvc_split_weight_f16x2(const float* w, int64_t rows, int32_t K, float scale, void* out, void* stream);
+
+/* The same split with the scale taken from a device slot: scale = the largest power of two with *absmax * scale < 2^15
+ * (what knnsvc_conv_gemm derives from x_absmax / w_absmax).  For operands whose range is only known on the device — the
+ * kNN's query and pool features (lib_ongaku_test.py:148-175 takes whatever WavLM produced). */
+int knnsvc_split_f16x2_dyn(const float* w, int64_t rows, int32_t K, const float* absmax, void* out, void* stream);
+
+/* slot = max(slot, max |x[r, c]|) over a [rows, cols] matrix with row pitch ld (atomicMax on the bit pattern, NaN wins);
+ * the caller zeroes the slot.  Feeds x_absmax / w_absmax for tensors that no GEMM epilogue produced. */
+int knnsvc_absmax(const float* x, int64_t rows, int32_t cols, int32_t ld, float* slot, void* stream);
 
 /* Activations in the f16x2 split layout ("A2"): a [rows, C] matrix (C % 32 == 0, row pitch ld floats, ld % 32 == 0)
  * occupies the same bytes as fp32, but every group of 32 channels is stored as 32 fp16 `hi` values followed by
@@ -131,7 +152,10 @@ int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head
  * (bucket LUT already applied), gate [batches*T, heads], out [batches*T, E].  head_dim must be 64.
  * Nothing of size T x T is ever written to HBM. */
 /* kv_f16x2: the K and V column blocks of `qkv` (columns E..3E) already hold the f16x2 split layout, written by the QKV
- * projection with knnsvc_conv_desc.out_f16x2 = E (split from column E on); Q stays fp32.  f16x2 kernel only. */
+ * projection with knnsvc_conv_desc.out_f16x2 = E (split from column E on); Q stays fp32.  f16x2 kernel only.
+ * out_f16x2 is a flag word: bit 0 = write the output in the split layout; bit 2 (value 4) = wide range: Q, K or V may
+ * exceed what the f16x2 kernel's fixed operand scales hold (|k|, |v| < 4094, |q| < ~20000 — the caller decides this
+ * once, from bounds implied by the weights), so the bf16x3 kernel (fp32 exponent range) runs instead; fp32 in and out. */
 int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
                            int32_t T, int32_t heads, float* out, int32_t out_f16x2, int32_t kv_f16x2, void* stream);
 
@@ -195,7 +219,9 @@ int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, const float* q
 /* compute_wavlm_weight / compute_extended_weight (ddsp_prematch_dataset.py:574-680, 807-924):
  * Adam(amsgrad) on softmax weights with the reference's stopping rules, run entirely on the
  * device (no per-iteration host sync).  scale = 0.1 (WavLM) or 1000 (harmonics).
- * out_w [nq,4]; out_iters[0] = iterations executed.  workspace from knnsvc_smooth_workspace_bytes. */
+ * out_w [nq,4]; out_iters[0] = iterations executed.  workspace from knnsvc_smooth_workspace_bytes.
+ * max_iter > 0: the reference's cap (100 000 there).  max_iter < 0 (measurement aid): exactly -max_iter iterations
+ * with the stopping rules switched off (bench.py's sensitivity figure for data on which the loops run long). */
 /* row_scale (may be NULL) [nq,4]: compute_weight_with_amp (ddsp_prematch_dataset.py:684-804) — candidate k of
  * frame t and its two neighbours are multiplied by row_scale[t,k] (the amp_ratio of per_spk_extract) before the
  * loss is formed; with scale = 1000 this is the prematch weight optimisation. */

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libknnsvc_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("w_bf16x3", vp),
         ("w_f16x2", vp), ("w_f16x2_scale", f32), ("a_f16x2_scale", f32),
         ("x_f16x2", i32), ("out_f16x2", i32),
+        ("x_absmax", vp), ("w_absmax", vp), ("out_absmax", vp), ("out_f16x2_scale", f32),
     ]
 
 
@@ -44,6 +45,8 @@ SIGNATURES = {
     "knnsvc_conv_gemm": (i32, [C.POINTER(ConvDesc), vp]),
     "knnsvc_split_weight_bf16x3": (i32, [vp, i64, i32, vp, vp]),
     "knnsvc_split_weight_f16x2": (i32, [vp, i64, i32, f32, vp, vp]),
+    "knnsvc_split_f16x2_dyn": (i32, [vp, i64, i32, vp, vp, vp]),
+    "knnsvc_absmax": (i32, [vp, i64, i32, i32, vp, vp]),
     "knnsvc_layernorm": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp]),
     "knnsvc_wavlm_conv0": (i32, [vp, i32, i64, vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]),

@@ -600,11 +600,14 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
     KN_REQUIRE(qkv && gate && table && out, "wavlm_attention: null pointer");
     KN_REQUIRE(batches > 0 && T > 0 && heads > 0 && heads <= 65535 && batches <= 65535, "wavlm_attention: bad sizes");
     KN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "wavlm_attention: 16-byte alignment");
-    static int mode = -1;          // KNNSVC_ATTENTION = f16x2 (default) | bf16x3 | fp32 (exact-f32 MFMA kernel)
-    if (mode < 0) {
+    static int env_mode = -1;      // KNNSVC_ATTENTION = f16x2 (default) | bf16x3 | fp32 (exact-f32 MFMA kernel)
+    if (env_mode < 0) {
         const char* e = getenv("KNNSVC_ATTENTION");
-        mode = !e ? 2 : (e[0] == 'b') ? 3 : (e[0] == 'f' && e[1] == 'p') ? 0 : 2;
+        env_mode = !e ? 2 : (e[0] == 'b') ? 3 : (e[0] == 'f' && e[1] == 'p') ? 0 : 2;
     }
+    // bit 2 of the flags: the caller's range analysis says Q / K / V may leave the f16x2 kernel's fixed-scale range
+    const int mode = (out_f16x2 & 4) && env_mode == 2 ? 3 : env_mode;
+    out_f16x2 &= 1;
     if (mode == 2) {
         const size_t l2 = (size_t)KT * KP2 + (size_t)KT * VP2 + (size_t)(2 * T - 1 + 64) * 4;
         KN_REQUIRE(l2 <= 160 * 1024, "wavlm_attention: T too long for the LDS bias table (T <= ~16000)");

@@ -28,7 +28,41 @@ struct ConvArgs {
     float out_scale;            // accumulator -> output factor (1 except on the f16x2 path)
     float a_scale;              // f16x2 path: power-of-two factor applied to activations before the split
     int lin;                    // plain output below 2 GiB: the buffer-addressed epilogue applies (conv_epilogue_lin)
+    // dynamic range of the f16x2 path (include/knnsvc_hip.h, "Range"): device slots holding an upper bound of |x| / |w|;
+    // when set, the kernel derives the power-of-two operand scale from the slot (kn_pick_scale) instead of a_scale / w_scale
+    const float* x_absmax; const float* w_absmax;
+    float* out_absmax;          // optional: atomicMax of |out| over everything this launch stores (a later launch's x_absmax)
+    float w_scale;              // f16x2 path: the scale the weights were split with
+    float split_scale;          // scale of the split layout written by the epilogue (out_split)
 };
+
+// largest power of two s with absmax * s < 2^15 (fp16 tops out at 65504): absmax in [2^E, 2^(E+1)) -> s = 2^(14-E).
+// 0 / tiny bounds cap the scale at 2^54; inf / NaN give a tiny scale and stay inf / NaN in the product (loud, not wrong).
+__device__ __host__ __forceinline__ float kn_pick_scale(float absmax) {
+    unsigned u;
+    __builtin_memcpy(&u, &absmax, 4);
+    unsigned e = (u >> 23) & 0xFFu;
+    e = e < 87u ? 87u : e;
+    u = (268u - e) << 23;
+    float s;
+    __builtin_memcpy(&s, &u, 4);
+    return s;
+}
+
+// the kernel parameter struct is a by-value copy: patch the scales in place before anything reads them (uniform loads)
+__device__ __forceinline__ void resolve_scales(ConvArgs& a) {
+    if (a.x_absmax) a.a_scale = kn_pick_scale(*a.x_absmax);
+    if (a.w_absmax) a.w_scale = kn_pick_scale(*a.w_absmax);
+    if (a.x_absmax || a.w_absmax) a.out_scale = 1.0f / (a.a_scale * a.w_scale);
+}
+
+// |v| as ordered bits: NaN sorts above inf, so a NaN anywhere in the output reaches the slot (fmaxf would drop it)
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ void publish_absmax(float* slot, unsigned m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax((unsigned*)slot, m);
+}
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 
@@ -228,6 +262,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
     float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
     const float* rz = a.resid ? a.resid + b * a.r_bstride + g * a.r_gstride : nullptr;
     const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
+    unsigned amax = 0;
 #pragma unroll
     for (int j = 0; j < G::TN; ++j) {
         const int n = n0 + G::acc_col(wave, lane, j);
@@ -270,7 +305,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
                     // f16x2 split layout for the next GEMM's A operand: element (row, c) -> hi at (c/32)*128 + (c%32)*2,
                     // lo 64 bytes further.  Lanes n and n^1 hold neighbouring columns of the same row: the even lane
                     // stores both hi halves, the odd lane both lo halves — one 4-byte store per lane, as in fp32 mode.
-                    const float xs = v * KN_F16X2_A_SCALE;
+                    const float xs = v * a.split_scale;
                     const _Float16 h = (_Float16)xs;
                     const _Float16 l = (_Float16)(xs - (float)h);
                     const unsigned hl = (unsigned)__builtin_bit_cast(unsigned short, h) |
@@ -286,6 +321,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
                 if (rz) v += rv[r];
                 if (a.accumulate) v += av[r];
                 if (a.div != 1.0f) v = v / a.div;
+                if (a.out_absmax) { const unsigned ab = abs_bits(v); amax = ab > amax ? ab : amax; }
 #ifdef KN_WHATIF_NOSTORE
                 if (v == 123456.789f) oz[orow * a.ldo + col] = v;      // timing-only build: keeps the value live, stores nothing
 #else
@@ -294,6 +330,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
             }
         }
     }
+    if (a.out_absmax) publish_absmax(a.out_absmax, amax);
 }
 
 // Lean epilogue for plain (non-transposed) outputs whose byte extent fits 31 bits: rows are addressed through buffer
@@ -311,6 +348,7 @@ __device__ __forceinline__ void conv_epilogue_lin(const ConvArgs& a, typename G:
     const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, ((a.m - 1) * a.ldo + a.n) * 4);
     const __amdgpu_buffer_rsrc_t r_rsrc = uniform_rsrc(rz ? (const void*)rz : (const void*)oz, rz ? ((a.m - 1) * a.ldr + a.n) * 4 : 0);
     constexpr int NR = G::NR;
+    unsigned amax = 0;
 #pragma unroll
     for (int j = 0; j < G::TN; ++j) {
         const int n = n0 + G::acc_col(wave, lane, j);
@@ -345,7 +383,7 @@ __device__ __forceinline__ void conv_epilogue_lin(const ConvArgs& a, typename G:
                 else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
                 const int off = bo + ((r & 3) + 8 * (r >> 2)) * ldo4;
                 if (sp) {       // see conv_epilogue: lanes n and n^1 exchange halves, one 4-byte store each
-                    const float xs = v * KN_F16X2_A_SCALE;
+                    const float xs = v * a.split_scale;
                     const _Float16 h = (_Float16)xs;
                     const _Float16 l = (_Float16)(xs - (float)h);
                     const unsigned hl = (unsigned)__builtin_bit_cast(unsigned short, h) |
@@ -358,10 +396,13 @@ __device__ __forceinline__ void conv_epilogue_lin(const ConvArgs& a, typename G:
                 if (rz) v += rv[r];
                 if (a.accumulate) v += av[r];
                 if (a.div != 1.0f) v = v / a.div;
+                // (rows past M hold act(bias) of an all-zero A row: they are not stored, but may enter the bound — harmless)
+                if (a.out_absmax) { const unsigned ab = abs_bits(v); amax = ab > amax ? ab : amax; }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, 0, 0);
             }
         }
     }
+    if (a.out_absmax) publish_absmax(a.out_absmax, amax);
 }
 
 template <class G>
@@ -425,6 +466,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm3_kernel(ConvArgs a) {
 template <class G, bool A2>
 __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     // XCD-aware tile order (see conv_gemm2big_kernel): ids congruent mod 8 share an L2; a group is 8 row tiles x all
@@ -463,6 +505,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
 template <class G, int MINB>
 __global__ __launch_bounds__(256, MINB) void conv_gemm2win_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
@@ -513,6 +556,7 @@ int launch2win(const ConvArgs& a, int batches, hipStream_t st) {
 template <class G>
 __global__ __launch_bounds__(256, 2) void conv_gemm2dma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
@@ -569,6 +613,7 @@ int launch2dma(const ConvArgs& a, int batches, hipStream_t st) {
 template <class G, int MINB>
 __global__ __launch_bounds__(256, MINB) void conv_gemm2ring_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
@@ -624,6 +669,7 @@ int launch2ring(const ConvArgs& a, int batches, hipStream_t st) {
 template <class G, bool A2>
 __global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2; the fp32 A panel of a
@@ -692,9 +738,11 @@ int launch2(const ConvArgs& a, int batches, hipStream_t st) {
 }
 
 // one thread per 4 consecutive k of one weight row: scale * fp32 -> (hi, lo) fp16 planes, round to nearest
-__global__ void split_weight2_kernel(const float* __restrict__ w, long n, int K, float scale, unsigned short* __restrict__ out) {
+__global__ void split_weight2_kernel(const float* __restrict__ w, long n, int K, float scale, const float* __restrict__ absmax,
+                                     unsigned short* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long groups_per_row = K / 4;
+    if (absmax) scale = kn_pick_scale(*absmax);
     if (i >= n * groups_per_row) return;
     const long row = i / groups_per_row; const int k = (int)(i - row * groups_per_row) * 4;
     g2_u32x2 hi, lo;
@@ -822,7 +870,9 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.K = d->cin * d->taps;
     a.w3 = (const unsigned short*)d->w_bf16x3;
     a.w2 = (const unsigned short*)d->w_f16x2;
-    a.out_scale = 1.0f; a.a_scale = 1.0f;
+    a.out_scale = 1.0f; a.a_scale = 1.0f; a.w_scale = 1.0f;
+    a.x_absmax = nullptr; a.w_absmax = nullptr; a.out_absmax = d->out_absmax;
+    a.split_scale = d->out_f16x2_scale > 0.f ? d->out_f16x2_scale : KN_F16X2_A_SCALE;
     a.x_split = d->x_f16x2; a.out_split = d->out_f16x2 != 0; a.split_from = d->out_f16x2 > 1 ? d->out_f16x2 : 0;
     KN_REQUIRE(d->out_f16x2 >= 0 && (d->out_f16x2 <= 1 || d->out_f16x2 % 32 == 0), "conv_gemm: out_f16x2 is 0, 1 or the first split column (a multiple of 32)");
     a.lin = !d->convt_u && (long)d->m * d->ldo * 4 < (1L << 31) && (!d->resid || (long)d->m * d->ldr * 4 < (1L << 31)) &&
@@ -841,14 +891,21 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     if (a.out_split)
         KN_REQUIRE(!d->resid && !d->accumulate && a.div == 1.0f && !d->convt_u && d->n % 32 == 0 && d->ldo % 32 == 0 &&
                    ((uintptr_t)d->out & 15) == 0, "conv_gemm: out_f16x2 needs a plain [m, n % 32 == 0] output (no resid/accumulate/div/convt)");
-    if (a.x_split)
-        KN_REQUIRE(fast && a.w2 && d->a_slope == 1.0f && (d->a_f16x2_scale == 0.f || d->a_f16x2_scale == KN_F16X2_A_SCALE),
-                   "conv_gemm: x_f16x2 needs the f16x2 fast path (cin % 32 == 0, split weights), a_slope 1 and the default scale");
+    if (a.out_split) {
+        int e2 = 0;
+        KN_REQUIRE(frexpf(a.split_scale, &e2) == 0.5f, "conv_gemm: out_f16x2_scale must be a power of two");
+        KN_REQUIRE(!a.out_absmax, "conv_gemm: out_absmax is for fp32 outputs (a split output's scale is chosen by the caller)");
+    }
+    if (a.x_split)      // the scale the producer split with: a_f16x2_scale (0 = 16), or kn_pick_scale(*x_absmax)
+        KN_REQUIRE(fast && a.w2 && d->a_slope == 1.0f,
+                   "conv_gemm: x_f16x2 needs the f16x2 fast path (cin % 32 == 0, split weights) and a_slope 1");
     if (fast && a.w2) {        // fp32 emulated on the fp16 matrix cores (gemm2_core.h)
-        KN_REQUIRE(d->w_f16x2_scale > 0.f, "conv_gemm: w_f16x2 without its scale");
+        KN_REQUIRE(d->w_f16x2_scale > 0.f || d->w_absmax, "conv_gemm: w_f16x2 without its scale");
         a.a_scale = d->a_f16x2_scale > 0.f ? d->a_f16x2_scale : KN_F16X2_A_SCALE;
-        { int e2 = 0; KN_REQUIRE(frexpf(a.a_scale, &e2) == 0.5f && frexpf(d->w_f16x2_scale, &e2) == 0.5f, "conv_gemm: f16x2 scales must be powers of two"); }
-        a.out_scale = 1.0f / (a.a_scale * d->w_f16x2_scale);
+        a.w_scale = d->w_f16x2_scale > 0.f ? d->w_f16x2_scale : 1.0f;
+        { int e2 = 0; KN_REQUIRE(frexpf(a.a_scale, &e2) == 0.5f && frexpf(a.w_scale, &e2) == 0.5f, "conv_gemm: f16x2 scales must be powers of two"); }
+        a.out_scale = 1.0f / (a.a_scale * a.w_scale);
+        a.x_absmax = d->x_absmax; a.w_absmax = d->w_absmax;      // device-side scales override the two above
         // 256x256 double-buffered tile with LDS-DMA weights (one block per CU): fewer L2/LDS bytes per MFMA and a
         // higher sustained clock (1.65 vs 1.39 GHz) — 279 vs 242 TFLOP/s on an isolated long-K GEMM (FFN2), but a lone
         // block per CU cannot hide its prologue/epilogue and loses when other streams share the chip (end-to-end bench:
@@ -929,6 +986,50 @@ extern "C" int knnsvc_split_weight_f16x2(const float* w, int64_t rows, int32_t K
     KN_REQUIRE(scale > 0.f && frexpf(scale, &e) == 0.5f, "split_weight: scale must be a power of two");
     const long groups = rows * (K / 4);
     hipLaunchKernelGGL(split_weight2_kernel, dim3((unsigned)cdiv64(groups, 256)), dim3(256), 0, (hipStream_t)stream,
-                       w, (long)rows, K, scale, (unsigned short*)out);
+                       w, (long)rows, K, scale, (const float*)nullptr, (unsigned short*)out);
     return knnsvc_check_launch("split_weight2");
+}
+
+extern "C" int knnsvc_split_f16x2_dyn(const float* w, int64_t rows, int32_t K, const float* absmax, void* out, void* stream) {
+    KN_REQUIRE(w && out && absmax && rows > 0 && K > 0 && K % 32 == 0, "split_f16x2_dyn: K must be a positive multiple of 32");
+    KN_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0, "split_f16x2_dyn: 16-byte alignment");
+    const long groups = rows * (K / 4);
+    hipLaunchKernelGGL(split_weight2_kernel, dim3((unsigned)cdiv64(groups, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, (long)rows, K, 1.0f, absmax, (unsigned short*)out);
+    return knnsvc_check_launch("split_f16x2_dyn");
+}
+
+namespace {
+// grid-stride over 4-float groups of the rows (vec: 16-byte aligned rows), scalar otherwise; one atomicMax per wave
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long rows, int cols, int ld, int vec,
+                                                     float* __restrict__ slot) {
+    const int c4 = vec ? cols >> 2 : 0;
+    unsigned m = 0;
+    const long n4 = rows * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4; const int c = (int)(i - r * c4) * 4;
+        const f32x4 v = *(const f32x4*)(x + r * ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned ab = abs_bits(v[e]); m = ab > m ? ab : m; }
+    }
+    const int tail = cols - c4 * 4;
+    if (tail) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * tail; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / tail; const int c = c4 * 4 + (int)(i - r * tail);
+            const unsigned ab = abs_bits(x[r * ld + c]); m = ab > m ? ab : m;
+        }
+    }
+    publish_absmax(slot, m);
+}
+}  // namespace
+
+extern "C" int knnsvc_absmax(const float* x, int64_t rows, int32_t cols, int32_t ld, float* slot, void* stream) {
+    KN_REQUIRE(x && slot && rows >= 0 && cols > 0 && ld >= cols, "absmax: bad arguments");
+    if (rows == 0) return KNNSVC_OK;
+    const int vec = ((((uintptr_t)x & 15) == 0) && (ld % 4 == 0)) ? 1 : 0;
+    const long work = rows * (long)(vec ? (cols + 3) / 4 : cols);
+    long blocks = cdiv64(work, 256 * 8);
+    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)rows, cols, ld, vec, slot);
+    return knnsvc_check_launch("absmax");
 }

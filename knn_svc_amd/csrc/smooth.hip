@@ -100,7 +100,9 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
     int since = 0, it = 0;
     const float b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
     double pb1 = 1.0, pb2 = 1.0;
-    for (it = 0; it < max_iter; ++it) {
+    const bool forced = max_iter < 0;            // measurement mode: exactly |max_iter| iterations, stopping rules off
+    const int cap = forced ? -max_iter : max_iter;
+    for (it = 0; it < cap; ++it) {
         // ---- phase 1: softmax weights ---------------------------------------------------------
         for (long t = tid; t < nq; t += 1024) {
             const f32x4 th = theta[t];
@@ -150,12 +152,12 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
         const float loss = s_loss;
         // ---- phase 3: the reference's loop control (uniform across the block) -------------------
         if (it % 100 == 1) {
-            if (fabs(min_loss - conv_min) < 1e-5) break;
+            if (!forced && fabs(min_loss - conv_min) < 1e-5) break;
             conv_min = min_loss;
         }
         const bool improved = loss < (float)min_loss;
         if (improved) { min_loss = (double)loss; since = 0; } else ++since;
-        if (since >= 1000) break;
+        if (!forced && since >= 1000) break;
         // ---- phase 4: gradient through softmax + Adam(amsgrad) ----------------------------------
         pb1 *= 0.9; pb2 *= 0.999;
         const float step_size = (float)(-(0.1 / (1.0 - pb1)));
@@ -224,7 +226,9 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
     int since = 0, it = 0;
     const float b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
     double pb1 = 1.0, pb2 = 1.0;
-    for (it = 0; it < max_iter; ++it) {
+    const bool forced = max_iter < 0;            // measurement mode: exactly |max_iter| iterations, stopping rules off
+    const int cap = forced ? -max_iter : max_iter;
+    for (it = 0; it < cap; ++it) {
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
             const long t = tid + 512L * f;
@@ -271,12 +275,12 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
         __syncthreads();
         const float loss = s_loss;
         if (it % 100 == 1) {
-            if (fabs(min_loss - conv_min) < 1e-5) break;
+            if (!forced && fabs(min_loss - conv_min) < 1e-5) break;
             conv_min = min_loss;
         }
         const bool improved = loss < (float)min_loss;
         if (improved) { min_loss = (double)loss; since = 0; } else ++since;
-        if (since >= 1000) break;
+        if (!forced && since >= 1000) break;
         pb1 *= 0.9; pb2 *= 0.999;
         const float step_size = (float)(-(0.1 / (1.0 - pb1)));
         const float bc2_sqrt = (float)sqrt(1.0 - pb2);
@@ -333,7 +337,7 @@ extern "C" int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float
                                      int32_t ld, float scale, const float* row_scale, int32_t max_iter, float* out_w,
                                      int32_t* out_iters, void* workspace, size_t workspace_bytes, void* stream) {
     KN_REQUIRE(idx && pool && out_w && workspace, "smooth_weights: null pointer");
-    KN_REQUIRE(nq > 0 && np > 0 && dim > 0 && ld >= dim && max_iter > 0, "smooth_weights: bad sizes");
+    KN_REQUIRE(nq > 0 && np > 0 && dim > 0 && ld >= dim && max_iter != 0, "smooth_weights: bad sizes");
     KN_REQUIRE(((uintptr_t)out_w & 15) == 0, "smooth_weights: out_w must be 16-byte aligned");
     if (workspace_bytes < knnsvc_smooth_workspace_bytes(nq))
         return knnsvc_fail(KNNSVC_EWORKSPACE, "smooth_weights: workspace %zu < %zu bytes", workspace_bytes,

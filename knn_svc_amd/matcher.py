@@ -53,10 +53,9 @@ class KNeighborsVC:
 
     @staticmethod
     def _check_finite(wav):
-        # the emulated-fp32 GEMMs turn an out-of-range activation into NaN instead of a wrong sample: surface it
+        # operand scales follow the data (range slots), so a non-finite sample means a non-finite input or weight
         if not bool(torch.isfinite(wav).all()):
-            raise ops.KnnSvcError("vocode: non-finite waveform (activation outside the f16x2 range, or non-finite input); "
-                                  "re-run with KNNSVC_GEMM=bf16x3")
+            raise ops.KnnSvcError("vocode: non-finite waveform (non-finite features, f0, harmonics or weights)")
 
     def _vocode_async(self, c, f0, harm=None):
         """One utterance, enqueue only (no host sync): the tail stage of the dataset-mode pipeline."""

@@ -127,8 +127,10 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
               convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False,
-              w2=None, w2_scale=0.0):
-    """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr)."""
+              w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0):
+    """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr).
+    ``x_absmax`` / ``w_absmax`` / ``out_absmax``: one-element device tensors (range slots of the f16x2 path, see the
+    header): bound of |x| / |w| the kernel derives its operand scales from, and where this launch folds max|out|."""
     lib = _lib.load()
     d = ConvDesc()
     d.x = x.data_ptr(); d.x_bstride = x_bstride; d.x_gstride = x_gstride
@@ -154,11 +156,37 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.a_f16x2_scale = a_scale
     d.x_f16x2 = 1 if x_split else 0
     d.out_f16x2 = int(out_split) if (out_split is not True and out_split is not False) else (1 if out_split else 0)   # True / first split column
+    d.x_absmax = x_absmax.data_ptr() if x_absmax is not None else None
+    d.w_absmax = w_absmax.data_ptr() if w_absmax is not None else None
+    d.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
+    d.out_f16x2_scale = out_split_scale
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
     return out
 
 
-def linear(x2d, w, bias=None, act=ACT_NONE, resid=None, out=None, x_split=False, out_split=False):
+def absmax(x2d, slot=None):
+    """max |x| of a [rows, cols] view (row stride allowed) folded into ``slot`` (a zeroed one-element device tensor is
+    made when None): the range slot a later conv_gemm takes as x_absmax / w_absmax.  NaN in x makes the slot NaN."""
+    _need(x2d, name="absmax.x")
+    if slot is None:
+        slot = torch.zeros(1, device=x2d.device, dtype=torch.float32)
+    if x2d.dim() == 1:
+        x2d = x2d[None]
+    if x2d.stride(1) != 1:
+        raise KnnSvcError("absmax: rows must be contiguous")
+    check(_lib.load().knnsvc_absmax(_p(x2d), x2d.shape[0], x2d.shape[1], x2d.stride(0) if x2d.shape[0] > 1 else x2d.shape[1],
+                                    _p(slot), _stream()), "absmax")
+    return slot
+
+
+def pick_scale(bound: float) -> float:
+    """Host mirror of the kernels' kn_pick_scale: the largest power of two s with bound * s < 2^15."""
+    if not (bound > 0.0) or not math.isfinite(bound):
+        return 2.0 ** 54 if bound == 0.0 else 2.0 ** -114
+    return 2.0 ** (14 - max(math.frexp(bound)[1] - 1, -40))
+
+
+def linear(x2d, w, bias=None, act=ACT_NONE, resid=None, out=None, x_split=False, out_split=False, **kw):
     """out[M,N] = act(x2d[M,K] @ w[N,K]^T + bias) (+ resid).  x_split / out_split: operand / result in the f16x2
     split layout (include/knnsvc_hip.h, "A2"), carried in float32 tensors of the usual shape; out_split may also be
     the first split column (a multiple of 32): columns before it stay fp32."""
@@ -167,7 +195,7 @@ def linear(x2d, w, bias=None, act=ACT_NONE, resid=None, out=None, x_split=False,
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
-    return conv_gemm(x2d, w, out, m=M, n=N, cin=K, bias=bias, act=act, resid=resid, x_split=x_split, out_split=out_split)
+    return conv_gemm(x2d, w, out, m=M, n=N, cin=K, bias=bias, act=act, resid=resid, x_split=x_split, out_split=out_split, **kw)
 
 
 def split_pack(x2d: torch.Tensor) -> torch.Tensor:
@@ -226,11 +254,15 @@ def attention_mode() -> str:
     return "bf16x3" if e[:1] == "b" else "fp32" if e[:2] == "fp" else "f16x2"
 
 
-def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_split=False):
-    """kv_split: the K and V column blocks of qkv hold the f16x2 split layout (QKV projection run with out_split=E)."""
+def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_split=False, wide=False):
+    """kv_split: the K and V column blocks of qkv hold the f16x2 split layout (QKV projection run with out_split=E).
+    wide: Q / K / V may exceed the f16x2 kernel's fixed-scale range (decided at load from the weights,
+    WavLMEncoder._range_plan): run the bf16x3 kernel (fp32 exponent range) whatever KNNSVC_ATTENTION says."""
+    if wide and (out_split or kv_split):
+        raise KnnSvcError("wavlm_attention: wide-range mode has fp32 inputs and outputs")
     out = torch.empty(batches * T, heads * 64, device=qkv.device, dtype=torch.float32)
     check(_lib.load().knnsvc_wavlm_attention(_p(qkv), _p(gate), _p(table), batches, T, heads, _p(out),
-                                             1 if out_split else 0, 1 if kv_split else 0, _stream()), "wavlm_attention")
+                                             (1 if out_split else 0) | (4 if wide else 0), 1 if kv_split else 0, _stream()), "wavlm_attention")
     return out
 
 
@@ -245,9 +277,6 @@ def row_norms(x2d):
     return norm, sq
 
 
-KNN_FEATURE_SCALE = 16.0     # fixed power-of-two pre-scale of both operands on the f16x2 kNN route (|x| < 4094)
-
-
 def knn_mode() -> str:
     """KNNSVC_KNN = f16x2 | fp32.  f16x2 (default while KNNSVC_GEMM is f16x2): q.p^T from the emulated-fp32 GEMM +
     knnsvc_knn_select; fp32: the fused exact-fp32-MFMA tile kernel (knnsvc_knn_topk)."""
@@ -260,7 +289,10 @@ def knn_mode() -> str:
 
 def prepare_knn_pool(pool, k=32):
     """Pre-split image of a pool for the two-kernel kNN route, reusable across searches against the same pool
-    (dataset mode and prematch search one pool once per utterance): list of (first row, rows view, f16x2 image).
+    (dataset mode and prematch search one pool once per utterance): list of (first row, rows view, f16x2 image, range
+    slot).  The fp16 split needs a power-of-two pre-scale that fits the features' range; WavLM features have no a-priori
+    bound (outlier channels), so the scale is derived ON THE DEVICE from max|pool| (knnsvc_absmax -> knnsvc_split_f16x2_dyn;
+    the GEMM reads the same slot as w_absmax) — no host round trip, no fixed range.
     Returns None when the route does not apply (see knn_topk)."""
     _need(pool, name="knn.pool")
     npool, dim = pool.shape
@@ -276,29 +308,32 @@ def prepare_knn_pool(pool, k=32):
         npc = pc.shape[0]
         if npc < k:
             raise KnnSvcError("knn_topk: pool chunk smaller than k")
+        slot = absmax(pc)
         p2 = torch.empty(npc * (dim // 32) * 64, device=pool.device, dtype=torch.int16)
-        check(lib.knnsvc_split_weight_f16x2(_p(pc), npc, dim, KNN_FEATURE_SCALE, _p(p2), _stream()), "split_weight")
-        chunks.append((p0, pc, p2))
+        check(lib.knnsvc_split_f16x2_dyn(_p(pc), npc, dim, _p(slot), _p(p2), _stream()), "split_pool")
+        chunks.append((p0, pc, p2, slot))
     return chunks
 
 
 def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None):
-    """Two-kernel route: dot products on the f16x2 GEMM (pool rows = pre-split "weights", fixed scale 16), then the
-    reference's distance formula + selection (knnsvc_knn_select).  Pool and query are chunked so that every buffer
+    """Two-kernel route: dot products on the f16x2 GEMM (pool rows = pre-split "weights"), then the reference's distance
+    formula + selection (knnsvc_knn_select).  Both operands are scaled by device-chosen powers of two (range slots, see
+    prepare_knn_pool) — exact, so the dots do not depend on the scale.  Pool and query are chunked so that every buffer
     resource stays below 1 GiB and the dot matrix below ~1 GiB; pool chunks are folded with knnsvc_knn_merge."""
     lib = _lib.load()
     nq, dim = q.shape
     dev = q.device
     q_rows_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
     parts_i, parts_d = [], []
-    # the queries are split once into the A2 layout (the weight-split kernel writes exactly that image at scale 16) and
+    # the queries are split once into the A2 layout (the weight-split kernel writes exactly that image) and
     # every column tile of the GEMM stages them with plain copies instead of re-splitting them
     q2 = None
     import os
-    if KNN_FEATURE_SCALE == 16.0 and nq >= 128 and os.environ.get("KNNSVC_KNN_A2", "1") != "0":
+    q_slot = absmax(q)
+    if nq >= 128 and os.environ.get("KNNSVC_KNN_A2", "1") != "0":
         q2 = torch.empty(nq, dim, device=dev, dtype=torch.float32)
-        check(lib.knnsvc_split_weight_f16x2(_p(q), nq, dim, KNN_FEATURE_SCALE, _p(q2), _stream()), "split_queries")
-    for p0, pc, p2 in (prepared if prepared is not None else prepare_knn_pool(pool, k)):
+        check(lib.knnsvc_split_f16x2_dyn(_p(q), nq, dim, _p(q_slot), _p(q2), _stream()), "split_queries")
+    for p0, pc, p2, p_slot in (prepared if prepared is not None else prepare_knn_pool(pool, k)):
         npc = pc.shape[0]
         idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
         dist = torch.empty(nq, k, device=dev, dtype=torch.float32)
@@ -307,8 +342,7 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
             qc = (q2 if q2 is not None else q)[q0:q0 + q_rows]
             m = qc.shape[0]
             dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
-            conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, a_scale=KNN_FEATURE_SCALE, w2=p2, w2_scale=KNN_FEATURE_SCALE,
-                      x_split=q2 is not None)
+            conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, w2=p2, x_split=q2 is not None, x_absmax=q_slot, w_absmax=p_slot)
             check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
                                         idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
                                         _stream()), "knn_select")
@@ -403,8 +437,13 @@ def concat_reselect(idx4, q, q_norm, pool, p_norm, shifted_f0=None, pool_f0=None
     return out
 
 
+ADAM_FORCED_ITERS = None     # measurement aid (bench.py "value_long_adam"): run exactly this many iterations per loop
+
+
 def smooth_weights(idx4, pool, scale, max_iter=100000, return_iters=False, row_scale=None):
     """``row_scale`` [nq,4]: the amp_ratio of compute_weight_with_amp (ddsp_prematch_dataset.py:684-804)."""
+    if ADAM_FORCED_ITERS:
+        max_iter = -int(ADAM_FORCED_ITERS)
     _need(idx4, torch.int64, "idx4"); _need(pool, name="pool")
     if row_scale is not None:
         _need(row_scale, name="row_scale")

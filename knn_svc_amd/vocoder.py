@@ -123,50 +123,67 @@ class Vocoder:
         hop, n_up, uic = self.hop, self.n_up, self.uic
         L = N * hop
         new = lambda r, ch: torch.empty(r, ch, device=dev, dtype=torch.float32)
+        # Range slots of the f16x2 GEMMs (include/knnsvc_hip.h, "Range"): one device float per logical tensor.  Every
+        # producer folds max|out| into its output's slot (out_absmax), every consumer derives its activation scale from its
+        # input's slot (x_absmax) — the generator's activations have no a-priori bound (residual sums over 4 x 9 ResBlock
+        # convs, arbitrary trained weights), and this way no range can overflow fp16 and small-amplitude stages keep their
+        # bits, with no host round trip (the whole forward stays one hipGraph).
+        slots = torch.zeros(512, device=dev, dtype=torch.float32)
+        n_slot = [0]
+
+        def slot():
+            n_slot[0] += 1
+            return slots[n_slot[0] - 1:n_slot[0]]
         # lengths of the time axis at each level of the side path: lens[0] = L ... lens[n_up] = N
         lens = [L]
         for i in range(n_up):
             lens.append(lens[-1] // self.downs[i]["u"])
         assert lens[-1] == N
-        # concat buffers: up stage i consumes cat[i] = [ups_i output | res[n_up-1-i]]
-        cat = []
+        # concat buffers: up stage i consumes cat[i] = [ups_i output | res[n_up-1-i]]; one slot per buffer (both producers
+        # fold into it; the side path reads its part before the main path has written the other — a smaller bound, still
+        # a bound of what it reads)
+        cat, cat_slot = [], []
         for i in range(n_up):
             ch = uic // 2 ** (i + 1)
             cat.append(new(lens[n_up - 1 - i], ch + self.side[n_up - 1 - i]))
-        cat_pre = new(N, uic + self.side[n_up])
+            cat_slot.append(slot())
+        cat_pre, cat_pre_slot = new(N, uic + self.side[n_up]), slot()
 
         def res_view(level):
-            """(tensor view, ld, channels) of res[level] inside its concat buffer."""
+            """(tensor view, ld, channels, slot) of res[level] inside its concat buffer."""
             if level == n_up:
-                return cat_pre[:, uic:], cat_pre.shape[1], self.side[level]
+                return cat_pre[:, uic:], cat_pre.shape[1], self.side[level], cat_pre_slot
             buf = cat[n_up - 1 - level]
             ch = uic // 2 ** (n_up - level)
-            return buf[:, ch:], buf.shape[1], self.side[level]
+            return buf[:, ch:], buf.shape[1], self.side[level], cat_slot[n_up - 1 - level]
 
         # ---- excitation + sin_prenet -> res[0] -------------------------------------------------
-        cond, ld0, c0 = res_view(0)
+        cond, ld0, c0, s0 = res_view(0)
         ops.additive_synth(f0.contiguous(), harm.contiguous() if self.kind == "mix" else None, self.prenet_w, self.prenet_b,
                            cond, ld0, hop=hop, sr=self.sr, mode=0 if self.kind == "mix" else 1)
+        ops.absmax(cond[:, :c0], s0)
         # ---- side (down) path ----------------------------------------------------------------------
         for i in range(n_up):
-            src, ld_s, c_s = res_view(i)
-            dst, ld_d, c_d = res_view(i + 1)
+            src, ld_s, c_s, s_src = res_view(i)
+            dst, ld_d, c_d, s_dst = res_view(i + 1)
             dn = self.downs[i]
             t_in = lens[i]
             t_mid = t_in // dn["u"] + 1            # the conv yields one more row than the crop keeps; the
-            mid = new(t_mid, c_d)                   # k=3 resblock conv still reads it (ddsp_models.py:189-194)
+            mid, s_mid = new(t_mid, c_d), slot()    # k=3 resblock conv still reads it (ddsp_models.py:189-194)
             self._conv(src, dn["w"], mid, T_in=t_in, cin=c_s, cout=c_d, k=dn["k"], m=t_mid, stride=dn["u"],
-                       pad=dn["k"] // 2, ldx=ld_s, bias=dn["b"])
+                       pad=dn["k"] // 2, ldx=ld_s, bias=dn["b"], x_absmax=s_src, out_absmax=s_mid)
             rb = self.rbd[i]
             self._conv(mid, rb["w"], dst, T_in=t_mid, cin=c_d, cout=c_d, k=3, m=lens[i + 1], pad=1, bias=rb["b"],
-                       a_slope=LRELU, resid=mid, ldr=c_d, ldo=ld_d)
+                       a_slope=LRELU, resid=mid, ldr=c_d, ldo=ld_d, x_absmax=s_mid, out_absmax=s_dst)
         # ---- main path ------------------------------------------------------------------------------
-        x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b)
+        s_x0 = slot()
+        x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b, x_absmax=ops.absmax(c.contiguous(), slot()), out_absmax=s_x0)
         hd = x0.shape[1]
         self._conv(x0, self.pre_w, cat_pre, T_in=N, cin=hd, cout=uic, k=7, m=N, pad=3, bias=self.pre_b,
-                   ldo=cat_pre.shape[1])
-        x = new(N, uic)
-        self._conv(cat_pre, self.cpre_w, x, T_in=N, cin=cat_pre.shape[1], cout=uic, k=3, m=N, pad=1, bias=self.cpre_b)
+                   ldo=cat_pre.shape[1], x_absmax=s_x0, out_absmax=cat_pre_slot)
+        x, s_x = new(N, uic), slot()
+        self._conv(cat_pre, self.cpre_w, x, T_in=N, cin=cat_pre.shape[1], cout=uic, k=3, m=N, pad=1, bias=self.cpre_b,
+                   x_absmax=cat_pre_slot, out_absmax=s_x)
         t_cur = N
         for i in range(n_up):
             up = self.ups[i]
@@ -177,27 +194,33 @@ class Vocoder:
             ld_c = cat[i].shape[1]
             ops.conv_gemm(x, up["w"], cat[i], m=t_cur + R - 1, n=u * cout, cin=cin, taps=R, stride=1, dil=-1, pad=0,
                           t_in=t_cur, bias=up["b"], bias_period=cout, a_slope=LRELU, ldo=ld_c,
-                          convt_u=u, convt_cout=cout, convt_pad=(k - u) // 2, t_out=t_out)
-            xc = new(t_out, cout)
-            self._conv(cat[i], self.ccv[i], xc, T_in=t_out, cin=ld_c, cout=cout, k=3, m=t_out, pad=1)
-            xs = new(t_out, cout)
+                          convt_u=u, convt_cout=cout, convt_pad=(k - u) // 2, t_out=t_out, x_absmax=s_x, out_absmax=cat_slot[i])
+            xc, s_xc = new(t_out, cout), slot()
+            self._conv(cat[i], self.ccv[i], xc, T_in=t_out, cin=ld_c, cout=cout, k=3, m=t_out, pad=1,
+                       x_absmax=cat_slot[i], out_absmax=s_xc)
+            xs, s_xs = new(t_out, cout), slot()
             t1, ra, rb_ = new(t_out, cout), new(t_out, cout), new(t_out, cout)
             nblk = len(self.res[i])
             for j, blk in enumerate(self.res[i]):
                 kr = blk["k"]
-                cur = xc
+                cur, s_cur = xc, s_xc
                 for m, cv in enumerate(blk["convs"]):
                     d = cv["d"]
+                    s_t1 = slot()
                     self._conv(cur, cv["w1"], t1, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, dil=d,
-                               pad=(kr * d - d) // 2, bias=cv["b1"], a_slope=LRELU, act=ops.ACT_LRELU, act_slope=LRELU)
+                               pad=(kr * d - d) // 2, bias=cv["b1"], a_slope=LRELU, act=ops.ACT_LRELU, act_slope=LRELU,
+                               x_absmax=s_cur, out_absmax=s_t1)
                     last = m == len(blk["convs"]) - 1
                     dst = xs if last else (ra if cur is not ra else rb_)
+                    s_dst = s_xs if last else slot()
                     self._conv(t1, cv["w2"], dst, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, pad=(kr - 1) // 2,
                                bias=cv["b2"], resid=cur, ldr=cout,
-                               accumulate=(last and j > 0), div=(float(nblk) if (last and j == nblk - 1) else 1.0))
-                    cur = dst
-            x, t_cur = xs, t_out
+                               accumulate=(last and j > 0), div=(float(nblk) if (last and j == nblk - 1) else 1.0),
+                               x_absmax=s_t1, out_absmax=s_dst)
+                    cur, s_cur = dst, s_dst
+            x, s_x, t_cur = xs, s_xs, t_out
         y = new(t_cur, 1)
         self._conv(x, self.post_w, y, T_in=t_cur, cin=x.shape[1], cout=1, k=7, m=t_cur, pad=3, a_slope=0.01,
-                   act=ops.ACT_TANH)
+                   act=ops.ACT_TANH, x_absmax=s_x)
+        assert n_slot[0] <= slots.numel()
         return y.reshape(-1)

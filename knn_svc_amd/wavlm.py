@@ -116,11 +116,53 @@ class WavLMEncoder:
                 w2=fw(state[p + "fc2.weight"]), b2=f(state[p + "fc2.bias"]),
             ))
         self.rel_emb = state["encoder.layers.0.self_attn.relative_attention_bias.weight"].detach().float().cpu()
+        self.plan = self._range_plan(state)
         self._tables = {}
         self._graphs = {}          # (B, L) -> (hipGraph, static input, static output)
         self.use_graphs = True
 
     # -------------------------------------------------------------------------------------------
+    A2_LIMIT = 0.9 * 65504.0 / 16.0          # |x| an activation may reach in the fixed-scale (16) split layout
+
+    def _range_plan(self, state) -> dict:
+        """Which activations may travel in the f16x2 split layout ("A2", fixed scale 16: |x| < 4094)?  Decided once, at
+        load, from ANALYTIC bounds of every such tensor given the weights — never from data, so no input can overflow
+        the layout: a LayerNorm output obeys |y_i| <= max|g| sqrt(C-1) + max|b| and ||y||_2 <= max|g| sqrt(C) + ||b||_2;
+        a linear layer of it |y_j| <= ||x||_2 ||w_j||_2 + |b_j| (Cauchy-Schwarz); GELU and the softmax-weighted sum of
+        V do not grow their inputs.  With trained or seeded WavLM weights every bound is far below the limit and the plan
+        is "everything split"; a tensor whose bound is not (outlier-heavy fine-tunes) travels as fp32 instead and its
+        consumer takes its scale from a device-side range slot (ops.absmax / out_absmax -> x_absmax), and a layer whose
+        Q/K/V bound is not runs the bf16x3 attention kernel (fp32 exponent range)."""
+        lim = self.A2_LIMIT
+        f = lambda k: state[k].detach().float()
+        ln_elem = lambda g, b, c: float(g.abs().max()) * math.sqrt(max(c - 1, 1)) + float(b.abs().max())
+        ln_l2 = lambda g, b, c: float(g.abs().max()) * math.sqrt(c) + float(b.norm())
+        lin = lambda l2, w, b: l2 * float(w.norm(dim=1).max()) + float(b.abs().max())
+        plan = dict(conv=[], layers=[], bounds={})
+        for i, (dim, _k, _s) in enumerate(C.conv_layers(self.cfg)):
+            b = ln_elem(f(f"feature_extractor.conv_layers.{i}.2.1.weight"), f(f"feature_extractor.conv_layers.{i}.2.1.bias"), dim)
+            plan["conv"].append(b < lim); plan["bounds"][f"conv{i}"] = b
+        cdim = C.conv_layers(self.cfg)[-1][0]
+        b = ln_elem(f("layer_norm.weight"), f("layer_norm.bias"), cdim)
+        plan["feats"] = b < lim; plan["bounds"]["feats"] = b
+        E = self.E
+        for l in range(self.n_layers):
+            p = f"encoder.layers.{l}."
+            g1, b1 = f(p + "self_attn_layer_norm.weight"), f(p + "self_attn_layer_norm.bias")
+            g2, b2 = f(p + "final_layer_norm.weight"), f(p + "final_layer_norm.bias")
+            xn_e, xn_2 = ln_elem(g1, b1, E), ln_l2(g1, b1, E)
+            a = p + "self_attn."
+            qb = lin(xn_2, f(a + "q_proj.weight"), f(a + "q_proj.bias"))
+            kb = lin(xn_2, f(a + "k_proj.weight"), f(a + "k_proj.bias"))
+            vb = lin(xn_2, f(a + "v_proj.weight"), f(a + "v_proj.bias"))
+            x2_e, x2_2 = ln_elem(g2, b2, E), ln_l2(g2, b2, E)
+            hb = lin(x2_2, f(p + "fc1.weight"), f(p + "fc1.bias"))
+            # the f16x2 attention kernel splits K and V at scale 16 and Q at 16 log2(e)/8 (attention.hip)
+            narrow = kb < lim and vb < lim and qb < lim * 5.0
+            plan["layers"].append(dict(xn=xn_e < lim, xn2=x2_e < lim, h=hb < lim, attn_f16=narrow))
+            plan["bounds"][f"layer{l}"] = dict(xn=xn_e, q=qb, k=kb, v=vb, xn2=x2_e, h=hb)
+        return plan
+
     def n_frames(self, n_samples: int) -> int:
         n = n_samples
         for c in self.conv:
@@ -169,47 +211,61 @@ class WavLMEncoder:
         # producer (LayerNorm, the fused first conv, the GELU epilogue of FFN1, attention) splits every element once
         # and the GEMM stages its A operand with plain copies instead of re-splitting it in every column tile.
         a2 = ops.gemm_mode() == "f16x2" and os.environ.get("KNNSVC_A2", "1") != "0"
-        sp = lambda dim: a2 and dim % 32 == 0           # a [*, dim] activation can be carried split
+        dyn = ops.gemm_mode() == "f16x2"                # fp32 GEMM inputs take their scale from a device range slot
+        plan = self.plan
+        sp = lambda dim, ok=True: a2 and ok and dim % 32 == 0      # a [*, dim] activation can be carried split
+        slot_of = lambda t: ops.absmax(t) if dyn else None          # bound of a tensor no GEMM epilogue produced
         x_sp = False                                    # is x currently in the split layout?
         for li, c in enumerate(self.conv):
             t_out = (t_in - c["k"]) // c["s"] + 1
             if li == 0 and cin == 1 and c["dim"] in (64, 128, 256, 512) and c["k"] <= 16 and c["s"] <= 8:
-                x_sp = sp(c["dim"]) and c["dim"] >= 256 and len(self.conv) > 1
+                x_sp = sp(c["dim"], plan["conv"][0]) and c["dim"] >= 256 and len(self.conv) > 1
                 x = ops.wavlm_conv0(x, c["w"], c["g"], c["b"], c["k"], c["s"], out_split=x_sp)   # conv + LN + GELU in one pass
                 t_in, cin = t_out, c["dim"]
                 continue
             y = torch.empty(B * t_out, c["dim"], device=dev, dtype=torch.float32)
             ops.conv_gemm(x, c["w"], y, m=t_out, n=c["dim"], cin=cin, taps=c["k"], stride=c["s"], t_in=t_in,
-                          batches=B, x_bstride=t_in * cin, o_bstride=t_out * c["dim"], x_split=x_sp)
-            x_sp = sp(c["dim"]) and li + 1 < len(self.conv)         # the last layer's output feeds a LayerNorm, not a GEMM
+                          batches=B, x_bstride=t_in * cin, o_bstride=t_out * c["dim"], x_split=x_sp,
+                          x_absmax=None if (x_sp or cin % 32) else slot_of(x.view(-1, cin)))
+            x_sp = sp(c["dim"], plan["conv"][li]) and li + 1 < len(self.conv)         # the last layer's output feeds a LayerNorm, not a GEMM
             ops.layernorm(y, c["g"], c["b"], gelu=True, out=y, out_split=x_sp)
             x, t_in, cin = y, t_out, c["dim"]
         T = t_in
         assert not x_sp
-        f_sp = sp(cin)
+        f_sp = sp(cin, plan["feats"])
         feats = ops.layernorm(x, self.ln_g, self.ln_b, out_split=f_sp)
-        x = ops.linear(feats, self.proj_w, self.proj_b, x_split=f_sp)             # [B*T, E]
+        x_slot = torch.zeros(1, device=dev, dtype=torch.float32) if dyn else None
+        x = ops.linear(feats, self.proj_w, self.proj_b, x_split=f_sp, x_absmax=None if f_sp else slot_of(feats),
+                       out_absmax=x_slot)             # [B*T, E]
         E, H, G, K = self.E, self.H, self.G, self.Kpos
         cg = E // G
         x2 = torch.empty_like(x)
         ops.conv_gemm(x, self.pos_w, x2, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T, ldx=E, ldo=E,
                       bias=self.pos_b, act=ops.ACT_GELU, resid=x, ldr=E, batches=B, groups=G,
                       x_bstride=T * E, x_gstride=cg, w_gstride=cg * cg * K, bias_gstride=cg,
-                      o_bstride=T * E, o_gstride=cg, r_bstride=T * E, r_gstride=cg)
+                      o_bstride=T * E, o_gstride=cg, r_bstride=T * E, r_gstride=cg, x_absmax=x_slot)
         x = x2
         table = self._table(T)
-        e_sp, h_sp = sp(E), sp(self.layers[0]["w1"].shape[0]) if self.layers else False
-        for ly in self.layers:
+        hdim = self.layers[0]["w1"].shape[0] if self.layers else 0
+        for ly, pl in zip(self.layers, plan["layers"]):
+            e_sp = sp(E, pl["xn"])
             xn = ops.layernorm(x, ly["ln1_g"], ly["ln1_b"], out_split=e_sp)
             gate = ops.wavlm_gate(xn, H, ly["gate_w"], ly["gate_b"], ly["grep_a"], x_split=e_sp)
             # K and V leave the projection pre-split (every query block of a head re-split the same keys otherwise); Q stays fp32
-            kv_sp = e_sp and ops.attention_mode() == "f16x2"
-            qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"], x_split=e_sp, out_split=E if kv_sp else False)
-            att = ops.wavlm_attention(qkv, gate, table, B, T, H, out_split=e_sp, kv_split=kv_sp)
-            x = ops.linear(att, ly["wo"], ly["bo"], resid=x, x_split=e_sp)
-            xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"], out_split=e_sp)
-            hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU, x_split=e_sp, out_split=h_sp)
-            x = ops.linear(hmid, ly["w2"], ly["b2"], resid=x, x_split=h_sp)
+            narrow = pl["attn_f16"] or ops.attention_mode() != "f16x2"
+            kv_sp = sp(E) and narrow and ops.attention_mode() == "f16x2"
+            qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"], x_split=e_sp, out_split=E if kv_sp else False,
+                             x_absmax=None if e_sp else slot_of(xn))
+            a_sp = sp(E) and narrow                       # attention output <= max|V|: same bound
+            att = ops.wavlm_attention(qkv, gate, table, B, T, H, out_split=a_sp, kv_split=kv_sp, wide=not narrow)
+            x = ops.linear(att, ly["wo"], ly["bo"], resid=x, x_split=a_sp, x_absmax=None if a_sp else slot_of(att))
+            e2_sp = sp(E, pl["xn2"])
+            xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"], out_split=e2_sp)
+            h_sp = sp(hdim, pl["h"])
+            h_slot = torch.zeros(1, device=dev, dtype=torch.float32) if (dyn and not h_sp) else None
+            hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU, x_split=e2_sp, out_split=h_sp,
+                              x_absmax=None if e2_sp else slot_of(xn), out_absmax=h_slot)
+            x = ops.linear(hmid, ly["w2"], ly["b2"], resid=x, x_split=h_sp, x_absmax=h_slot)
         return x.view(B, T, E)
 
     def full_features(self, wav_1d: torch.Tensor, max_batch: int = 8) -> torch.Tensor:

@@ -1,0 +1,121 @@
+"""GPU: parity against the CPU oracle at FULL dimensions AND FULL length — the shapes bench.py runs
+(one 30 s chunk = T 1500 frames), not short stand-ins: the multi-key-tile path of the attention kernel, the
+>= 800-distance buckets of the relative position bias, the last-tile masks, the fp64 phase prefix of the additive
+synthesiser over 1500 frames, the generator's long time axes.  Reference: wavlm/modules.py:457-564,
+wavlm/WavLM.py:572-714, ddsp_prematch_dataset.py:165-208, hifigan/ddsp_models.py:176-233."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from knn_svc_amd import config as C, synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _stats(out, ref):
+    d = (out.detach().cpu().double() - ref.detach().cpu().double())
+    return float(d.abs().max()), float(d.pow(2).mean().sqrt()), float(ref.abs().max()), float(ref.double().pow(2).mean().sqrt())
+
+
+def test_wavlm_large_six_layers_one_full_chunk_vs_oracle():
+    """WavLM-Large, 6 layers, ONE 30 s chunk (480 320 padded samples -> T = 1500) against the oracle."""
+    from knn_svc_amd.wavlm import WavLMEncoder
+    from oracle import wavlm_ref
+    cfg = C.WAVLM_LARGE
+    sd = S.seeded_state(S.wavlm_param_spec(cfg, 6), seed=1)
+    w, _ = S.synth_clip(30 * 16000, 31)
+    x = torch.from_numpy(np.pad(w, (0, 320)))[None]
+    ref = wavlm_ref.extract_layer(sd, cfg, x, 6)
+    assert ref.shape == (1, 1500, 1024)
+    out = WavLMEncoder(sd, cfg, DEV, n_layers=6).encode_batch(x.to(DEV))
+    mx, rms, rmax, rrms = _stats(out, ref)
+    print(f"WavLM-Large 6 layers, T=1500: max|d| {mx:.2e} rms {rms:.2e} (ref max {rmax:.2f} rms {rrms:.3f})")
+    assert mx < 1e-4 * max(1.0, rmax) and rms < 5e-6 * max(1.0, rrms)
+    # the features feed a cosine kNN: per-frame direction error
+    cos = F.cosine_similarity(out[0].cpu().double(), ref[0].double(), dim=1)
+    print(f"  min per-frame cosine {float(cos.min()):.9f}")
+    assert float((1 - cos).max()) < 1e-9
+
+
+def test_attention_full_length_vs_oracle():
+    """attention2_kernel at E=1024 / H=16 / T=1500 (12 query blocks x many key tiles per head, distances beyond the
+    last log bucket, ragged last tile since 1500 % 128 != 0) vs F.scaled_dot_product_attention with the gated bias."""
+    from knn_svc_amd import ops
+    from oracle import wavlm_ref
+    cfg = dict(C.WAVLM_LARGE, encoder_layers=1)
+    H, E, T, B = 16, 1024, 1500, 1
+    sd = S.seeded_state([s for s in S.wavlm_param_spec(cfg) if s[0].startswith("encoder.layers.0.self_attn")], 3)
+    g = torch.Generator().manual_seed(2)
+    xn = torch.randn(T, B, E, generator=g)
+    p = "encoder.layers.0.self_attn."
+    gate_ref = wavlm_ref.gate(sd, cfg, 0, xn)
+    w8, b8 = sd[p + "grep_linear.weight"], sd[p + "grep_linear.bias"]
+    w2 = torch.stack([w8[:4].sum(0), w8[4:].sum(0)]).contiguous()
+    b2 = torch.stack([b8[:4].sum(), b8[4:].sum()])
+    xbt = xn.transpose(0, 1).reshape(B * T, E).contiguous().to(DEV)
+    gate = ops.wavlm_gate(xbt, H, w2.to(DEV), b2.to(DEV), sd[p + "grep_a"].reshape(-1).to(DEV))
+    pb = wavlm_ref.position_bias(sd, cfg, T)
+    # scale the projections up so that the scores are not flat (seeded N(0, 0.02) weights give near-uniform softmax)
+    q = 6.0 * F.linear(xn, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"])
+    k = 6.0 * F.linear(xn, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
+    v = F.linear(xn, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    sh = lambda t: t.reshape(T, B * H, 64).transpose(0, 1).reshape(B, H, T, 64)
+    ref = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), attn_mask=gate_ref * pb[None])
+    ref = ref.permute(0, 2, 1, 3).reshape(B * T, E)
+    lut = wavlm_ref.rel_bucket_table(T, 320, 800)
+    assert int(lut.max()) == 319 and int(lut.min()) == 0                      # both saturated log buckets are reached
+    table = sd[p + "relative_attention_bias.weight"][lut].T.contiguous()
+    qkv = torch.cat([q, k, v], -1).transpose(0, 1).reshape(B * T, 3 * E).contiguous().to(DEV)
+    out = ops.wavlm_attention(qkv, gate, table.to(DEV), B, T, H)
+    mx, rms, rmax, rrms = _stats(out, ref)
+    print(f"attention T=1500: max|d| {mx:.2e} rms {rms:.2e} (ref max {rmax:.3f} rms {rrms:.4f})")
+    assert mx < 2e-5 * max(1.0, rmax) and rms < 2e-6 * max(1.0, rrms)
+    # first and last query rows see the extreme relative distances
+    for rows in (slice(0, 4), slice(T - 4, T)):
+        assert float((out[rows].cpu() - ref[rows]).abs().max()) < 2e-5 * max(1.0, rmax)
+
+
+def test_vocoder_full_size_300_frames_vs_oracle():
+    """Full-size 'mix' generator (22.9 M parameters), 300 frames = 6 s = 96 000 samples, vs the CPU oracle."""
+    from knn_svc_amd.vocoder import Vocoder
+    from oracle import vocoder_ref
+    h = C.HIFIGAN_V1
+    sd = S.seeded_state(S.generator_param_spec(h, "mix"), 2)
+    g = torch.Generator().manual_seed(3)
+    N = 300
+    c = torch.randn(N, 1024, generator=g)
+    _, f0 = S.synth_clip(N * 320, 5); f0 = torch.from_numpy(f0[:N].copy())
+    harm = torch.rand(N, 49, generator=g) * 0.02
+    ref = vocoder_ref.synthesizer(sd, h, "mix", c[None], f0[None, :, None], harm[None])[0, 0]
+    y = Vocoder(sd, h, "mix", DEV).forward(c.to(DEV), f0.to(DEV), harm.to(DEV))
+    mx, rms, rmax, rrms = _stats(y, ref)
+    print(f"full generator, 300 frames: rms {rms:.2e} max|d| {mx:.2e} (ref rms {rrms:.3f})")
+    assert y.numel() == N * 320 and rms < 2e-6 and mx < 5e-5      # north_star bar: 1e-4 RMS
+
+
+def test_additive_synth_1500_frames_gliding_f0_vs_oracle():
+    """get_bulk_dsp_choral over a whole 30 s chunk with a gliding f0 and unvoiced gaps: the fp64 phase prefix runs
+    over 480 000 samples (DESIGN 'known sensitivity'), harmonics cross Nyquist as f0 rises."""
+    from knn_svc_amd import ops
+    from oracle import synth_ref
+    N = 1500
+    _, f0 = S.synth_clip(N * 320, 77)
+    f0 = torch.from_numpy(f0[:N].copy())
+    f0 = torch.where(f0 > 0, f0 * (1.0 + 0.9 * torch.linspace(0, 1, N)), f0)        # glide up to ~800 Hz: k*f0 crosses 8 kHz
+    g = torch.Generator().manual_seed(7)
+    amp = torch.rand(N, 49, generator=g) * 0.05
+    amp[::7] *= -0.3                                                                  # bicubic overshoot region / sign changes
+    ref = synth_ref.additive_synth(f0[None, :, None], amp[None])[0, :, 0]
+    pw = torch.randn(32, 3, generator=g); pb = torch.randn(32, generator=g)
+    cond = torch.empty(N * 320, 32, device=DEV)
+    exc = ops.additive_synth(f0.to(DEV), amp.to(DEV), pw.to(DEV), pb.to(DEV), cond, 32, want_exc=True)
+    mx, rms, rmax, rrms = _stats(exc, ref)
+    print(f"additive synth 1500 frames: max|d| {mx:.2e} rms {rms:.2e} (ref max {rmax:.3f})")
+    assert mx < 2e-5 and rms < 2e-6
+    # the error must not grow along the phase integrator: last second as good as the first
+    d = (exc.cpu() - ref).abs()
+    assert float(d[-16000:].max()) < 2e-5 and float(d[:16000].max()) < 2e-5
+    ref_cond = F.conv1d(ref[None, None], pw[:, None, :], pb, padding=1)[0].T
+    assert float((cond.cpu() - ref_cond).abs().max()) < 1e-4

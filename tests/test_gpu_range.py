@@ -1,0 +1,160 @@
+"""GPU: the f16x2 (fp32-on-fp16-matrix-cores) path under activation ranges the seeded N(0, s) weights never produce —
+outlier channels (x 10^3..10^4), tiny-rms tensors, weights that push LayerNorm / FFN / attention / generator
+activations past the fixed-scale limit of 4094.  Nothing here may come out NaN or inaccurate, and nothing needs a manual
+re-run in another mode: operand scales are derived on the device from range slots (knnsvc_absmax, out_absmax -> x_absmax),
+the encoder's split-layout plan is decided from analytic bounds of the weights, and out-of-range attention layers run the
+bf16x3 kernel.  Released WavLM-Large / generator checkpoints are known for outlier channels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from knn_svc_amd import config as C, synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(out, ref):
+    out, ref = out.detach().cpu().double(), ref.detach().cpu().double()
+    return float((out - ref).pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-300)), float((out - ref).abs().max() / (ref.abs().max() + 1e-300))
+
+
+def _heavy(M, K, seed, outliers=(3, 500, 901), mag=2.0e4):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g)
+    for j, c in enumerate(outliers):
+        x[:, c % K] *= mag / (1 + j)                 # a few channels 10^3..10^4 times larger than the rest
+    return x
+
+
+@pytest.mark.parametrize("M,K,N", [(1500, 1024, 1024), (300, 4096, 1024), (129, 64, 130)])
+def test_linear_outlier_channels_with_range_slot(M, K, N):
+    from knn_svc_amd import ops
+    x = _heavy(M, K, 1)
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(N, K, generator=g) * 0.03
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().T + b.double()
+    xd, wd, bd = x.to(DEV), ops.attach_split(w.to(DEV)), b.to(DEV)
+    assert float(x.abs().max()) > 4094 * 4                        # far outside the fixed-scale range
+    slot = ops.absmax(xd)
+    assert float(slot) == float(x.abs().max())
+    out_slot = torch.zeros(1, device=DEV)
+    out = ops.linear(xd, wd, bd, x_absmax=slot, out_absmax=out_slot)
+    rms, mx = _rel(out, ref)
+    print(f"linear with outlier channels ({M}x{K}x{N}): rel rms {rms:.2e} max {mx:.2e}")
+    assert bool(torch.isfinite(out).all()) and rms < 2e-7 and mx < 2e-6
+    # the epilogue's fold of max|out| is a bound of what was stored (rows past M may add |bias|: still a bound)
+    true_max = float(out.abs().max())
+    assert true_max <= float(out_slot) <= max(true_max, float(b.abs().max())) * (1 + 1e-6)
+    # the fixed default scale cannot hold these activations: documented as loud (NaN), never silently wrong
+    bad = ops.linear(xd, wd, bd)
+    assert not bool(torch.isfinite(bad).all())
+
+
+@pytest.mark.parametrize("scale", [1e-6, 3e-3, 7e4])
+def test_linear_tiny_and_huge_rms_with_range_slot(scale):
+    from knn_svc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(700, 1024, generator=g) * scale
+    w = torch.randn(512, 1024, generator=g) * 0.05
+    ref = x.double() @ w.double().T
+    out = ops.linear(x.to(DEV), ops.attach_split(w.to(DEV)), x_absmax=ops.absmax(x.to(DEV)))
+    rms, mx = _rel(out, ref)
+    print(f"linear at activation scale {scale:g}: rel rms {rms:.2e} max {mx:.2e}")
+    assert rms < 2e-7 and mx < 2e-6
+
+
+def test_range_slot_results_do_not_depend_on_the_scale():
+    """Power-of-two operand scales are exact: the slot-driven GEMM is bit-identical to the fixed-scale one wherever
+    the latter is in range."""
+    from knn_svc_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1000, 1024, generator=g).to(DEV)
+    w = ops.attach_split((torch.randn(768, 1024, generator=g) * 0.02).to(DEV))
+    a = ops.linear(x, w)
+    b = ops.linear(x, w, x_absmax=ops.absmax(x))
+    c = ops.linear(x, w, x_absmax=torch.full((1,), 1000.0, device=DEV))      # a loose bound is fine too
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("fs", [2.0 ** 15, 2.0 ** -15, 300.0])
+def test_knn_feature_scale_invariance(fs):
+    """WavLM features have no a-priori range: the kNN picks its operand scales from max|q| / max|pool| on the device."""
+    from knn_svc_amd import ops
+    from oracle import knn_ref
+    q = S.clustered_features(200, 1024, 41) * fs
+    p = S.clustered_features(4096, 1024, 42) * fs
+    idx, dist = ops.knn_topk(q.to(DEV), p.to(DEV), 32)
+    ref_i, ref_d = knn_ref.knn_topk(q, p, 32)
+    st = knn_ref.topk_agreement(ref_i, idx.cpu(), knn_ref.cosine_dist_f64(q, p), tau=5e-7)
+    print(f"kNN at feature scale {fs:g}:", st)
+    assert st["unexplained"] == 0 and st["top4"] >= 0.99 and float((dist.cpu() - ref_d).abs().max()) < 5e-6
+    if fs in (2.0 ** 15, 2.0 ** -15):          # a power-of-two rescaling changes no bit of the dots, norms or distances
+        i1, d1 = ops.knn_topk((q / fs).to(DEV), (p / fs).to(DEV), 32)
+        assert torch.equal(i1, idx) and torch.equal(d1, dist)
+
+
+def _scaled_state(sd, factors):
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k, f in factors.items():
+        assert k in sd, k
+        sd[k] = sd[k] * f
+    return sd
+
+
+def test_wavlm_large_with_outlier_weights_takes_the_wide_paths():
+    """LayerNorm gains / FFN / q-k projections scaled so that layer 1's FFN hidden and layer 0's keys exceed 4094: the
+    range plan must route those tensors around the fixed-scale split layout, and the result must still match the oracle."""
+    from knn_svc_amd.wavlm import WavLMEncoder
+    from oracle import wavlm_ref
+    cfg = C.WAVLM_LARGE
+    base = S.seeded_state(S.wavlm_param_spec(cfg, 3), seed=1)
+    sd = _scaled_state(base, {
+        "encoder.layers.1.final_layer_norm.weight": 60.0, "encoder.layers.1.fc1.weight": 40.0,     # FFN hidden up to ~7000
+        "encoder.layers.1.fc2.weight": 1.0 / 2400.0,                                                # keep the stream sane
+        "encoder.layers.0.self_attn.k_proj.weight": 3000.0, "encoder.layers.0.self_attn.q_proj.weight": 1.0 / 3000.0,   # keys up to ~14000
+        "encoder.layers.2.self_attn_layer_norm.weight": 1500.0, "encoder.layers.2.self_attn.v_proj.weight": 1.0 / 1500.0,   # LN output up to ~6000
+        "encoder.layers.2.self_attn.q_proj.weight": 1.0 / 1500.0, "encoder.layers.2.self_attn.k_proj.weight": 1.0 / 1500.0,
+    })
+    w0, _ = S.synth_clip(32000, 11)
+    x = torch.from_numpy(np.pad(w0, (0, 320)))[None]
+    ref = wavlm_ref.extract_layer(sd, cfg, x, 3)
+    enc = WavLMEncoder(sd, cfg, DEV, n_layers=3)
+    pl = enc.plan["layers"]
+    print("range plan:", pl, {k: (v if not isinstance(v, dict) else {a: round(b, 1) for a, b in v.items()})
+                              for k, v in enc.plan["bounds"].items() if k.startswith("layer")})
+    assert not pl[1]["h"] and not pl[0]["attn_f16"] and not pl[2]["xn"]
+    assert pl[0]["xn"] and pl[0]["h"] and pl[1]["xn2"] and pl[2]["h"] and pl[1]["attn_f16"]   # untouched tensors keep the split layout
+    out = enc.encode_batch(x.to(DEV))
+    assert bool(torch.isfinite(out).all())
+    rms, mx = _rel(out, ref)
+    print(f"WavLM-Large with outlier weights: rel rms {rms:.2e} max {mx:.2e}")
+    assert rms < 5e-6 and mx < 5e-5
+    # the seeded state itself plans "everything split" (the fast path is what the other tests and bench.py run)
+    enc0 = WavLMEncoder(base, cfg, DEV, n_layers=3)
+    assert all(all(v.values()) for v in enc0.plan["layers"]) and all(enc0.plan["conv"]) and enc0.plan["feats"]
+
+
+@pytest.mark.parametrize("gain", [400.0, 2e-4])
+def test_generator_with_large_and_tiny_activations(gain):
+    """Full-size 'mix' generator whose first conv is scaled so that the internal activations are ~10^3 x larger / 10^4 x
+    smaller than with the seeded weights; conv_post is scaled back so that tanh stays in its linear region."""
+    from knn_svc_amd.vocoder import Vocoder
+    from oracle import vocoder_ref
+    h = C.HIFIGAN_V1
+    base = S.seeded_state(S.generator_param_spec(h, "mix"), 2)
+    sd = _scaled_state(base, {"dec.conv_pre.weight": gain, "dec.conv_pre.bias": gain, "sin_prenet.weight": gain,
+                              "sin_prenet.bias": gain, "dec.conv_post.weight": 1.0 / gain})
+    g = torch.Generator().manual_seed(3)
+    N = 40
+    c = torch.randn(N, 1024, generator=g) * 3.0
+    _, f0 = S.synth_clip(N * 320, 5); f0 = torch.from_numpy(f0[:N].copy())
+    harm = torch.rand(N, 49, generator=g) * 0.02
+    ref = vocoder_ref.synthesizer(sd, h, "mix", c[None], f0[None, :, None], harm[None])[0, 0]
+    y = Vocoder(sd, h, "mix", DEV).forward(c.to(DEV), f0.to(DEV), harm.to(DEV))
+    assert bool(torch.isfinite(y).all())
+    rms = float((y.cpu() - ref).pow(2).mean().sqrt())
+    print(f"generator with conv_pre x {gain:g}: rms {rms:.2e} (ref rms {float(ref.pow(2).mean().sqrt()):.3f})")
+    assert rms < 5e-6                                                     # north_star bar: 1e-4 RMS
