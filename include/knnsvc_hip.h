@@ -163,8 +163,11 @@ int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* tab
  * Cosine-distance kNN (lib_ongaku_test.py:148-175 fast_cosine_dist + Tensor.topk(k, largest=False),
  * driver loop ddsp_prematch_dataset.py:1195-1210).
  * ------------------------------------------------------------------------------------------ */
-/* norm[r] = sqrt(sum x^2) (torch.norm, lib_ongaku_test.py:150-151); sq[r] = sum x^2 (cdist's own term) */
-int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, float* norm, float* sq, void* stream);
+/* norm[r] = sqrt(sum x^2) (torch.norm, lib_ongaku_test.py:150-151); sq[r] = sum x^2 (cdist's own term).
+ * max_slot (may be NULL): DEVICE float, folded with the largest row norm (atomicMax on the bit pattern; the caller
+ * zeroes it) — an upper bound of max|x| that costs no extra pass: the range slot the kNN's f16x2 GEMM scales by. */
+int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, float* norm, float* sq, float* max_slot,
+                     void* stream);
 
 size_t knnsvc_knn_workspace_bytes(int64_t nq, int64_t np, int32_t k);
 

@@ -51,7 +51,7 @@ SIGNATURES = {
     "knnsvc_wavlm_conv0": (i32, [vp, i32, i64, vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, i32, vp]),
-    "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp, vp]),
     "knnsvc_knn_workspace_bytes": (sz, [i64, i64, i32]),
     "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, i64, i64, vp, vp, vp, sz, vp, vp]),
     "knnsvc_knn_select": (i32, [vp, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i64, vp, vp, vp, vp]),

@@ -58,10 +58,12 @@ __device__ __forceinline__ void resolve_scales(ConvArgs& a) {
 
 // |v| as ordered bits: NaN sorts above inf, so a NaN anywhere in the output reaches the slot (fmaxf would drop it)
 __device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
+// One atomic per wave at most — and none when the slot already holds a larger value (a relaxed load first: tens of
+// thousands of same-address atomics per launch would serialise in L2; a stale smaller value only costs the atomic).
 __device__ __forceinline__ void publish_absmax(float* slot, unsigned m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax((unsigned*)slot, m);
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n((const unsigned*)slot, __ATOMIC_RELAXED)) atomicMax((unsigned*)slot, m);
 }
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void knn_merge_pairs_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ x, long rows, int dim, int ldx,
-                                                       float* __restrict__ norm, float* __restrict__ sq) {
+                                                       float* __restrict__ norm, float* __restrict__ sq, float* __restrict__ max_slot) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -357,8 +357,15 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
     for (int c = lane; c < dim; c += 64) { const double v = xr[c]; s += v * v; }
     s = wave_sum_d(s);
     if (lane == 0) {
+        const float nr = (float)sqrt(s);
         if (sq) sq[row] = (float)s;
-        if (norm) norm[row] = (float)sqrt(s);
+        if (norm) norm[row] = nr;
+        // range slot: max row norm >= max |x| (bit-pattern max: a NaN row makes the slot NaN); relaxed pre-check keeps
+        // the same-address atomics to the few rows that raise the maximum
+        if (max_slot) {
+            const unsigned b = __float_as_uint(nr) & 0x7FFFFFFFu;
+            if (b > __atomic_load_n((const unsigned*)max_slot, __ATOMIC_RELAXED)) atomicMax((unsigned*)max_slot, b);
+        }
     }
 }
 
@@ -377,11 +384,11 @@ int split_count(long nq, long np) {
 }  // namespace
 
 extern "C" int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, float* norm, float* sq,
-                                void* stream) {
+                                float* max_slot, void* stream) {
     KN_REQUIRE(x && rows >= 0 && dim > 0 && ldx >= dim, "row_norms: bad arguments");
     if (rows == 0) return KNNSVC_OK;
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       x, (long)rows, dim, ldx, norm, sq);
+                       x, (long)rows, dim, ldx, norm, sq, max_slot);
     return knnsvc_check_launch("row_norms");
 }
 

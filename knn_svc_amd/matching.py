@@ -190,7 +190,8 @@ def prepare_pool(matching_list, split=True):
     once per target pool in dataset mode instead of once per utterance.  ``split=False``: norms only (the neighbours
     come from the pool-sharded search)."""
     P = matching_list
-    return dict(stats=ops.row_norms(P), split=ops.prepare_knn_pool(P, C.KNN_K) if split else None)
+    stats = ops.row_norms(P)
+    return dict(stats=stats, split=ops.prepare_knn_pool(P, C.KNN_K, stats) if split else None)
 
 
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,

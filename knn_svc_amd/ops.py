@@ -156,6 +156,8 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.a_f16x2_scale = a_scale
     d.x_f16x2 = 1 if x_split else 0
     d.out_f16x2 = int(out_split) if (out_split is not True and out_split is not False) else (1 if out_split else 0)   # True / first split column
+    if not x_split and (x_absmax is not None or out_absmax is not None) and not range_slots_on():
+        x_absmax = out_absmax = None            # A/B aid: fixed activation scale 16 (a pre-split operand keeps its slot)
     d.x_absmax = x_absmax.data_ptr() if x_absmax is not None else None
     d.w_absmax = w_absmax.data_ptr() if w_absmax is not None else None
     d.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
@@ -168,6 +170,8 @@ def absmax(x2d, slot=None):
     """max |x| of a [rows, cols] view (row stride allowed) folded into ``slot`` (a zeroed one-element device tensor is
     made when None): the range slot a later conv_gemm takes as x_absmax / w_absmax.  NaN in x makes the slot NaN."""
     _need(x2d, name="absmax.x")
+    if not range_slots_on() and slot is not None:
+        return slot
     if slot is None:
         slot = torch.zeros(1, device=x2d.device, dtype=torch.float32)
     if x2d.dim() == 1:
@@ -267,13 +271,22 @@ def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_spl
 
 
 # ------------------------------------------------------------------ kNN
+def range_slots_on() -> bool:
+    """KNNSVC_RANGE_SLOTS=0 (A/B aid): f16x2 GEMMs fall back to the fixed activation scale 16 (|x| < 4094)."""
+    import os
+    return os.environ.get("KNNSVC_RANGE_SLOTS", "1") != "0"
+
+
 def row_norms(x2d):
-    """-> (norm [rows], sumsq [rows])"""
+    """-> (norm [rows], sumsq [rows]).  ``norm._slot``: one-element device tensor holding the largest row norm — an
+    upper bound of max|x| the kernel folds on the way (the kNN's range slot; no extra pass over the features)."""
     _need(x2d, name="row_norms.x")
     rows, dim = x2d.shape
     norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
     sq = torch.empty(rows, device=x2d.device, dtype=torch.float32)
-    check(_lib.load().knnsvc_row_norms(_p(x2d), rows, dim, x2d.stride(0), _p(norm), _p(sq), _stream()), "row_norms")
+    slot = torch.zeros(1, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_row_norms(_p(x2d), rows, dim, x2d.stride(0), _p(norm), _p(sq), _p(slot), _stream()), "row_norms")
+    norm._slot = slot
     return norm, sq
 
 
@@ -287,7 +300,7 @@ def knn_mode() -> str:
     return mode
 
 
-def prepare_knn_pool(pool, k=32):
+def prepare_knn_pool(pool, k=32, p_stats=None):
     """Pre-split image of a pool for the two-kernel kNN route, reusable across searches against the same pool
     (dataset mode and prematch search one pool once per utterance): list of (first row, rows view, f16x2 image, range
     slot).  The fp16 split needs a power-of-two pre-scale that fits the features' range; WavLM features have no a-priori
@@ -308,7 +321,9 @@ def prepare_knn_pool(pool, k=32):
         npc = pc.shape[0]
         if npc < k:
             raise KnnSvcError("knn_topk: pool chunk smaller than k")
-        slot = absmax(pc)
+        slot = getattr(p_stats[0], "_slot", None) if p_stats is not None else None      # bound of the whole pool: fine for a chunk
+        if slot is None:
+            slot = absmax(pc)
         p2 = torch.empty(npc * (dim // 32) * 64, device=pool.device, dtype=torch.int16)
         check(lib.knnsvc_split_f16x2_dyn(_p(pc), npc, dim, _p(slot), _p(p2), _stream()), "split_pool")
         chunks.append((p0, pc, p2, slot))
@@ -329,11 +344,13 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
     # every column tile of the GEMM stages them with plain copies instead of re-splitting them
     q2 = None
     import os
-    q_slot = absmax(q)
+    q_slot = getattr(qn, "_slot", None)
+    if q_slot is None:
+        q_slot = absmax(q)
     if nq >= 128 and os.environ.get("KNNSVC_KNN_A2", "1") != "0":
         q2 = torch.empty(nq, dim, device=dev, dtype=torch.float32)
         check(lib.knnsvc_split_f16x2_dyn(_p(q), nq, dim, _p(q_slot), _p(q2), _stream()), "split_queries")
-    for p0, pc, p2, p_slot in (prepared if prepared is not None else prepare_knn_pool(pool, k)):
+    for p0, pc, p2, p_slot in (prepared if prepared is not None else prepare_knn_pool(pool, k, (pn, ps))):
         npc = pc.shape[0]
         idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
         dist = torch.empty(nq, k, device=dev, dtype=torch.float32)

@@ -211,7 +211,7 @@ class WavLMEncoder:
         # producer (LayerNorm, the fused first conv, the GELU epilogue of FFN1, attention) splits every element once
         # and the GEMM stages its A operand with plain copies instead of re-splitting it in every column tile.
         a2 = ops.gemm_mode() == "f16x2" and os.environ.get("KNNSVC_A2", "1") != "0"
-        dyn = ops.gemm_mode() == "f16x2"                # fp32 GEMM inputs take their scale from a device range slot
+        dyn = ops.gemm_mode() == "f16x2" and ops.range_slots_on()   # fp32 GEMM inputs take their scale from a device range slot
         plan = self.plan
         sp = lambda dim, ok=True: a2 and ok and dim % 32 == 0      # a [*, dim] activation can be carried split
         slot_of = lambda t: ops.absmax(t) if dyn else None          # bound of a tensor no GEMM epilogue produced
