@@ -59,7 +59,10 @@ __global__ __launch_bounds__(320) void additive_synth_kernel(const float* __rest
             const float w = (float)(2.0 * 3.14159265358979323846 * (ph - rint(ph)));
             if (mode == 1) v = sinf(w);
             else {
-                const float rx = scale * ((float)t + 0.5f) - 0.5f;
+                // torch evaluates area_pixel_compute_source_index (scale * (dst + 0.5) - 0.5) with ONE rounding: its CPU
+                // and CUDA builds both contract the expression into an fma.  Two roundings move tx by up to an ulp of the
+                // frame index — 3e-5 at frame 512, 6e-5 at 1024 — and with it the cubic weights (2e-5 in the waveform).
+                const float rx = __builtin_fmaf(scale, (float)t + 0.5f, -0.5f);
                 const float fl = floorf(rx);
                 const float tx = rx - fl;
                 const long ix = (long)fl;

@@ -12,6 +12,12 @@ import torch
 import torch.nn.functional as F
 
 
+def _fp32(x: torch.Tensor) -> torch.Tensor:
+    """The reference's explicit ``.float()`` casts (Fp32LayerNorm, the fp32 GELU).  A float64 tensor passes through: the
+    tests evaluate this same oracle in fp64 (state dict and input cast to double) as the exact-arithmetic yardstick."""
+    return x if x.dtype == torch.float64 else x.float()
+
+
 def conv_layers_of(cfg):
     return list(eval(cfg["conv_feature_layers"]))
 
@@ -55,7 +61,7 @@ def feature_extractor(sd, cfg, wav: torch.Tensor) -> torch.Tensor:
     for i, (dim, k, s) in enumerate(conv_layers_of(cfg)):
         p = f"feature_extractor.conv_layers.{i}."
         x = F.conv1d(x, sd[p + "0.weight"], None, stride=s)
-        x = F.layer_norm(x.transpose(1, 2).float(), (dim,), sd[p + "2.1.weight"], sd[p + "2.1.bias"], 1e-5)
+        x = F.layer_norm(_fp32(x.transpose(1, 2)), (dim,), sd[p + "2.1.weight"], sd[p + "2.1.bias"], 1e-5)
         x = F.gelu(x.transpose(1, 2))
     return x
 
@@ -113,7 +119,7 @@ def encoder_layer(sd, cfg, l: int, x_tbe: torch.Tensor, pbias_htt: torch.Tensor)
     o = F.linear(o, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
     x = x_tbe + o
     xn = F.layer_norm(x, (E,), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], 1e-5)
-    hmid = F.gelu(F.linear(xn, sd[p + "fc1.weight"], sd[p + "fc1.bias"]).float())
+    hmid = F.gelu(_fp32(F.linear(xn, sd[p + "fc1.weight"], sd[p + "fc1.bias"])))
     return x + F.linear(hmid, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
 
 

@@ -41,7 +41,7 @@ def test_knn_full_size_properties(north_star_features):
     ref_i, ref_d = knn_ref.knn_topk(q[rows], p, 32)
     st = knn_ref.topk_agreement(ref_i, idx_c[rows], knn_ref.cosine_dist_f64(q[rows], p), tau=5e-7)
     print("full-size kNN, 32 sampled rows:", st)
-    assert st["unexplained"] == 0 and st["top4"] >= 0.9 and st["sets"] >= 0.9
+    assert st["unexplained"] == 0 and st["top4"] == 1.0 and st["sets"] == 1.0 and st["allk"] >= 0.96 and st["max_gap"] <= 5e-7
     assert float((dist_c[rows] - ref_d).abs().max()) < 5e-6
     # determinism: the same launch twice is bit-identical
     idx2, dist2 = ops.knn_topk(qd, pd, 32)
@@ -75,7 +75,7 @@ def test_match_full_size_against_oracle_pieces(north_star_features):
     sel2 = select_ref.concat_reselect(ranked[:300, :4].clone(), q[:300], p, sf0.cpu()[:300], pf0, concat_weight=0.2)
     match2 = float((dbg["idx_harm"].cpu()[:300] == sel2).all(1).float().mean())
     print(f"concat re-selection, first 300 of 1500 frames: plain {match:.3f}, pitched {match2:.3f}")
-    assert match >= 0.97 and match2 >= 0.97
+    assert match == 1.0 and match2 == 1.0
     for w, idx, pool, scale in ((dbg["w_wavlm"], dbg["idx_wavlm"], p, 0.1), (dbg["w_harm"], dbg["idx_harm"], harm, 1000.0)):
         w, idx = w.cpu(), idx.cpu()
         assert float((w.sum(1) - 1).abs().max()) < 1e-5 and float(w.min()) >= 0
@@ -173,7 +173,7 @@ def test_knn_multi_chunk_pool_and_mask_across_chunks():
     ref_i, ref_d = knn_ref.knn_topk(q[rows], p, 32)
     st = knn_ref.topk_agreement(ref_i, idx_c[rows], knn_ref.cosine_dist_f64(q[rows], p), tau=5e-7)
     print("300k-row pool, sampled rows:", st)
-    assert st["unexplained"] == 0 and float((dist_c[rows] - ref_d).abs().max()) < 5e-6
+    assert st["unexplained"] == 0 and st["top4"] == 1.0 and st["sets"] == 1.0 and float((dist_c[rows] - ref_d).abs().max()) < 5e-6
     # explicit shards at other boundaries give the same merged lists
     cuts = [0, 70_000, 200_000, np_rows]
     parts = [ops.knn_topk(qd, pd[a:b].contiguous(), 32, idx_offset=a) for a, b in zip(cuts[:-1], cuts[1:])]
@@ -218,7 +218,9 @@ def test_prematch_speaker_full_size_properties():
         assert float((w.sum(1) - 1).abs().max()) < 1e-5 and bool((w >= 0).all())
         rows = torch.arange(0, T, 211)
         ref = prematch_ref.self_knn(feats[s:e][rows], pool_h, s, e)
-        assert float((ref[:, :4] == nn[rows][:, :4]).float().mean()) > 0.95
-        assert float(np.mean([set(a.tolist()) == set(b.tolist()) for a, b in zip(ref, nn[rows])])) > 0.85
+        first4 = float((ref[:, :4] == nn[rows][:, :4]).all(1).float().mean())
+        sets = float(np.mean([set(a.tolist()) == set(b.tolist()) for a, b in zip(ref, nn[rows])]))
+        print(f"prematch speaker, utterance {i}: first-4 rows equal {first4:.3f}, top-32 sets equal {sets:.3f}")
+        assert first4 >= 0.99 and sets >= 0.95
         ra = prematch_ref.amp_ratio(spec[s:e][rows], spec, nnf[rows][:, :4])
         assert float(((ra - ar[rows]).abs() / ra).max()) < 2e-6

@@ -277,7 +277,9 @@ def test_knn_golden(golden):
     # index parity is defined up to the reference's own fp32 rounding gaps (SURVEY §7 hard part 1):
     # every disagreement must sit inside a gap <= tau of the exact distance
     assert st["unexplained"] == 0, st
-    assert st["top4"] >= 0.97 and st["sets"] >= 0.95, st
+    # ratcheted to the measured values (r02: top-4 100 %, ordered top-32 99.5 %, sets 100 %, largest inversion 1.7e-7):
+    # the first four neighbours — the ones the path uses — and the top-32 set are exactly the reference's
+    assert st["top4"] == 1.0 and st["sets"] == 1.0 and st["allk"] >= 0.99 and st["max_gap"] <= 2.5e-7, st
     assert float((dist - _t(g["dist"])).abs().max()) < 5e-6   # a few ulp of |q|^2+|p|^2 over |q||p|
     # internal consistency: sorted ascending, indices in range, no duplicates
     assert bool((dist[:, 1:] >= dist[:, :-1]).all())
@@ -345,7 +347,7 @@ def test_f0_shift_and_rerank(golden):
     rk = ops.f0_rerank(nn32, _t(g["shifted"]).to(DEV), pf0)
     match = float((rk.cpu() == _t(g["ranked"]).long()).all(dim=1).float().mean())
     print("f0 rerank exact-row match:", match)
-    assert match >= 0.98
+    assert match == 1.0
 
 
 def test_concat_reselect(golden):
@@ -360,7 +362,7 @@ def test_concat_reselect(golden):
     ma = float((a.cpu() == _t(g["sel_plain"]).long()).all(dim=1).float().mean())
     mb = float((b.cpu() == _t(g["sel_f0"]).long()).all(dim=1).float().mean())
     print("concat reselect exact-row match: plain", ma, "f0", mb)
-    assert ma >= 0.95 and mb >= 0.95
+    assert ma == 1.0 and mb == 1.0
 
 
 # ------------------------------------------------------------------ smoothness weights
@@ -374,12 +376,12 @@ def test_smooth_weights(golden):
     w, it = ops.smooth_weights(idx, p.to(DEV), 0.1, return_iters=True)
     e = _err(w, _t(g["w_wavlm"]))[0]
     print("wavlm weights max|d|", e, "iters", int(it), "ref", int(g["iters_wavlm"]))
-    assert e < 5e-3
+    assert e < 1e-3 and int(it) == int(g["iters_wavlm"])       # measured 2.8e-4; the reference's own trajectory moves by 2e-4
     assert abs(float(w.sum(1).mean()) - 1.0) < 1e-5
     wh, ith = ops.smooth_weights(idx, _t(g["harm_pool"]).to(DEV), 1000.0, return_iters=True)
     e = _err(wh, _t(g["w_harm"]))[0]
     print("harm weights max|d|", e, "iters", int(ith), "ref", int(g["iters_harm"]))
-    assert e < 5e-3
+    assert e < 1e-3 and int(ith) == int(g["iters_harm"])       # measured 1.9e-4
     # weighted gather
     out = ops.weighted_gather(idx, w, p.to(DEV))
     ref = (p[idx.cpu().reshape(-1)].reshape(-1, 4, 1024) * w.cpu()[..., None]).sum(1)

@@ -298,7 +298,7 @@ def test_prematch_files_match_reference(golden, tmp_path):
             if ok.all():
                 assert float(np.abs(w - g[f"{name}__u{i}__harmonics_best_weight_para"]).max()) < 5e-3
     print(f"prematch: {same}/{rows} frames with identical first-4 neighbours (plain and f0-priority)")
-    assert same >= 0.97 * rows
+    assert same == rows                       # measured: every frame (514 / 514)
 
 
 def test_bulk_match_pipelined_vocoder_equals_sequential(tmp_path, monkeypatch):
