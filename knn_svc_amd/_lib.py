@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libknnsvc_hip.so")
+LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
 ABI_VERSION = 8
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t

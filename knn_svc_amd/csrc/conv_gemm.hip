@@ -413,6 +413,94 @@ __device__ __forceinline__ void conv_epilogue_any(const ConvArgs& a, typename G:
     else conv_epilogue<G>(a, acc, m0, n0, b, g);
 }
 
+// Epilogue of the 128x128-wave-tile kernel (Gemm2Quad): 256 accumulator values per lane, one block per CU, nothing else on
+// the CU to hide it.  Two things made the column-per-lane epilogue (conv_epilogue_lin) as long as the K = 1024 main loop here:
+// 256 four-byte store instructions per wave, and — worse — CODE SIZE: bias / activation / residual arithmetic replicated for
+// 256 register-resident elements is ~350 KB of straight-line code that every wave runs through once per tile, i.e. the
+// epilogue ran at instruction-fetch speed (a build without any global store took exactly as long).  So:
+//   * each 32-row band of the wave tile goes through a wave-private LDS patch (the operand ring is idle by now): the only
+//     fully unrolled code is accumulator * scale -> ds_write (3 instructions per element);
+//   * a ROLLED loop then takes the band back, four consecutive columns of one row per lane and trip: bias, activation,
+//     residual / accumulate operands (16-byte loads), divide, range slot, 16-byte store (two 512-byte row segments per
+//     instruction) or the split layout — a few hundred instructions executed 64 times per wave instead of 40 000 once.
+// Needs n % 4 == 0, 16-byte aligned rows and a split boundary on a wave-tile column (multiple of 128).
+template <class G>
+__device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], float* lds_generic,
+                                                   int m0, int n0, int b, int g) {
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    constexpr int PITCH = G::TN * 32 + 4;                          // floats per patch row (+4: rows 4 apart land on other banks)
+    constexpr int TRIPS = (32 * G::TN * 32 / 4) / 64;              // float4 per lane and band
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    lds_f* patch = (lds_f*)lds_generic + wave * (32 * PITCH);
+    float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
+    const float* rz = a.resid ? a.resid + b * a.r_bstride + g * a.r_gstride : nullptr;
+    const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
+    const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, ((a.m - 1) * a.ldo + a.n) * 4);
+    const __amdgpu_buffer_rsrc_t r_rsrc = uniform_rsrc(rz ? (const void*)rz : (const void*)oz, rz ? ((a.m - 1) * a.ldr + a.n) * 4 : 0);
+    const int wrow0 = m0 + (wave / G::WN) * G::TM * 32, wcol0 = n0 + (wave % G::WN) * G::TN * 32;
+    // in the read-back loop a lane always owns the same four columns: (lane % 32) * 4 .. + 3 of the wave tile
+    const int c = (lane & (G::TN * 8 - 1)) * 4, n = wcol0 + c;
+    const int row_in_trip = lane / (G::TN * 8);                   // trip `it` covers rows it * (64 / (TN*8)) + this
+    const bool nv = n < a.n;                                       // n % 4 == 0 and a.n % 4 == 0: all four columns or none
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (bz && nv) {
+        if (a.bias_period) { for (int e = 0; e < 4; ++e) bias4[e] = bz[(n + e) % a.bias_period]; }
+        else bias4 = *(const f32x4*)(bz + n);
+    }
+    const bool sp = a.out_split && wcol0 >= a.split_from;          // wave-uniform (split_from is a multiple of the wave tile width)
+    const int act = a.act;
+    unsigned amax = 0;
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + li] = acc[i][j][r] * a.out_scale;   // power of two: exact
+        // the patch is private to this wave and LDS operations of one wave complete in order: no barrier
+#pragma unroll 1
+        for (int it = 0; it < TRIPS; ++it) {
+            const int row = it * (64 / (G::TN * 8)) + row_in_trip;
+            f32x4 v = *(const lds_f4*)(patch + row * PITCH + c) + bias4;
+            if (act == KNNSVC_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            } else if (act == KNNSVC_ACT_LRELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.act_slope);
+            } else if (act == KNNSVC_ACT_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+            }
+            const int m = wrow0 + i * 32 + row;
+            if (sp) {       // f16x2 split layout: (row, n) -> hi at (n/32)*128 + (n%32)*2, lo 64 bytes further
+                g2_u32x2 hi, lo;
+                f16x2_split4(v, a.split_scale, hi, lo);
+                const int off = nv ? m * a.ldo * 4 + (n >> 5) * 128 + (n & 31) * 2 : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(hi, o_rsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(lo, o_rsrc, off == OOB ? OOB : off + 64, 0, 0);
+                continue;
+            }
+            const int off = nv ? (m * a.ldo + n) * 4 : OOB;
+            if (rz) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, nv ? (m * a.ldr + n) * 4 : OOB, 0, 0));
+            if (a.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, off, 0, 0));
+            if (a.div != 1.0f) v = v / a.div;
+            if (a.out_absmax) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const unsigned ab = abs_bits(v[e]); amax = ab > amax ? ab : amax; }
+            }
+#ifdef KN_T_NOSTORE       // timing aid: everything but the global store
+            if (v[0] == 123456.789f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, off, 0, 0);
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, off, 0, 0);
+#endif
+        }
+    }
+    if (a.out_absmax) publish_absmax(a.out_absmax, amax);
+}
+
 template <class G, int VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -650,7 +738,18 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm2ring_kernel(ConvArgs a) {
     };
     G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
                 a.n, a.K, m0, n0, acc);
+#ifdef KN_T_NOEPI          // timing aid: main loop only (one store per lane keeps the accumulators live)
+    { float sink = 0.f;
+#pragma unroll
+      for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
+      if (sink == 123456.789f) a.out[threadIdx.x] = sink; }
+#else
     conv_epilogue_lin<G>(a, acc, m0, n0, b, g);
+#endif
 }
 
 template <class G, int MINB>
@@ -666,6 +765,80 @@ int launch2ring(const ConvArgs& a, int batches, hipStream_t st) {
     dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm2ring_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2ring");
+}
+
+// A2 activations + split weights by LDS-DMA, 256x256 block / 128x128 wave tiles, hand-pipelined loop (gemm2_core.h, Gemm2Quad)
+template <class G>
+__global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_scales(a);
+    const int z = blockIdx.z;
+    const int b = z / a.groups, g = z - b * a.groups;
+    // XCD-aware order: ids congruent mod 8 share an L2; an XCD's 32 resident blocks form a (8 row tiles x 4 column tiles)
+    // patch: A panels re-read by 4, weight panels by 8 blocks out of that L2
+    const int gy = (a.n + G::BN - 1) / G::BN;
+    const int gx8 = (int)gridDim.x / gy;
+    constexpr int CW = 4;
+    int L = blockIdx.x;
+    const int full = (gy / CW) * CW * gx8;
+    int c0, cw;
+    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
+    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
+    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
+    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
+    if (m0 >= a.m) return;
+    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
+    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
+    auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
+    int c_in_tap = 0, uoff = 0;
+    const int cin = a.cin, step_tap = (a.dil * a.ldx - a.cin) * 4;
+    auto step = [&](int kt) -> int {
+        if (kt > 0) { c_in_tap += 32; uoff += 128; if (c_in_tap == cin) { c_in_tap = 0; uoff += step_tap; } }
+        return uoff;
+    };
+    G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
+                a.n, a.K, m0, n0, acc);
+#ifdef KN_T_NOEPI
+    { float sink = 0.f;
+#pragma unroll
+      for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
+      if (sink == 123456.789f) a.out[threadIdx.x] = sink; }
+#else
+#ifdef KN_T_LINEPI         // timing aid: the column-per-lane epilogue instead of the LDS-transposed one
+    conv_epilogue_lin<G>(a, acc, m0, n0, b, g);
+#else
+    __syncthreads();                                  // every wave is done with the ring: its stages become the epilogue patches
+    conv_epilogue_wide<G>(a, acc, lds, m0, n0, b, g);
+#endif
+#endif
+}
+
+template <class G>
+int launch2quad(const ConvArgs& a, int batches, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm2quad_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
+    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2quad_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return knnsvc_check_launch("conv_gemm2quad");
 }
 
 template <class G, bool A2>
@@ -809,6 +982,9 @@ using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
 using D128 = Gemm2Dma<128, 128, 2, 2, 2, 2>;
 using R128 = Gemm2Ring<128, 128, 2, 2, 2, 2>;
 using R128x2 = Gemm2Ring<128, 128, 2, 2, 2, 2, 2>;
+using Q256 = Gemm2QuadR;          // register-staged (default)
+using Q256D = Gemm2Quad<4>;        // LDS-DMA ring (KNNSVC_QUAD_DMA=1, A/B)
+using R512 = Gemm2Ring<256, 256, 2, 2, 4, 4, 3>;       // 128x128 wave tiles, 256 accumulator registers, one block per CU
 using R256 = Gemm2Ring<256, 128, 2, 2, 4, 2, 3>;       // 128x64 wave tiles, 72 KB ring: two blocks per CU     // 2-stage ring: 32 KB, four blocks per CU
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
 using W128S = Gemm2Win<64, 128, 2, 2, 1, 2, 64>;      // short time axes (first generator stage): twice the blocks, 37 KB
@@ -917,6 +1093,21 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
                 { g_last_kernel = "F256"; return launch2big<F256>(a, d->batches, st); }
         }
+        if (a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
+            (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
+            d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
+            d->bias_gstride % 4 == 0) {
+            // 256x256 block, 128x128 wave tiles, hand-pipelined DMA ring (Gemm2Quad): KNNSVC_QUAD=0 switches it off, =2 forces
+            // it for every qualifying launch; by default it takes launches with at least two full rounds of tiles over the chip
+            const char* qe = getenv("KNNSVC_QUAD");      // read per launch: tests and A/B runs switch it inside one process
+            const int quad = qe ? atoi(qe) : 1;
+            const long tiles = cdiv64(a.m, 256) * cdiv64(d->n, 256) * d->batches * d->groups;
+            if (quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448)) {
+                const char* qd = getenv("KNNSVC_QUAD_DMA");
+                if (qd && qd[0] == '1') { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
+                g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st);
+            }
+        }
         if (d->n > 64 && a.x_split) {
             // Opt-in (KNNSVC_DMA=1): both operands by LDS-DMA, double-buffered, 2 blocks/CU.  Measured 252 vs 275 TFLOP/s
             // for the register-staged A2 kernel on FFN1: with one slab of prefetch the vmcnt(0) + barrier at the end
@@ -928,6 +1119,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             if (r && r[0] == '1') { g_last_kernel = "R128"; return launch2ring<R128, 3>(a, d->batches, st); }
             if (r && r[0] == '2') { g_last_kernel = "R128x2"; return launch2ring<R128x2, 4>(a, d->batches, st); }
             if (r && r[0] == '3') { g_last_kernel = "R256"; return launch2ring<R256, 2>(a, d->batches, st); }
+            if (r && r[0] == '4') { g_last_kernel = "R512"; return launch2ring<R512, 1>(a, d->batches, st); }
 
         }
         // stride-1 multi-tap convolutions on fp32 input: windowed kernel (A staged once per channel slab, not once per tap)

@@ -618,6 +618,308 @@ struct Gemm2Ring {
 };
 
 // -------------------------------------------------------------------------------------------------
+// Quad variant (round 2): 256x256 block, FOUR waves, 128x128 wave tiles (16 accumulator tiles = 256 AGPRs per lane, one
+// wave per SIMD, one block per CU), both operands by LDS-DMA through a ring of four half-slab stages (16 k = 64 bytes per
+// operand row, 32 KB per stage) — and a main loop that is software-pipelined BY HAND, because with one wave per SIMD
+// nothing else hides a stall.  Why this shape: per MFMA a 128x128 wave tile reads a third of the LDS bytes of the 64x64
+// wave tiles of Gemm2Tile (8 fragment pairs feed 48 MFMAs) and a 256x256 block stages a quarter of the bytes per MFMA —
+// at 128x128 the LDS array was ~85 % busy (writes at ~83 B/clk cost more than the reads), which is what held that loop at
+// ~57 % matrix-pipe utilisation whatever fed it.  The first cut of this tile (Gemm2Ring<256,256,...>: all DMA pieces, then
+// all fragment reads, then 48 MFMAs) ran serialised — 2700 instead of 1536 cycles per half slab.  Here, per half slab h:
+//   tile step t = 0..15 (three MFMAs each);
+//   behind steps 0..7: one DMA piece each of half slab h+3 (its ~100-cycle issue hides under the MFMAs just queued);
+//   after step 7: vmcnt wait for this wave's pieces of h+1 + ONE barrier;
+//   behind steps 8..15: the 16 fragment reads of half slab h+1 into the OTHER fragment register set (two per step).
+// so the next half slab starts on MFMAs at once.  Image, swizzle and DMA piece mapping as Gemm2Ring.
+// -------------------------------------------------------------------------------------------------
+template <int STAGES_ = 4>
+struct Gemm2Quad {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;
+    static constexpr int BM = 256, BN = 256, WM = 2, WN = 2, TM = 4, TN = 4, STAGES = STAGES_;
+    static constexpr int BK = 16, ROW = 64, NW = 4, THREADS = 256;
+    static constexpr int A_DMA = BM * ROW / 1024 / NW;         // 4 LDS-DMA instructions per wave per half slab
+    static constexpr int B_DMA = BN * ROW / 1024 / NW;         // 4
+    static constexpr int PER = A_DMA + B_DMA;                  // 8: one behind each of the first eight tile steps
+    static_assert(PER == 8 && STAGES == 4, "schedule below is written for 8 pieces and a 4-stage ring");
+    static constexpr int BOFF = BM * ROW;
+    static constexpr int STAGE = (BM + BN) * ROW;
+    static constexpr int LDS_BYTES = STAGES * STAGE;           // 128 KB
+    static constexpr int OOB_OFF = 0x40000000;
+
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) void lds_v;
+    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
+
+    template <class RowOff, class Step, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
+                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 31, lh = lane >> 5;
+        const int swz = (li >> 2) & 3;
+        const int a_row = (wm * TM * 32 + li) * ROW;
+        const int b_row = BOFF + (wn * TN * 32 + li) * ROW;
+        int x_off[2];                                              // [plane]: swizzled slot of this lane's k-half
+#pragma unroll
+        for (int p = 0; p < 2; ++p) x_off[p] = ((p * 2 + lh) ^ swz) * 16;
+        int a_src[A_DMA], b_src[B_DMA];
+        const int row_bytes = (K / 32) * 128;
+#pragma unroll
+        for (int t = 0; t < A_DMA; ++t) {
+            const int row = (wave * A_DMA + t) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((row >> 2) & 3);
+            const int ro = a_row_off(m0 + row);
+            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (q >> 1) * 64 + (q & 1) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < B_DMA; ++t) {
+            const int row = (wave * B_DMA + t) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((row >> 2) & 3);
+            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (q >> 1) * 64 + (q & 1) * 16 : OOB_OFF;
+        }
+        const int ns = 2 * nk;
+        int u_cur = 0, issued = 0;                                 // A byte offset of the 32-channel slab being issued; half slabs issued
+        int ua = 0, ub = 0;                                        // per-half-slab uniform offsets of the piece being issued
+        // one DMA piece (T = 0..3: A rows, 4..7: weight rows) of the half slab `issued`, into ring slot `issued % 4`
+#define KN_Q_BEGIN() { if ((issued & 1) == 0) u_cur = a_step(issued >> 1); ua = u_cur + (issued & 1) * 32; ub = (issued >> 1) * 128 + (issued & 1) * 32; }
+#define KN_Q_PIECE(T)                                                                                                     \
+    {                                                                                                                     \
+        const int stg = (issued & 3) * STAGE;                                                                             \
+        if ((T) < A_DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_desc, (lds_v*)(lds + stg + (wave * A_DMA + ((T) & 3)) * 1024), 16, a_src[(T) & 3] + ua, 0, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + stg + BOFF + (wave * B_DMA + ((T) & 3)) * 1024), 16, b_src[(T) & 3], ub, 0, 0); \
+    }
+        f16x8 fa[2][TM][2], fb[2][TN][2];                          // [register set][tile][plane]
+#define KN_Q_READ_A(SET, STG, I) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fa[SET][I][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + a_row + (I) * 32 * ROW + x_off[p])); }
+#define KN_Q_READ_B(SET, STG, J) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fb[SET][J][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + b_row + (J) * 32 * ROW + x_off[p])); }
+#define KN_Q_MFMA(SET, I, J)                                                                                              \
+    {                                                                                                                     \
+        f32x16 c = acc[I][J];                                                                                             \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][1], fb[SET][J][0], c, 0, 0, 0);   /* small terms first */    \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][1], c, 0, 0, 0);                             \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][0], c, 0, 0, 0);                             \
+        acc[I][J] = c;                                                                                                    \
+    }
+        // prologue: half slabs 0, 1, 2 in flight; 0 landed and read into register set 0
+#pragma unroll
+        for (int pre = 0; pre < 3; ++pre)
+            if (pre < ns) {
+                KN_Q_BEGIN()
+#pragma unroll
+                for (int t = 0; t < PER; ++t) KN_Q_PIECE(t)
+                ++issued;
+            }
+        if (ns > 2) __builtin_amdgcn_s_waitcnt(0x4F70);            // vmcnt(16): all but the two youngest half slabs
+        else if (ns > 1) __builtin_amdgcn_s_waitcnt(0x0F78);       // vmcnt(8)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) KN_Q_READ_A(0, 0, i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) KN_Q_READ_B(0, 0, j)
+
+        // one half slab on register set SET; the next one's fragments go to set SET ^ 1
+#define KN_Q_HALF(SET, H)                                                                                                 \
+    {                                                                                                                     \
+        const bool more_dma = issued < ns;            /* half slab H + 3 exists */                                        \
+        const bool more_rd = (H) + 1 < ns;                                                                                \
+        const int nstg = (((H) + 1) & 3) * STAGE;                                                                         \
+        if (more_dma) KN_Q_BEGIN()                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                                                  \
+            KN_Q_MFMA(SET, t >> 2, t & 3)                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            if (t < 8) {                                                                                                  \
+                if (more_dma) KN_Q_PIECE(t)                                                                               \
+                if (t == 7) {                                                                                             \
+                    if (more_dma) ++issued;                                                                               \
+                    /* this wave's pieces of half slab H + 1 have landed: everything but the younger half slabs */       \
+                    if ((H) + 3 < ns) __builtin_amdgcn_s_waitcnt(0x4070);          /* vmcnt(16), lgkmcnt(0) */            \
+                    else if ((H) + 2 < ns) __builtin_amdgcn_s_waitcnt(0x0078);     /* vmcnt(8),  lgkmcnt(0) */            \
+                    else __builtin_amdgcn_s_waitcnt(0x0070);                       /* vmcnt(0),  lgkmcnt(0) */            \
+                    __builtin_amdgcn_s_barrier();                                                                         \
+                }                                                                                                         \
+            } else if (more_rd) {                                                                                         \
+                const int u = t - 8;                  /* two fragment pairs of H + 1 per step: A0..3 then B0..3 */        \
+                if (u < 4) KN_Q_READ_A(SET ^ 1, nstg, u)                                                                  \
+                else KN_Q_READ_B(SET ^ 1, nstg, u - 4)                                                                    \
+            }                                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+        }                                                                                                                 \
+    }
+        for (int h = 0; h < ns; h += 2) {             // ns = 2 nk is even: two half slabs per trip, register sets 0 and 1
+            KN_Q_HALF(0, h)
+            KN_Q_HALF(1, h + 1)
+        }
+#undef KN_Q_HALF
+#undef KN_Q_MFMA
+#undef KN_Q_READ_A
+#undef KN_Q_READ_B
+#undef KN_Q_PIECE
+#undef KN_Q_BEGIN
+    }
+
+    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
+        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
+        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
+    }
+};
+
+// -------------------------------------------------------------------------------------------------
+// Quad variant, register-staged (the default of the two).  PMC view of the DMA-fed loop above (main loop only, FFN2):
+// matrix pipe 64 % busy, waves 45 % in issue stalls — an LDS-DMA instruction costs its wave 100-185 cycles of ISSUE
+// time (MI355X_MICROARCH.md, cycle constants), 8 pieces per half slab = ~1200 cycles against 384 for the 48 MFMAs, and
+// with one wave per SIMD nothing issues MFMAs meanwhile.  A plain 16-byte buffer load + ds_write_b128 pair issues in a
+// fraction of that, so here the operands travel global -> 8 x 4 staging VGPRs -> LDS, one piece behind each of the
+// first eight tile steps:
+//   step t < 8 : 3 MFMAs | ds_write piece t of half slab h+1 (loaded during the previous half slab) | load piece t of h+2
+//   after t = 7: lgkmcnt(0) + ONE barrier
+//   step t >= 8: 3 MFMAs | two fragment reads of h+1 into the other register set
+// The loads of a half slab have a whole half slab (~1500+ cycles) to land; the compiler's own vmcnt bookkeeping orders
+// each ds_write behind its load.  TWO stages of 32 KB suffice: h+1 is written into the stage h-1 was read from, and
+// those reads finished before the previous barrier.  Same image / swizzle / piece mapping as Gemm2Ring (a piece is what
+// one DMA instruction would move: lane L owns bytes 16 L .. 16 L + 15 of a 1 KiB run; the swizzle sits in the source offset).
+// -------------------------------------------------------------------------------------------------
+struct Gemm2QuadR {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;
+    static constexpr int BM = 256, BN = 256, WM = 2, WN = 2, TM = 4, TN = 4;
+    static constexpr int BK = 16, ROW = 64, NW = 4, THREADS = 256;
+    static constexpr int A_P = BM * ROW / 1024 / NW, B_P = BN * ROW / 1024 / NW, PER = A_P + B_P;      // 4 + 4 pieces per wave
+    static_assert(PER == 8, "schedule below is written for 8 pieces");
+    static constexpr int BOFF = BM * ROW;
+    static constexpr int STAGE = (BM + BN) * ROW;
+    static constexpr int EPI_BYTES = NW * 32 * (TN * 32 + 4) * 4;             // conv_epilogue_wide's per-wave patches
+    static constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    static constexpr int OOB_OFF = 0x40000000;
+
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
+
+    template <class RowOff, class Step, class RA, class RB>
+    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
+                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 31, lh = lane >> 5;
+        const int swz = (li >> 2) & 3;
+        const int a_row = (wm * TM * 32 + li) * ROW;
+        const int b_row = BOFF + (wn * TN * 32 + li) * ROW;
+        int x_off[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) x_off[p] = ((p * 2 + lh) ^ swz) * 16;
+        int a_src[A_P], b_src[B_P];
+        const int row_bytes = (K / 32) * 128;
+#pragma unroll
+        for (int t = 0; t < A_P; ++t) {
+            const int row = (wave * A_P + t) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((row >> 2) & 3);
+            const int ro = a_row_off(m0 + row);
+            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (q >> 1) * 64 + (q & 1) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < B_P; ++t) {
+            const int row = (wave * B_P + t) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((row >> 2) & 3);
+            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (q >> 1) * 64 + (q & 1) * 16 : OOB_OFF;
+        }
+        const int st_dst = wave * 4 * 1024 + lane * 16;            // this lane's byte inside piece 0 of its wave (A or B region)
+        const int ns = 2 * nk;
+        int u_cur = 0, issued = 0, ua = 0, ub = 0;
+        g2_u32x4 st[PER];                                          // staging registers: one half slab in flight
+#define KN_R_BEGIN() { if ((issued & 1) == 0) u_cur = a_step(issued >> 1); ua = u_cur + (issued & 1) * 32; ub = (issued >> 1) * 128 + (issued & 1) * 32; }
+#define KN_R_LOAD(T)                                                                                                      \
+    {                                                                                                                     \
+        if ((T) < A_P) st[T] = __builtin_amdgcn_raw_buffer_load_b128(ra_desc, a_src[(T) & 3] + ua, 0, 0);                 \
+        else st[T] = __builtin_amdgcn_raw_buffer_load_b128(rb_desc, b_src[(T) & 3], ub, 0);                               \
+    }
+#define KN_R_WRITE(T, STG) { *(lds_u4*)(lds + (STG) + ((T) < A_P ? 0 : BOFF) + st_dst + ((T) & 3) * 1024) = st[T]; }
+        f16x8 fa[2][TM][2], fb[2][TN][2];
+#define KN_R_READ_A(SET, STG, I) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fa[SET][I][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + a_row + (I) * 32 * ROW + x_off[p])); }
+#define KN_R_READ_B(SET, STG, J) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fb[SET][J][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + b_row + (J) * 32 * ROW + x_off[p])); }
+#define KN_R_MFMA(SET, I, J)                                                                                              \
+    {                                                                                                                     \
+        f32x16 c = acc[I][J];                                                                                             \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][1], fb[SET][J][0], c, 0, 0, 0);   /* small terms first */    \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][1], c, 0, 0, 0);                             \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][0], c, 0, 0, 0);                             \
+        acc[I][J] = c;                                                                                                    \
+    }
+        // prologue: half slab 0 -> stage 0, half slab 1 in flight in the staging registers, fragments of 0 in set 0
+        KN_R_BEGIN()
+#pragma unroll
+        for (int t = 0; t < PER; ++t) KN_R_LOAD(t)
+        ++issued;
+#pragma unroll
+        for (int t = 0; t < PER; ++t) KN_R_WRITE(t, 0)
+        if (ns > 1) {
+            KN_R_BEGIN()
+#pragma unroll
+            for (int t = 0; t < PER; ++t) KN_R_LOAD(t)
+            ++issued;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): this wave's writes are in LDS (vmcnt untouched)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) KN_R_READ_A(0, 0, i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) KN_R_READ_B(0, 0, j)
+
+        // HN: half slab H + 1 exists (its pieces sit in the staging registers); ML: half slab H + 2 exists (load it).  Both are
+        // LITERALS at every use: a run-time test here would put each step into its own basic block, and the compiler's
+        // waitcnt bookkeeping then falls back to vmcnt(0) before every ds_write — a full memory latency per step (measured:
+        // 203 instead of 360 TFLOP/s).  The steady state is one straight-line block per half slab.
+#define KN_R_HALF(SET, H, HN, ML)                                                                                         \
+    {                                                                                                                     \
+        const int nstg = (((H) + 1) & 1) * STAGE;                                                                         \
+        if (ML) KN_R_BEGIN()                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                                                  \
+            KN_R_MFMA(SET, t >> 2, t & 3)                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            if (t < 8) {                                                                                                  \
+                if (HN) KN_R_WRITE(t, nstg)                                                                               \
+                if (ML) KN_R_LOAD(t)                                                                                      \
+                if (t == 7) {                                                                                             \
+                    if (ML) ++issued;                                                                                     \
+                    __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): writes of H + 1 done, old fragment reads done */ \
+                    __builtin_amdgcn_s_barrier();                                                                         \
+                }                                                                                                         \
+            } else if (HN) {                                                                                              \
+                const int u = t - 8;                                                                                      \
+                if (u < 4) KN_R_READ_A(SET ^ 1, nstg, u)                                                                  \
+                else KN_R_READ_B(SET ^ 1, nstg, u - 4)                                                                    \
+            }                                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+        }                                                                                                                 \
+    }
+        int h = 0;
+        for (; h + 3 < ns; h += 2) {                  // steady state: both successors exist for both halves of the pair
+            KN_R_HALF(0, h, true, true)
+            KN_R_HALF(1, h + 1, true, true)
+        }
+        KN_R_HALF(0, h, true, false)                  // last pair (ns is even): ns - 2 still has a successor, nothing left to load
+        KN_R_HALF(1, h + 1, false, false)
+#undef KN_R_HALF
+#undef KN_R_MFMA
+#undef KN_R_READ_A
+#undef KN_R_READ_B
+#undef KN_R_WRITE
+#undef KN_R_LOAD
+#undef KN_R_BEGIN
+    }
+
+    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
+        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
+        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
+    }
+};
+
+// -------------------------------------------------------------------------------------------------
 // Windowed variant for stride-1 convolutions with several taps (HiFi-GAN ResBlock convs k = 3/7/11 with dilation,
 // WavLM's k = 128 positional conv).  The implicit-GEMM kernels above walk K tap-major and re-stage, for every tap, the
 // same input rows shifted by `dil` (a what-if build without A staging ran the generator in 7.6 instead of 10.0 ms).

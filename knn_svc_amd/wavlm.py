@@ -232,6 +232,9 @@ class WavLMEncoder:
             x, t_in, cin = y, t_out, c["dim"]
         T = t_in
         assert not x_sp
+        tap = getattr(self, "_tap", None)               # debugging aid (tools/layer_error.py): intermediate activations
+        if tap is not None:
+            tap["conv"] = x.clone()
         f_sp = sp(cin, plan["feats"])
         feats = ops.layernorm(x, self.ln_g, self.ln_b, out_split=f_sp)
         x_slot = torch.zeros(1, device=dev, dtype=torch.float32) if dyn else None
@@ -239,6 +242,8 @@ class WavLMEncoder:
                        out_absmax=x_slot)             # [B*T, E]
         E, H, G, K = self.E, self.H, self.G, self.Kpos
         cg = E // G
+        if tap is not None:
+            tap["proj"] = x.clone()
         x2 = torch.empty_like(x)
         ops.conv_gemm(x, self.pos_w, x2, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T, ldx=E, ldo=E,
                       bias=self.pos_b, act=ops.ACT_GELU, resid=x, ldr=E, batches=B, groups=G,

@@ -110,6 +110,74 @@ def test_linear_f16x2_big_tile(monkeypatch):
     assert float((o128 - o).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(2048 + 77, 1024, 1024), (700, 2048, 520), (256, 32, 256), (31, 4096, 1028)])
+def test_linear_quad_kernel(M, K, N, monkeypatch):
+    """conv_gemm2quad_kernel (256x256 block, 128x128 wave tiles, hand-pipelined 4-stage DMA ring, LDS-transposed
+    16-byte epilogue): ragged M and N tails, 1 / 32 / 64 / 128 slabs, every epilogue operand — bias, GELU, residual,
+    accumulate, divide, range slot, split-layout output — against fp64 and against the 128x128 kernel."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    wd = ops.attach_split(w.to(DEV))
+    if not hasattr(wd, "_w2"):
+        pytest.skip("KNNSVC_GEMM is not f16x2")
+    xs = ops.split_pack(x.to(DEV))
+    ref = x.double() @ w.double().T + b.double()
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("KNNSVC_QUAD", mode)
+        o = ops.linear(xs, wd, b.to(DEV), x_split=True)
+        assert ops.last_conv_kernel() == ("Q256" if mode == "2" else ("F128a2" if M * N >= 256 * 128 * 128 else ops.last_conv_kernel()))
+        outs[mode] = o.cpu()
+        e = float((o.cpu().double() - ref).abs().max())
+        assert e < 3e-5 * max(1.0, (K / 1024) ** 0.5), (mode, e)
+        # GELU + range slot
+        slot = torch.zeros(1, device=DEV)
+        og = ops.linear(xs, wd, b.to(DEV), act=ops.ACT_GELU, x_split=True, out_absmax=slot)
+        rg = torch.nn.functional.gelu(ref)
+        assert float((og.cpu().double() - rg).abs().max()) < 3e-5 * max(1.0, (K / 1024) ** 0.5)
+        assert float(og.abs().max()) <= float(slot) <= float(og.abs().max()) * 1.0001 + float(torch.nn.functional.gelu(b).abs().max())
+        # residual, then accumulate + divide on top of an existing output
+        orr = ops.linear(xs, wd, b.to(DEV), resid=r.to(DEV), x_split=True)
+        assert float((orr.cpu().double() - (ref + r.double())).abs().max()) < 4e-5 * max(1.0, (K / 1024) ** 0.5)
+        acc = r.to(DEV).clone()
+        ops.conv_gemm(xs, wd, acc, m=M, n=N, cin=K, bias=b.to(DEV), accumulate=True, div=3.0, x_split=True)
+        assert float((acc.cpu().double() - (ref + r.double()) / 3.0).abs().max()) < 2e-5 * max(1.0, (K / 1024) ** 0.5)
+        if N % 32 == 0:     # split-layout output (whole, and from column 32 on)
+            osp = ops.linear(xs, wd, b.to(DEV), x_split=True, out_split=True)
+            assert float((ops.split_unpack(osp).cpu().double() - ref).abs().max()) < 3e-5 * max(1.0, (K / 1024) ** 0.5)
+            oh = ops.linear(xs, wd, b.to(DEV), x_split=True, out_split=32).cpu()
+            assert float((oh[:, :32].double() - ref[:, :32]).abs().max()) < 3e-5
+            assert float((ops.split_unpack(oh[:, 32:].contiguous().to(DEV)).cpu().double() - ref[:, 32:]).abs().max()) < 3e-5 * max(1.0, (K / 1024) ** 0.5)
+    # same products, same order along K inside a tile row: the two kernels agree to fp32 accumulation noise
+    assert float((outs["2"] - outs["0"]).abs().max()) < 2e-5 * max(1.0, (K / 1024) ** 0.5)
+
+
+def test_conv_quad_kernel_taps_stride_batches(monkeypatch):
+    """The quad kernel on a strided 3-tap convolution over a batch of sequences (WavLM's conv stack shape: A2 input,
+    stride 2, per-batch strides) and with conv padding rows, against the 128x128 kernel."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(19)
+    B, T, Cin, Cout, k, st = 3, 2001, 256, 512, 3, 2
+    x = torch.randn(B * T, Cin, generator=g)
+    w = ops.attach_split(ops.pack_conv_weight(torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5).to(DEV))
+    xs = ops.split_pack(x.to(DEV))
+    t_out = (T - k) // st + 1
+    res = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("KNNSVC_QUAD", mode)
+        y = torch.empty(B * t_out, Cout, device=DEV)
+        ops.conv_gemm(xs, w, y, m=t_out, n=Cout, cin=Cin, taps=k, stride=st, t_in=T, batches=B, x_bstride=T * Cin, o_bstride=t_out * Cout, x_split=True)
+        yp = torch.empty(B * T, Cout, device=DEV)
+        ops.conv_gemm(xs, w, yp, m=T, n=Cout, cin=Cin, taps=k, stride=1, pad=1, t_in=T, batches=B, x_bstride=T * Cin, o_bstride=T * Cout, x_split=True)
+        res[mode] = (y.cpu(), yp.cpu(), ops.last_conv_kernel())
+    assert res["2"][2] == "Q256"
+    ref = torch.nn.functional.conv1d(x.view(B, T, Cin).transpose(1, 2).double(), w.cpu().view(Cout, k, Cin).permute(0, 2, 1).double(), stride=st)
+    assert float((res["2"][0].view(B, t_out, Cout).transpose(1, 2).double() - ref).abs().max()) < 2e-5
+    assert float((res["2"][0] - res["0"][0]).abs().max()) < 2e-5 and float((res["2"][1] - res["0"][1]).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("xs,ws,a_scale", [(1e-3, 1e-4, 4096.0), (30.0, 5.0, 0.0), (0.05, 40.0, 0.0)])
 def test_linear_f16x2_scales(xs, ws, a_scale, monkeypatch):
     """The power-of-two operand scaling keeps small activations / odd weight magnitudes at fp32 accuracy,
