@@ -54,8 +54,12 @@ class GemmTimer:
         self.records = []
         self.enabled = False
         self.all_variants = False
-        # both instantiations of conv_gemm2_kernel<Gemm2Tile<128,128,...>> (A fp32 / A pre-split) count as the dominant kernel
-        self.dominant = {"f16x2": ("F128", "F128a2"), "bf16x3": ("H128",), "fp32": ("G128v8",)}[ops.gemm_mode()]
+        # candidates for "the dominant kernel": both instantiations of conv_gemm2_kernel<Gemm2Tile<128,128,...>> (A fp32 / A
+        # pre-split) count as one kernel, conv_gemm2quad_kernel<Gemm2QuadR> (long-K launches) as another; summary() reports the
+        # one with more time in the step and carries the other along as `secondary`
+        self.families = {"f16x2": (("F128", "F128a2"), ("Q256",)), "bf16x3": (("H128",),), "fp32": (("G128v8",),)}[ops.gemm_mode()]
+        self.dominant = tuple(t for fam in self.families for t in fam)
+        self.fam_bytes = {}
         self.dom_bytes = 0
         self._orig = ops.conv_gemm
 
@@ -81,15 +85,19 @@ class GemmTimer:
             t_in = kw.get("t_in") or kw["m"]
             self.records.append((e0, e1, flop, (kw["m"], kw["n"], K, z), var))
             if var in self.dominant:      # algorithmic floats moved: A read once (not im2col-expanded) + W + output
-                self.dom_bytes += z * (t_in * kw["cin"] + kw["n"] * K + kw["m"] * kw["n"])
+                self.fam_bytes[var] = self.fam_bytes.get(var, 0) + z * (t_in * kw["cin"] + kw["n"] * K + kw["m"] * kw["n"])
             return r
         ops.conv_gemm = wrapped
 
     def summary(self):
-        dom = [r for r in self.records if r[4] in self.dominant]
-        ms = sum(r[0].elapsed_time(r[1]) for r in dom)
-        fl = sum(r[2] for r in dom)
-        return len(dom), ms, fl
+        """(tags, launches, ms, flop, floats moved) of every kernel family, most time first."""
+        out = []
+        for fam in self.families:
+            recs = [r for r in self.records if r[4] in fam]
+            if recs:
+                out.append((fam, len(recs), sum(r[0].elapsed_time(r[1]) for r in recs), sum(r[2] for r in recs),
+                            sum(self.fam_bytes.get(t, 0) for t in fam)))
+        return sorted(out, key=lambda t: -t[2])
 
 
 STRONG = False                         # --scaling strong: ONE 10-minute pool split over the ranks, one replicated source
@@ -384,7 +392,8 @@ def main():
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    n_launch, gemm_ms, gemm_flop = timer.summary()
+    fams = timer.summary()
+    dom_tags, n_launch, gemm_ms, gemm_flop, dom_floats = fams[0] if fams else (timer.dominant[:1], 0, 0.0, 0.0, 0)
     if a.stages and rank == 0:
         agg = {}
         for e0, e1, fl, shp, var in timer.records:
@@ -401,10 +410,11 @@ def main():
         value = (1 if STRONG else ws) * SRC_SECONDS * a.steps / dt      # strong: ONE conversion per step, all ranks on it
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak, mfmas, kernel_name = {
+            "Q256": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2quad_kernel<Gemm2QuadR> (implicit GEMM, 256x256 block / 128x128 wave tiles, fp32 emulated as 3 fp16 MFMAs)"),
             "F128": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2_kernel<Gemm2Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 3 fp16 MFMAs)"),
             "H128": (BF16X3_PEAK_TFLOPS, 6, "conv_gemm3_kernel<Gemm3Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 6 bf16 MFMAs)"),
             "G128v8": (FP32_MFMA_PEAK_TFLOPS, 1, "conv_gemm_kernel<GemmTile<128,128,2,2,2,2>, 8> (implicit GEMM on v_mfma_f32_32x32x2_f32)"),
-        }[timer.dominant[0]]
+        }[dom_tags[0]]
         line = {
             "metric": "audio-sec converted/sec (xRT) end-to-end, cold target pool",
             "value": round(value, 3), "unit": "x real-time", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
@@ -432,7 +442,11 @@ def main():
                          "timing": "HIP events around each launch in an eager re-run of the same K steps right after the "
                                    "timed region (which replays hipGraphs)",
                          "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(1, n_launch), 4),
-                         "kernel_ms_per_step": round(gemm_ms / a.steps, 3)},
+                         "kernel_ms_per_step": round(gemm_ms / a.steps, 3),
+                         "secondary": [{"kernel": "+".join(f), "launches": nl, "kernel_ms_per_step": round(ms / a.steps, 3),
+                                        "achieved": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
+                                        "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else 0.0}
+                                       for f, nl, ms, fl, _b in fams[1:]]},
         }
         line["config"]["adam_iterations"] = [int(step.last["iters_wavlm"]), int(step.last["iters_harm"])]
         tl = torch.tensor([dt_long], device=dev, dtype=torch.float64)
@@ -466,7 +480,7 @@ def main():
             t = json.load(open(pmc))
             line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes"
-            line["roofline"]["algorithmic_bytes_per_launch"] = int(4 * timer.dom_bytes / max(1, n_launch))
+            line["roofline"]["algorithmic_bytes_per_launch"] = int(4 * dom_floats / max(1, n_launch))
         if ws == 1 and not a.no_cpu_baseline:
             L = step.last
             c = lambda x: x.detach().cpu()

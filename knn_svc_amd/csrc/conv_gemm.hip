@@ -459,11 +459,31 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + li] = acc[i][j][r] * a.out_scale;   // power of two: exact
-        // the patch is private to this wave and LDS operations of one wave complete in order: no barrier
+        // the patch is private to this wave and LDS operations of one wave complete in order: no barrier.
+        // Software-pipelined by one trip: the LDS read and the residual / accumulate loads of trip it + 1 are in flight while
+        // trip it runs its arithmetic and its store (the loop is rolled, so nothing else would hide their latency).
+        const int rstep = 64 / (G::TN * 8);
+        const int mrow0 = wrow0 + i * 32 + row_in_trip;
+        auto ld_patch = [&](int it) -> f32x4 { return *(const lds_f4*)(patch + (it * rstep + row_in_trip) * PITCH + c); };
+        auto ld_res = [&](int it) -> f32x4 {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, nv ? ((mrow0 + it * rstep) * a.ldr + n) * 4 : OOB, 0, 0));
+        };
+        auto ld_acc = [&](int it) -> f32x4 {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, nv ? ((mrow0 + it * rstep) * a.ldo + n) * 4 : OOB, 0, 0));
+        };
+        const bool use_res = rz != nullptr && !sp, use_acc = a.accumulate && !sp;
+        f32x4 vn = ld_patch(0), rn = {0.f, 0.f, 0.f, 0.f}, an = rn;
+        if (use_res) rn = ld_res(0);
+        if (use_acc) an = ld_acc(0);
 #pragma unroll 1
         for (int it = 0; it < TRIPS; ++it) {
-            const int row = it * (64 / (G::TN * 8)) + row_in_trip;
-            f32x4 v = *(const lds_f4*)(patch + row * PITCH + c) + bias4;
+            f32x4 v = vn + bias4;
+            const f32x4 rv = rn, av = an;
+            if (it + 1 < TRIPS) {
+                vn = ld_patch(it + 1);
+                if (use_res) rn = ld_res(it + 1);
+                if (use_acc) an = ld_acc(it + 1);
+            }
             if (act == KNNSVC_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
@@ -474,7 +494,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
             }
-            const int m = wrow0 + i * 32 + row;
+            const int m = mrow0 + it * rstep;
             if (sp) {       // f16x2 split layout: (row, n) -> hi at (n/32)*128 + (n%32)*2, lo 64 bytes further
                 g2_u32x2 hi, lo;
                 f16x2_split4(v, a.split_scale, hi, lo);
@@ -484,8 +504,8 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
                 continue;
             }
             const int off = nv ? (m * a.ldo + n) * 4 : OOB;
-            if (rz) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, nv ? (m * a.ldr + n) * 4 : OOB, 0, 0));
-            if (a.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, off, 0, 0));
+            if (use_res) v += rv;
+            if (use_acc) v += av;
             if (a.div != 1.0f) v = v / a.div;
             if (a.out_absmax) {
 #pragma unroll
@@ -1097,12 +1117,16 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
             d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
             d->bias_gstride % 4 == 0) {
-            // 256x256 block, 128x128 wave tiles, hand-pipelined DMA ring (Gemm2Quad): KNNSVC_QUAD=0 switches it off, =2 forces
-            // it for every qualifying launch; by default it takes launches with at least two full rounds of tiles over the chip
+            // 256x256 block, 128x128 wave tiles, hand-pipelined loop (Gemm2QuadR): KNNSVC_QUAD=0 switches it off, =2 forces it
+            // for every qualifying launch.  Default: long-K launches (K >= 1536: FFN2, the conv stack) with at least ~two rounds
+            // of tiles over the chip and no transcendental epilogue.  Measured under sustained load with the real epilogues
+            // (tools/quad_epi_ab.sh): FFN2 372 vs 339 TFLOP/s, conv stack +4..9 %, but FFN1 278 vs 316 and out-proj 254 vs 281 —
+            // one block per CU exposes its whole epilogue (129 M erf evaluations of FFN1 have no other block's MFMAs to hide
+            // under), and a K = 1024 tile spends a third of its life there.
             const char* qe = getenv("KNNSVC_QUAD");      // read per launch: tests and A/B runs switch it inside one process
             const int quad = qe ? atoi(qe) : 1;
             const long tiles = cdiv64(a.m, 256) * cdiv64(d->n, 256) * d->batches * d->groups;
-            if (quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448)) {
+            if (quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448 && a.K >= 1536 && d->act != KNNSVC_ACT_GELU && d->act != KNNSVC_ACT_TANH)) {
                 const char* qd = getenv("KNNSVC_QUAD_DMA");
                 if (qd && qd[0] == '1') { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
                 g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st);
