@@ -344,7 +344,8 @@ def main():
     pipe = LanePipeline(dev, lanes=1) if a.pipeline_depth > 1 else None
     args = (enc, voc, src, sf0, pool_w, pool_f0, a.max_batch, pipe)
     with torch.inference_mode():
-        step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)              # one-time setup outside W: hipGraph capture, split weights
+        for _ in range(2):        # one-time setup outside W: split weights, then hipGraph capture (a shape is captured at its second sight)
+            step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
         if a.warmup:
             run_steps(a.warmup, a.pipeline_depth, *args)
         barrier()

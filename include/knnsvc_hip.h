@@ -88,6 +88,13 @@ typedef struct knnsvc_conv_desc {
      *   out_f16x2_scale: scale of the split layout written under out_f16x2 (0 = 16); the consumer passes the same value
      *     as its a_f16x2_scale. */
     const float* x_absmax; const float* w_absmax; float* out_absmax; float out_f16x2_scale;
+    /* Dynamic length (optional; NULL = off): n_dyn is a DEVICE int32 holding a count n (frames); the kernel then uses
+     *   t_in = n * dyn_t_in_mul + dyn_t_in_add,  m = n * dyn_m_mul + dyn_m_add,  t_out = n * dyn_t_out_mul (transposed mode)
+     * instead of the fields above, which become the MAXIMA the launch is sized for (grid, 31-bit offsets).  Input rows
+     * >= t_in read as zero (the convolution's own zero padding at the sequence end), output rows >= m are not written.
+     * One launch — one captured hipGraph — thus serves every sequence length up to its bucket with the results of an
+     * exact-length launch: the generator's frame-count buckets (hifigan/ddsp_models.py:176-233 is fully convolutional). */
+    const int32_t* n_dyn; int32_t dyn_t_in_mul; int32_t dyn_t_in_add; int32_t dyn_m_mul; int32_t dyn_m_add; int32_t dyn_t_out_mul;
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
@@ -156,8 +163,18 @@ int knnsvc_wavlm_gate(const float* xn, int64_t rows, int32_t heads, int32_t head
  * out_f16x2 is a flag word: bit 0 = write the output in the split layout; bit 2 (value 4) = wide range: Q, K or V may
  * exceed what the f16x2 kernel's fixed operand scales hold (|k|, |v| < 4094, |q| < ~20000 — the caller decides this
  * once, from bounds implied by the weights), so the bf16x3 kernel (fp32 exponent range) runs instead; fp32 in and out. */
+/* kv_len (may be NULL): DEVICE int32 [batches] — batch row b attends to its first kv_len[b] keys only (clamped to 1..T):
+ * WavLM's key_padding_mask for a chunk that sits zero-padded inside a longer, bucketed sequence (wavlm/WavLM.py:311-321;
+ * F.multi_head_attention_forward masks padded keys with -inf).  The table stays indexed with the bucket's T.  Read on the
+ * device at launch time, so one captured hipGraph serves every length of its bucket.  Query rows >= kv_len[b] still get
+ * (finite, unused) outputs. */
 int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
-                           int32_t T, int32_t heads, float* out, int32_t out_f16x2, int32_t kv_f16x2, void* stream);
+                           int32_t T, int32_t heads, float* out, int32_t out_f16x2, int32_t kv_f16x2, const int32_t* kv_len,
+                           void* stream);
+
+/* x[b, t, :] = 0 for t >= lens[b] on a [batches, T, dim] activation (row pitch ld): WavLM's `x[padding_mask] = 0`
+ * (wavlm/WavLM.py:353, 574-575) in front of the positional convolution, for chunks padded up to a bucket length. */
+int knnsvc_mask_rows(float* x, int32_t batches, int32_t T, int32_t dim, int32_t ld, const int32_t* lens, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cosine-distance kNN (lib_ongaku_test.py:148-175 fast_cosine_dist + Tensor.topk(k, largest=False),
@@ -270,10 +287,12 @@ int knnsvc_harmonic_amps(const float* spec, const float* f0, int64_t T, int32_t 
  * (hifigan/ddsp_models.py:416,476): f0 [N], amp [N,H] -> cond [N*hop, n_ch] channel-last, and
  * optionally the raw excitation exc [N*hop].  mode 0 = additive (mix), 1 = plain sine of f0
  * (hifigan/ddsp_models_f0.py:348-356; amp ignored).  frame_phase: N doubles of workspace. */
+/* n_dyn (may be NULL): DEVICE int32 — the valid frame count (<= N): amplitude taps clamp at frame n - 1 and samples past n * hop
+ * are left alone, so a launch sized for a bucket of N frames reproduces the exact-length result (see knnsvc_conv_desc.n_dyn). */
 int knnsvc_additive_synth(const float* f0, const float* amp, int64_t N, int32_t H, int32_t hop,
                           int32_t sample_rate, int32_t mode, const float* prenet_w, const float* prenet_b,
                           int32_t n_ch, float* cond, int32_t ld_cond, float* exc, double* frame_phase,
-                          void* stream);
+                          const int32_t* n_dyn, void* stream);
 
 #ifdef __cplusplus
 }

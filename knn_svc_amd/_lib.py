@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("w_f16x2", vp), ("w_f16x2_scale", f32), ("a_f16x2_scale", f32),
         ("x_f16x2", i32), ("out_f16x2", i32),
         ("x_absmax", vp), ("w_absmax", vp), ("out_absmax", vp), ("out_f16x2_scale", f32),
+        ("n_dyn", vp), ("dyn_t_in_mul", i32), ("dyn_t_in_add", i32), ("dyn_m_mul", i32), ("dyn_m_add", i32), ("dyn_t_out_mul", i32),
     ]
 
 
@@ -50,7 +51,8 @@ SIGNATURES = {
     "knnsvc_layernorm": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp]),
     "knnsvc_wavlm_conv0": (i32, [vp, i32, i64, vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
-    "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, i32, vp]),
+    "knnsvc_wavlm_attention": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp]),
+    "knnsvc_mask_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp, vp]),
     "knnsvc_knn_workspace_bytes": (sz, [i64, i64, i32]),
     "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, i64, i64, vp, vp, vp, sz, vp, vp]),
@@ -69,7 +71,7 @@ SIGNATURES = {
     "knnsvc_reflect_pad": (i32, [vp, i64, i32, vp, vp]),
     "knnsvc_complex_mag": (i32, [vp, i64, i32, i32, vp, vp]),
     "knnsvc_harmonic_amps": (i32, [vp, vp, i64, i32, i32, vp, vp]),
-    "knnsvc_additive_synth": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp]),
+    "knnsvc_additive_synth": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
 }
 
 _lib = None

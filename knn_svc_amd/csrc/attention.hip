@@ -21,7 +21,7 @@ constexpr int LDKK = 68;        // K tile pitch (floats): 16 consecutive rows hi
 constexpr int LDV = 64;
 
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
-                                                       const float* __restrict__ table, int T, int heads,
+                                                       const float* __restrict__ table, const int* __restrict__ kv_len, int T, int heads,
                                                        float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ks = lds;                      // [KT][LDKK]
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const float* base = qkv + (long)b * T * ld;
     const int qi = blockIdx.x * 128 + wave * 32 + li;          // this lane's query
     const bool qvalid = qi < T;
+    // keys this batch row may attend to: WavLM's key_padding_mask (wavlm/WavLM.py:311-321, modules.py:540-563) for a chunk that
+    // sits zero-padded inside a longer bucket; rows >= Tk still get (unused, finite) outputs
+    int Tk = T;
+    if (kv_len) { Tk = kv_len[b]; Tk = Tk < 1 ? 1 : (Tk > T ? T : Tk); }
 
     for (int i = tid; i < 2 * T - 1; i += 256) tb[i] = table[(long)head * (2 * T - 1) + i];
 
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
     };
     gload(0);
-    const int ntiles = (T + KT - 1) / KT;
+    const int ntiles = (Tk + KT - 1) / KT;
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();                       // previous tile's LDS reads are done (also covers tb on t == 0)
 #pragma unroll
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kbase = t * KT + sub * 32;           // first key of this 32-key sub-tile
-            if (kbase >= T) break;
+            if (kbase >= Tk) break;
             // ---- S^T = K . Q^T  (A = K rows from LDS, B = Q fragment) ------------------------
             f32x16 s;
 #pragma unroll
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             for (int r = 0; r < 16; ++r) {
                 const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = -__builtin_inff();
-                if (key < T && qvalid) v = s[r] + g_i * tb[key - qi + T - 1];
+                if (key < Tk && qvalid) v = s[r] + g_i * tb[key - qi + T - 1];
                 s[r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -176,7 +180,7 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 __device__ __forceinline__ unsigned pack_hi(unsigned b, unsigned a) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
-                                                           const float* __restrict__ table, int T, int heads,
+                                                           const float* __restrict__ table, const int* __restrict__ kv_len, int T, int heads,
                                                            float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef __attribute__((address_space(3))) char lc;
@@ -196,6 +200,10 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
     const float* base = qkv + (long)b * T * ld;
     const int qi = blockIdx.x * 128 + wave * 32 + li;
     const bool qvalid = qi < T;
+    // keys this batch row may attend to: WavLM's key_padding_mask (wavlm/WavLM.py:311-321, modules.py:540-563) for a chunk that
+    // sits zero-padded inside a longer bucket; rows >= Tk still get (unused, finite) outputs
+    int Tk = T;
+    if (kv_len) { Tk = kv_len[b]; Tk = Tk < 1 ? 1 : (Tk > T ? T : Tk); }
 
     // bias table + 64 zero floats: the last key tile indexes past 2T-2 before it is masked
     for (int i = tid; i < 2 * T - 1 + 64; i += 256) tb[i] = i < 2 * T - 1 ? table[(long)head * (2 * T - 1) + i] : 0.f;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
         }
     };
     gload(0);
-    const int ntiles = (T + KT - 1) / KT;
+    const int ntiles = (Tk + KT - 1) / KT;
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
 #pragma unroll
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kbase = t * KT + sub * 32;
-            if (kbase >= T) break;
+            if (kbase >= Tk) break;
             // ---- S^T = K . Q^T : 4 d-steps x 6 products -----------------------------------------------
             f32x16 s;
 #pragma unroll
@@ -301,10 +309,10 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const float* __restr
             const l_f* tp = tbq + kbase;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = fmaf(g_i, tp[(r & 3) + 8 * (r >> 2)], s[r]);
-            if (kbase + 32 > T) {                                    // wave-uniform: only the last key tile masks
+            if (kbase + 32 > Tk) {                                    // wave-uniform: only the last key tile masks
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= T) s[r] = -__builtin_inff();
+                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) s[r] = -__builtin_inff();
             }
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 #pragma unroll
@@ -388,7 +396,7 @@ constexpr int VP2 = 320;          // V image: row = key, [hi 64 d | lo 64 d] + p
                                   // ds_read_b64_tr_b16 block cover the 64 banks exactly once
 
 __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
-                                                           const float* __restrict__ table, int T, int heads,
+                                                           const float* __restrict__ table, const int* __restrict__ kv_len, int T, int heads,
                                                            float* __restrict__ out, int out_split, int kv_split) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef __attribute__((address_space(3))) char lc;
@@ -407,6 +415,10 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
     const float* base = qkv + (long)b * T * ld;
     const int qi = blockIdx.x * 128 + wave * 32 + li;
     const bool qvalid = qi < T;
+    // keys this batch row may attend to: WavLM's key_padding_mask (wavlm/WavLM.py:311-321, modules.py:540-563) for a chunk that
+    // sits zero-padded inside a longer bucket; rows >= Tk still get (unused, finite) outputs
+    int Tk = T;
+    if (kv_len) { Tk = kv_len[b]; Tk = Tk < 1 ? 1 : (Tk > T ? T : Tk); }
 
     // bias table + 64 zero floats: the last key tile indexes past 2T-2 before it is masked
     for (int i = tid; i < 2 * T - 1 + 64; i += 256) tb[i] = i < 2 * T - 1 ? table[(long)head * (2 * T - 1) + i] : 0.f;
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
         }
     };
     gload(0);
-    const int ntiles = (T + KT - 1) / KT;
+    const int ntiles = (Tk + KT - 1) / KT;
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
         if (kv_split) {
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kbase = t * KT + sub * 32;
-            if (kbase >= T) break;
+            if (kbase >= Tk) break;
             // ---- S^T = K . Q^T : 4 d-steps x 6 products -----------------------------------------------
             f32x16 s;
 #pragma unroll
@@ -514,10 +526,10 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
             const l_f* tp = tbq + kbase;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = fmaf(g_i, tp[(r & 3) + 8 * (r >> 2)], s[r]);
-            if (kbase + 32 > T) {                                    // wave-uniform: only the last key tile masks
+            if (kbase + 32 > Tk) {                                    // wave-uniform: only the last key tile masks
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= T) s[r] = -__builtin_inff();
+                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) s[r] = -__builtin_inff();
             }
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 #pragma unroll
@@ -596,7 +608,8 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
 }  // namespace
 
 extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
-                                      int32_t T, int32_t heads, float* out, int32_t out_f16x2, int32_t kv_f16x2, void* stream) {
+                                      int32_t T, int32_t heads, float* out, int32_t out_f16x2, int32_t kv_f16x2, const int32_t* kv_len,
+                                      void* stream) {
     KN_REQUIRE(qkv && gate && table && out, "wavlm_attention: null pointer");
     KN_REQUIRE(batches > 0 && T > 0 && heads > 0 && heads <= 65535 && batches <= 65535, "wavlm_attention: bad sizes");
     KN_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "wavlm_attention: 16-byte alignment");
@@ -618,7 +631,7 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
             attr2 = l2;
         }
         dim3 grid2((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batches);
-        hipLaunchKernelGGL(attention2_kernel, grid2, dim3(256), l2, (hipStream_t)stream, qkv, gate, table, T, heads, out, out_f16x2, kv_f16x2);
+        hipLaunchKernelGGL(attention2_kernel, grid2, dim3(256), l2, (hipStream_t)stream, qkv, gate, table, kv_len, T, heads, out, out_f16x2, kv_f16x2);
         return knnsvc_check_launch("wavlm_attention2");
     }
     KN_REQUIRE(!out_f16x2 && !kv_f16x2, "wavlm_attention: split output / pre-split K,V are only implemented by the f16x2 kernel");
@@ -632,7 +645,7 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
             attr3 = l3;
         }
         dim3 grid3((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batches);
-        hipLaunchKernelGGL(attention3_kernel, grid3, dim3(256), l3, (hipStream_t)stream, qkv, gate, table, T, heads, out);
+        hipLaunchKernelGGL(attention3_kernel, grid3, dim3(256), l3, (hipStream_t)stream, qkv, gate, table, kv_len, T, heads, out);
         return knnsvc_check_launch("wavlm_attention3");
     }
     const size_t lds = (size_t)(KT * LDKK + KT * LDV + 2 * T - 1) * 4;
@@ -645,6 +658,6 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
         attr = lds;
     }
     dim3 grid((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batches);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, (hipStream_t)stream, qkv, gate, table, T, heads, out);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, (hipStream_t)stream, qkv, gate, table, kv_len, T, heads, out);
     return knnsvc_check_launch("wavlm_attention");
 }

@@ -34,6 +34,8 @@ struct ConvArgs {
     float* out_absmax;          // optional: atomicMax of |out| over everything this launch stores (a later launch's x_absmax)
     float w_scale;              // f16x2 path: the scale the weights were split with
     float split_scale;          // scale of the split layout written by the epilogue (out_split)
+    // dynamic sequence length (include/knnsvc_hip.h, "Dynamic length"): t_in / m / t_out are affine in a device-side count
+    const int* n_dyn; int dyn_tin_mul, dyn_tin_add, dyn_m_mul, dyn_m_add, dyn_tout_mul;
 };
 
 // largest power of two s with absmax * s < 2^15 (fp16 tops out at 65504): absmax in [2^E, 2^(E+1)) -> s = 2^(14-E).
@@ -49,8 +51,18 @@ __device__ __host__ __forceinline__ float kn_pick_scale(float absmax) {
     return s;
 }
 
-// the kernel parameter struct is a by-value copy: patch the scales in place before anything reads them (uniform loads)
+// the kernel parameter struct is a by-value copy: patch the run-time quantities in place before anything reads them
+// (uniform scalar loads): the valid sequence length of a launch captured for a whole length bucket, then the operand scales
+__device__ __forceinline__ void resolve_dyn(ConvArgs& a) {
+    if (a.n_dyn) {
+        const int n = *a.n_dyn;
+        a.t_in = n * a.dyn_tin_mul + a.dyn_tin_add;
+        a.m = n * a.dyn_m_mul + a.dyn_m_add;
+        if (a.convt_u) a.t_out = n * a.dyn_tout_mul;
+    }
+}
 __device__ __forceinline__ void resolve_scales(ConvArgs& a) {
+    resolve_dyn(a);
     if (a.x_absmax) a.a_scale = kn_pick_scale(*a.x_absmax);
     if (a.w_absmax) a.w_scale = kn_pick_scale(*a.w_absmax);
     if (a.x_absmax || a.w_absmax) a.out_scale = 1.0f / (a.a_scale * a.w_scale);
@@ -524,6 +536,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
 template <class G, int VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_dyn(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
@@ -554,6 +567,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 template <class G>
 __global__ __launch_bounds__(256, 3) void conv_gemm3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    resolve_dyn(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
@@ -1070,6 +1084,10 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.w2 = (const unsigned short*)d->w_f16x2;
     a.out_scale = 1.0f; a.a_scale = 1.0f; a.w_scale = 1.0f;
     a.x_absmax = nullptr; a.w_absmax = nullptr; a.out_absmax = d->out_absmax;
+    a.n_dyn = d->n_dyn; a.dyn_tin_mul = d->dyn_t_in_mul; a.dyn_tin_add = d->dyn_t_in_add; a.dyn_m_mul = d->dyn_m_mul;
+    a.dyn_m_add = d->dyn_m_add; a.dyn_tout_mul = d->dyn_t_out_mul;
+    if (d->n_dyn) KN_REQUIRE(d->dyn_t_in_mul >= 0 && d->dyn_m_mul >= 0 && d->dyn_t_in_add >= 0 && d->dyn_m_add >= 0 && d->batches == 1,
+                             "conv_gemm: dynamic length needs non-negative affine coefficients and batches == 1");
     a.split_scale = d->out_f16x2_scale > 0.f ? d->out_f16x2_scale : KN_F16X2_A_SCALE;
     a.x_split = d->x_f16x2; a.out_split = d->out_f16x2 != 0; a.split_from = d->out_f16x2 > 1 ? d->out_f16x2 : 0;
     KN_REQUIRE(d->out_f16x2 >= 0 && (d->out_f16x2 <= 1 || d->out_f16x2 % 32 == 0), "conv_gemm: out_f16x2 is 0, 1 or the first split column (a multiple of 32)");

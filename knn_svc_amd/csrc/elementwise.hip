@@ -255,7 +255,25 @@ __global__ void harmonic_amps_kernel(const float* __restrict__ spec, const float
     harm[i] = 0.0108f * v;
 }
 
+// rows t >= lens[b] of a [batches, T, dim] activation become zero (WavLM's x[padding_mask] = 0, wavlm/WavLM.py:353, 574-575)
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, int T, int dim, int ld, const int* __restrict__ lens) {
+    const int b = blockIdx.y;
+    const int len = lens[b];
+    const long n4 = (long)(T - len) * (dim / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long r = len + i / (dim / 4); const int c = (int)(i % (dim / 4)) * 4;
+        *(f32x4*)(x + ((long)b * T + r) * ld + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 }  // namespace
+
+extern "C" int knnsvc_mask_rows(float* x, int32_t batches, int32_t T, int32_t dim, int32_t ld, const int32_t* lens, void* stream) {
+    KN_REQUIRE(x && lens && batches > 0 && batches <= 65535 && T > 0 && dim > 0 && dim % 4 == 0 && ld >= dim && ld % 4 == 0 &&
+               ((uintptr_t)x & 15) == 0, "mask_rows: bad arguments");
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(64, (unsigned)batches), dim3(256), 0, (hipStream_t)stream, x, T, dim, ld, lens);
+    return knnsvc_check_launch("mask_rows");
+}
 
 extern "C" int knnsvc_layernorm(const float* x, int64_t rows, int32_t dim, int32_t ldx, const float* gamma,
                                 const float* beta, int32_t gelu, float* out, int32_t ldo, void* stream) {

@@ -34,12 +34,23 @@ __global__ __launch_bounds__(320) void additive_synth_kernel(const float* __rest
                                                             long N, int H, int hop, int sr, int mode,
                                                             const float* __restrict__ pw, const float* __restrict__ pb,
                                                             int n_ch, float* __restrict__ cond, int ld_cond,
-                                                            float* __restrict__ exc, const double* __restrict__ fph) {
+                                                            float* __restrict__ exc, const double* __restrict__ fph,
+                                                            const int* __restrict__ n_dyn) {
 #pragma clang fp contract(off)
     extern __shared__ float sm[];
     float* a5 = sm;                 // [5][H] amplitude rows clamp(n-2 .. n+2)
     float* y = sm + 5 * H;          // [hop + 2]
     const long n = blockIdx.x;
+    if (n_dyn) N = *n_dyn < N ? *n_dyn : N;     // valid frames of a launch sized for a bucket: edge clamps and the last sample follow it
+    if (n >= N) {            // a frame of the bucket past the valid length: defined (zero) condition rows, nothing else
+        for (int j = threadIdx.x; j < hop; j += blockDim.x) {
+            const long t = n * hop + j;
+            if (exc) exc[t] = 0.f;
+            float* cp = cond + t * (long)ld_cond;
+            for (int c = 0; c < n_ch; ++c) cp[c] = 0.f;
+        }
+        return;
+    }
     const long L = N * hop;
     if (mode == 0)
         for (int i = threadIdx.x; i < 5 * H; i += blockDim.x) {
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(320) void additive_synth_kernel(const float* __rest
 extern "C" int knnsvc_additive_synth(const float* f0, const float* amp, int64_t N, int32_t H, int32_t hop,
                                      int32_t sample_rate, int32_t mode, const float* prenet_w, const float* prenet_b,
                                      int32_t n_ch, float* cond, int32_t ld_cond, float* exc, double* frame_phase,
-                                     void* stream) {
+                                     const int32_t* n_dyn, void* stream) {
     KN_REQUIRE(f0 && prenet_w && prenet_b && cond && frame_phase, "additive_synth: null pointer");
     KN_REQUIRE(mode == 1 || amp, "additive_synth: amp required in additive mode");
     KN_REQUIRE(N > 0 && hop > 0 && sample_rate > 0 && n_ch > 0 && ld_cond >= n_ch, "additive_synth: bad sizes");
@@ -113,6 +124,6 @@ extern "C" int knnsvc_additive_synth(const float* f0, const float* amp, int64_t 
     const int Hs = mode == 0 ? H : 0;
     const size_t lds = (size_t)(5 * Hs + hop + 2) * 4;
     hipLaunchKernelGGL(additive_synth_kernel, dim3((unsigned)N), dim3(320), lds, st, f0, amp, (long)N, Hs, hop,
-                       sample_rate, mode, prenet_w, prenet_b, n_ch, cond, ld_cond, exc, (const double*)frame_phase);
+                       sample_rate, mode, prenet_w, prenet_b, n_ch, cond, ld_cond, exc, (const double*)frame_phase, n_dyn);
     return knnsvc_check_launch("additive_synth");
 }

@@ -130,7 +130,7 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     lo, hi = kdist.contiguous_share(len(kept)) if shard_files else (0, len(kept))
     loaded = {i: (torch.from_numpy(v[0]).to(dev), v[1]) for i, v in loaded.items() if lo <= i < hi}
     miss = sorted(loaded)
-    feats = wavlm.encode_many([loaded[i][0] for i in miss]) if miss else []
+    feats = wavlm.encode_many([loaded[i][0] for i in miss], pow2_batches=True) if miss else []
     for i, ft in zip(miss, feats):
         assert ft.shape[0] == Ts[i]
         f0, harm, spec = side_features(loaded[i][0], loaded[i][1], Ts[i])

@@ -116,6 +116,36 @@ def prepare_graph_capture(device) -> None:
     _GRAPH_READY.add(idx)
 
 
+_CAPTURE_STREAMS = {}
+
+
+def capture_graph(fn, device, pool=None):
+    """Capture ``fn()`` (which may only enqueue kernels on the current stream and allocate torch tensors) into a hipGraph
+    WITHOUT synchronising the device: ``torch.cuda.graph`` calls ``torch.cuda.synchronize()`` on entry, which would stall a
+    stream pipeline that happens to meet a new shape.  Capture runs on a private side stream ordered behind the caller's
+    stream.  -> (graph, fn's return value: the graph's static outputs)."""
+    prepare_graph_capture(device)
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    side = _CAPTURE_STREAMS.get(idx)
+    if side is None:
+        side = _CAPTURE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    cur = torch.cuda.current_stream(idx)
+    side.wait_stream(cur)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        if pool is not None:
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
+        else:
+            g.capture_begin(capture_error_mode="thread_local")
+        try:
+            out = fn()
+        finally:
+            g.capture_end()
+    cur.wait_stream(side)
+    return g, out
+
+
 # ------------------------------------------------------------------ implicit-GEMM convolution
 def last_conv_kernel() -> str:
     """Tag of the kernel the last conv_gemm of this thread dispatched to (measurement hook)."""
@@ -127,7 +157,7 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
               convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False,
-              w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0):
+              w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0, dyn=None):
     """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr).
     ``x_absmax`` / ``w_absmax`` / ``out_absmax``: one-element device tensors (range slots of the f16x2 path, see the
     header): bound of |x| / |w| the kernel derives its operand scales from, and where this launch folds max|out|."""
@@ -162,6 +192,16 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.w_absmax = w_absmax.data_ptr() if w_absmax is not None else None
     d.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
     d.out_f16x2_scale = out_split_scale
+    if dyn is not None:
+        # dyn = (device int32 count n, the bucket's count Nb): t_in / m / t_out of THIS call are what they are at n = Nb; each is
+        # affine in the count with an offset in [0, Nb) (the generator's lengths: Nb * factor, + 1 or + taps - 1), recovered here
+        n_t, nb = dyn
+        d.n_dyn = n_t.data_ptr()
+        d.dyn_t_in_mul, d.dyn_t_in_add = divmod(int(d.t_in), nb)
+        d.dyn_m_mul, d.dyn_m_add = divmod(int(m), nb)
+        d.dyn_t_out_mul = int(t_out) // nb if convt_u else 0
+        if convt_u and int(t_out) % nb:
+            raise KnnSvcError("conv_gemm: dynamic t_out must be a multiple of the bucket count")
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
     return out
 
@@ -258,7 +298,14 @@ def attention_mode() -> str:
     return "bf16x3" if e[:1] == "b" else "fp32" if e[:2] == "fp" else "f16x2"
 
 
-def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_split=False, wide=False):
+def mask_rows(x2d, batches, T, lens):
+    """Rows t >= lens[b] of the [batches*T, dim] activation become zero in place (``lens``: int32 device tensor)."""
+    _need(x2d, name="mask_rows.x"); _need(lens, torch.int32, "mask_rows.lens")
+    check(_lib.load().knnsvc_mask_rows(_p(x2d), batches, T, x2d.shape[1], x2d.stride(0), _p(lens), _stream()), "mask_rows")
+    return x2d
+
+
+def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_split=False, wide=False, kv_len=None):
     """kv_split: the K and V column blocks of qkv hold the f16x2 split layout (QKV projection run with out_split=E).
     wide: Q / K / V may exceed the f16x2 kernel's fixed-scale range (decided at load from the weights,
     WavLMEncoder._range_plan): run the bf16x3 kernel (fp32 exponent range) whatever KNNSVC_ATTENTION says."""
@@ -266,7 +313,8 @@ def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_spl
         raise KnnSvcError("wavlm_attention: wide-range mode has fp32 inputs and outputs")
     out = torch.empty(batches * T, heads * 64, device=qkv.device, dtype=torch.float32)
     check(_lib.load().knnsvc_wavlm_attention(_p(qkv), _p(gate), _p(table), batches, T, heads, _p(out),
-                                             (1 if out_split else 0) | (4 if wide else 0), 1 if kv_split else 0, _stream()), "wavlm_attention")
+                                             (1 if out_split else 0) | (4 if wide else 0), 1 if kv_split else 0, _p(kv_len),
+                                             _stream()), "wavlm_attention")
     return out
 
 
@@ -551,7 +599,7 @@ def harmonic_amps(spec, f0, n_harm=49):
     return out
 
 
-def additive_synth(f0, amp, prenet_w, prenet_b, cond, ld_cond, *, hop=320, sr=16000, mode=0, want_exc=False):
+def additive_synth(f0, amp, prenet_w, prenet_b, cond, ld_cond, *, hop=320, sr=16000, mode=0, want_exc=False, n_dyn=None):
     """f0 [N], amp [N,H] (None in sine mode) -> writes cond (a [N*hop, >=n_ch] view); returns exc or None."""
     N = f0.numel()
     n_ch = prenet_b.numel()
@@ -559,5 +607,5 @@ def additive_synth(f0, amp, prenet_w, prenet_b, cond, ld_cond, *, hop=320, sr=16
     exc = torch.empty(N * hop, device=f0.device, dtype=torch.float32) if want_exc else None
     ph = torch.empty(N, device=f0.device, dtype=torch.float64)
     check(_lib.load().knnsvc_additive_synth(_p(f0), _p(amp), N, H, hop, sr, mode, _p(prenet_w), _p(prenet_b), n_ch,
-                                            _p(cond), ld_cond, _p(exc), _p(ph), _stream()), "additive_synth")
+                                            _p(cond), ld_cond, _p(exc), _p(ph), _p(n_dyn), _stream()), "additive_synth")
     return exc

@@ -75,51 +75,67 @@ class Vocoder:
         self.post_w = f(ops.pack_conv_weight(state["dec.conv_post.weight"].float()))
         self.prenet_w = f(state["sin_prenet.weight"].float().reshape(-1, 3))
         self.prenet_b = f(state["sin_prenet.bias"])
-        self._graphs = {}          # N -> (hipGraph, static inputs, static output)
+        self._dyn = None
+        self._graphs = {}          # frame bucket -> (hipGraph, static inputs, device frame count, static output); insertion order = LRU
+        self._seen = set()
+        self._graph_pool = None if not torch.cuda.is_available() else torch.cuda.graph_pool_handle()
+        self.max_graphs = 32
         self.use_graphs = True
 
     # -------------------------------------------------------------------------------------------
     def _conv(self, x, w, out, *, T_in, cin, cout, k, **kw):
-        return ops.conv_gemm(x, w, out, n=cout, cin=cin, taps=k, t_in=T_in, **kw)
+        return ops.conv_gemm(x, w, out, n=cout, cin=cin, taps=k, t_in=T_in, dyn=self._dyn, **kw)
+
+    BUCKET_FRAMES = 25          # frame counts are rounded up to a multiple of this (0.5 s) for the graph cache
 
     @torch.inference_mode()
     def forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None) -> torch.Tensor:
         """c [N, hubert_dim], f0 [N], harm [N, 49] (mix only), all fp32 on the GPU -> waveform [N*hop].
 
-        The generator is ~110 short kernel launches whose host-side launch cost exceeds their device time
-        at 30 s and below, so the schedule for a given frame count N is captured once into a hipGraph
-        (every kernel takes caller-owned buffers and the capture stream, nothing allocates or syncs) and
-        replayed afterwards."""
+        The generator is ~110 short kernel launches whose host-side launch cost exceeds their device time at 30 s and
+        below, so its schedule is captured into a hipGraph and replayed.  Real utterances almost all differ in length, so a
+        graph is captured per frame-count BUCKET (N rounded up to 25 frames), not per N: every launch inside takes its
+        lengths from a device-side frame count (knnsvc_conv_desc.n_dyn: input rows past the valid length read as the
+        convolutions' own zero padding, rows past it are not written), which makes the bucket's graph compute exactly what
+        an exact-length run computes (`test_vocoder_bucket_graph_equals_exact_length`).  A shape is run eagerly at first
+        sight and captured when it comes back; capture does not synchronise the device (ops.capture_graph), so meeting a new
+        bucket inside the dataset-mode stream pipeline costs one eager pass, not a pipeline stall.  LRU cache, one shared
+        memory pool (the graphs only ever replay one after the other on the tail stream)."""
         N = c.shape[0]
         if not self.use_graphs or torch.cuda.is_current_stream_capturing():
             return self._forward(c, f0, harm)
-        ent = self._graphs.get(N)
+        q = self.BUCKET_FRAMES
+        Nb = -(-N // q) * q
+        key = Nb
+        ent = self._graphs.get(key)
         if ent is None:
-            sc, sf = torch.empty_like(c, memory_format=torch.contiguous_format), torch.empty_like(f0)
-            sh = torch.empty_like(harm) if harm is not None else None
-            sc.copy_(c); sf.copy_(f0)
-            if sh is not None:
-                sh.copy_(harm)
-            self._forward(sc, sf, sh)                      # warm-up: one-time function attributes, allocator pools
-            torch.cuda.synchronize()
-            ops.prepare_graph_capture(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._forward(sc, sf, sh)
-            ent = (g, sc, sf, sh, out)
-            if len(self._graphs) >= 16:                    # bound the private pools kept alive
-                self._graphs.pop(next(iter(self._graphs)))
-            self._graphs[N] = ent
-        g, sc, sf, sh, out = ent
-        sc.copy_(c); sf.copy_(f0)
+            if key not in self._seen:                      # first sight: eager, exact length
+                self._seen.add(key)
+                return self._forward(c, f0, harm)
+            dev = c.device
+            sc = torch.zeros(Nb, c.shape[1], device=dev, dtype=torch.float32)
+            sf = torch.zeros(Nb, device=dev, dtype=torch.float32)
+            sh = torch.zeros(Nb, harm.shape[1], device=dev, dtype=torch.float32) if harm is not None else None
+            nd = torch.full((1,), N, device=dev, dtype=torch.int32)
+            g, out = ops.capture_graph(lambda: self._forward(sc, sf, sh, n_dyn=nd), self.device, self._graph_pool)
+            ent = self._graphs[key] = (g, sc, sf, sh, nd, out)
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))            # least recently used
+        else:
+            self._graphs[key] = self._graphs.pop(key)                 # most recently used
+        g, sc, sf, sh, nd, out = ent
+        sc[:N].copy_(c); sf[:N].copy_(f0)
         if sh is not None:
-            sh.copy_(harm)
+            sh[:N].copy_(harm)
+        nd.fill_(N)
         g.replay()
-        return out.clone()
+        return out[:N * self.hop].clone()
 
-    def _forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None) -> torch.Tensor:
+    def _forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None, n_dyn: torch.Tensor | None = None) -> torch.Tensor:
+        """``n_dyn`` (device int32 [1], <= N): the valid frame count of a forward laid out for N = a bucket's frames."""
         dev = c.device
         N = c.shape[0]
+        dyn = self._dyn = None if n_dyn is None else (n_dyn, N)
         hop, n_up, uic = self.hop, self.n_up, self.uic
         L = N * hop
         new = lambda r, ch: torch.empty(r, ch, device=dev, dtype=torch.float32)
@@ -160,7 +176,7 @@ class Vocoder:
         # ---- excitation + sin_prenet -> res[0] -------------------------------------------------
         cond, ld0, c0, s0 = res_view(0)
         ops.additive_synth(f0.contiguous(), harm.contiguous() if self.kind == "mix" else None, self.prenet_w, self.prenet_b,
-                           cond, ld0, hop=hop, sr=self.sr, mode=0 if self.kind == "mix" else 1)
+                           cond, ld0, hop=hop, sr=self.sr, mode=0 if self.kind == "mix" else 1, n_dyn=n_dyn)
         ops.absmax(cond[:, :c0], s0)
         # ---- side (down) path ----------------------------------------------------------------------
         for i in range(n_up):
@@ -177,7 +193,7 @@ class Vocoder:
                        a_slope=LRELU, resid=mid, ldr=c_d, ldo=ld_d, x_absmax=s_mid, out_absmax=s_dst)
         # ---- main path ------------------------------------------------------------------------------
         s_x0 = slot()
-        x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b, x_absmax=ops.absmax(c.contiguous(), slot()), out_absmax=s_x0)
+        x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b, x_absmax=ops.absmax(c.contiguous(), slot()), out_absmax=s_x0, dyn=dyn)
         hd = x0.shape[1]
         self._conv(x0, self.pre_w, cat_pre, T_in=N, cin=hd, cout=uic, k=7, m=N, pad=3, bias=self.pre_b,
                    ldo=cat_pre.shape[1], x_absmax=s_x0, out_absmax=cat_pre_slot)
@@ -194,7 +210,7 @@ class Vocoder:
             ld_c = cat[i].shape[1]
             ops.conv_gemm(x, up["w"], cat[i], m=t_cur + R - 1, n=u * cout, cin=cin, taps=R, stride=1, dil=-1, pad=0,
                           t_in=t_cur, bias=up["b"], bias_period=cout, a_slope=LRELU, ldo=ld_c,
-                          convt_u=u, convt_cout=cout, convt_pad=(k - u) // 2, t_out=t_out, x_absmax=s_x, out_absmax=cat_slot[i])
+                          convt_u=u, convt_cout=cout, convt_pad=(k - u) // 2, t_out=t_out, x_absmax=s_x, out_absmax=cat_slot[i], dyn=dyn)
             xc, s_xc = new(t_out, cout), slot()
             self._conv(cat[i], self.ccv[i], xc, T_in=t_out, cin=ld_c, cout=cout, k=3, m=t_out, pad=1,
                        x_absmax=cat_slot[i], out_absmax=s_xc)

@@ -118,7 +118,10 @@ class WavLMEncoder:
         self.rel_emb = state["encoder.layers.0.self_attn.relative_attention_bias.weight"].detach().float().cpu()
         self.plan = self._range_plan(state)
         self._tables = {}
-        self._graphs = {}          # (B, L) -> (hipGraph, static input, static output)
+        self._graphs = {}          # (B, L, masked) -> (hipGraph, static output, static input, static lengths); insertion order = LRU order
+        self._seen = set()
+        self._graph_pool = None if not torch.cuda.is_available() else torch.cuda.graph_pool_handle()
+        self.max_graphs = 32
         self.use_graphs = True
 
     # -------------------------------------------------------------------------------------------
@@ -176,33 +179,43 @@ class WavLMEncoder:
         return self._tables[T]
 
     @torch.inference_mode()
-    def encode_batch(self, wav: torch.Tensor) -> torch.Tensor:
+    def encode_batch(self, wav: torch.Tensor, lens: torch.Tensor | None = None) -> torch.Tensor:
         """[B, L] equal-length (already padded) chunks on the GPU -> [B, T, E].
 
-        The ~70 launches of one batch are captured into a hipGraph per (B, L) and replayed: the schedule is
-        fixed-shape (30 s chunks), every kernel takes caller-owned buffers, and replay keeps the GPU fed even
-        when the host is slow or shared."""
-        key = tuple(wav.shape)
+        ``lens`` (int32 [B] on the device, optional): valid frames per row — the rows are chunks of different lengths that
+        were zero-padded up to a common BUCKET length; frames >= lens[b] are masked exactly the way WavLM's own padding mask
+        does it (zeroed in front of the positional conv, excluded as attention keys: wavlm/WavLM.py:311-321, 353, 574-575),
+        so rows < lens[b] come out bit-identical to encoding the chunk at its own length.  Rows >= lens[b] are garbage.
+
+        The ~70 launches of one batch are captured into a hipGraph per (B, L, masked?) and replayed: every kernel takes
+        caller-owned buffers, the lengths are read on the device, so ONE graph serves every utterance of its bucket.  The
+        cache is LRU (the 30 s graph of a long-running job must not be the first to go), all graphs share one memory pool
+        (they are only ever replayed one after the other on the encoding stream), and capturing does not synchronise the
+        device."""
+        key = tuple(wav.shape) + (lens is not None,)
         if not self.use_graphs or torch.cuda.is_current_stream_capturing():
-            return self._encode_batch(wav)
+            return self._encode_batch(wav, lens)
         ent = self._graphs.get(key)
         if ent is None:
+            self._table(self.n_frames(wav.shape[1]))       # bias table upload (host -> device) cannot be captured
+            if key not in self._seen:                      # first sight of a shape: run it eagerly (one-time function
+                self._seen.add(key)                        # attributes, allocator warm-up); capture when it comes back
+                return self._encode_batch(wav, lens)
             sin = wav.clone()
-            self._encode_batch(sin)                        # warm-up: bias table upload, function attributes, pools
-            torch.cuda.synchronize()
-            ops.prepare_graph_capture(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._encode_batch(sin)
-            if len(self._graphs) >= 8:
-                self._graphs.pop(next(iter(self._graphs)))
-            ent = self._graphs[key] = (g, sin, out)
-        g, sin, out = ent
+            slen = lens.clone() if lens is not None else None
+            ent = self._graphs[key] = ops.capture_graph(lambda: self._encode_batch(sin, slen), self.device, self._graph_pool) + (sin, slen)
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))            # least recently used
+        else:
+            self._graphs[key] = self._graphs.pop(key)                 # mark as most recently used
+        g, out, sin, slen = ent
         sin.copy_(wav)
+        if slen is not None:
+            slen.copy_(lens)
         g.replay()
         return out.clone()
 
-    def _encode_batch(self, wav: torch.Tensor) -> torch.Tensor:
+    def _encode_batch(self, wav: torch.Tensor, lens: torch.Tensor | None = None) -> torch.Tensor:
         B, L = wav.shape
         dev = wav.device
         x = wav.contiguous()
@@ -244,6 +257,8 @@ class WavLMEncoder:
         cg = E // G
         if tap is not None:
             tap["proj"] = x.clone()
+        if lens is not None:
+            ops.mask_rows(x, B, T, lens)                 # x[padding_mask] = 0 before the positional conv (WavLM.py:574-575)
         x2 = torch.empty_like(x)
         ops.conv_gemm(x, self.pos_w, x2, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T, ldx=E, ldo=E,
                       bias=self.pos_b, act=ops.ACT_GELU, resid=x, ldr=E, batches=B, groups=G,
@@ -262,7 +277,7 @@ class WavLMEncoder:
             qkv = ops.linear(xn, ly["wqkv"], ly["bqkv"], x_split=e_sp, out_split=E if kv_sp else False,
                              x_absmax=None if e_sp else slot_of(xn))
             a_sp = sp(E) and narrow                       # attention output <= max|V|: same bound
-            att = ops.wavlm_attention(qkv, gate, table, B, T, H, out_split=a_sp, kv_split=kv_sp, wide=not narrow)
+            att = ops.wavlm_attention(qkv, gate, table, B, T, H, out_split=a_sp, kv_split=kv_sp, wide=not narrow, kv_len=lens)
             x = ops.linear(att, ly["wo"], ly["bo"], resid=x, x_split=a_sp, x_absmax=None if a_sp else slot_of(att))
             e2_sp = sp(E, pl["xn2"])
             xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"], out_split=e2_sp)
@@ -275,46 +290,51 @@ class WavLMEncoder:
 
     def full_features(self, wav_1d: torch.Tensor, max_batch: int = 8) -> torch.Tensor:
         """One utterance [L] on the GPU -> [T_total, E] (get_full_wavlm_features + layer select)."""
-        plan = chunk_plan(wav_1d.numel())
-        outs = []
-        full = [(s, l, p) for (s, l, p) in plan if l == C.CHUNK_SAMPLES]
-        for i in range(0, len(full), max_batch):
-            grp = full[i:i + max_batch]
-            Lp = C.CHUNK_SAMPLES + grp[0][2]
-            buf = torch.zeros(len(grp), Lp, device=wav_1d.device, dtype=torch.float32)
-            for j, (s, l, _p) in enumerate(grp):
-                buf[j, :l] = wav_1d[s:s + l]
-            outs.append((grp[0][0], self.encode_batch(buf).reshape(-1, self.E)))
-        for (s, l, p) in plan:
-            if l != C.CHUNK_SAMPLES:
-                buf = torch.zeros(1, l + p, device=wav_1d.device, dtype=torch.float32)
-                buf[0, :l] = wav_1d[s:s + l]
-                outs.append((s, self.encode_batch(buf)[0]))
-        outs.sort(key=lambda t: t[0])
-        return torch.cat([o for _s, o in outs], 0)
+        return self.encode_many([wav_1d], max_batch=max_batch)[0]
 
-    def encode_many(self, wavs, max_batch: int = 8):
-        """List of utterances -> list of [T_i, E]; 30 s chunks of ALL utterances are batched together
-        (chunks are independent, ddsp_prematch_dataset.py:275-293)."""
-        jobs = []          # (utt, start, len, pad)
+    BUCKET_FRAMES = 50          # ragged chunks are padded up to a multiple of this many frames (1 s)
+
+    def bucket_frames(self, T: int) -> int:
+        q = self.BUCKET_FRAMES
+        return min(-(-T // q) * q, max(T, C.CHUNK_SAMPLES // C.HOP))
+
+    def encode_many(self, wavs, max_batch: int = 8, pow2_batches: bool = False):
+        """List of utterances -> list of [T_i, E].  Chunks are independent (ddsp_prematch_dataset.py:275-293), so the 30 s
+        chunks of ALL utterances are batched together, and the ragged tails — in dataset mode: nearly every utterance — are
+        grouped into length BUCKETS: each is cut / zero-padded to the bucket's sample count (320 T_b + 80: exactly the
+        receptive field of T_b frames; samples past a chunk's own last frame never reach a frame < T) and encoded with its own
+        frame count as the mask length (encode_batch).  A bucket is one (B, L) shape = one hipGraph, instead of one per
+        distinct utterance length.  ``pow2_batches``: groups are split into batches of 2^k rows (dataset mode: the batch size
+        then also comes from a small set)."""
+        jobs = []          # (utt, start, len, own frames)
         for u, w in enumerate(wavs):
-            for (s, l, p) in chunk_plan(w.numel()):
-                jobs.append((u, s, l, p))
-        by_len = {}
+            for (s_, l, p) in chunk_plan(w.numel()):
+                jobs.append((u, s_, l, self.n_frames(l + p)))
+        by_bucket = {}
         for j in jobs:
-            by_len.setdefault(j[2] + j[3], []).append(j)
+            by_bucket.setdefault(self.bucket_frames(j[3]), []).append(j)
         pieces = {}
-        for Lp, grp in by_len.items():
-            for i in range(0, len(grp), max_batch):
-                sub = grp[i:i + max_batch]
-                buf = torch.zeros(len(sub), Lp, device=self.device, dtype=torch.float32)
-                for r, (u, s, l, _p) in enumerate(sub):
-                    buf[r, :l] = wavs[u][s:s + l]
-                out = self.encode_batch(buf)
-                for r, (u, s, _l, _p) in enumerate(sub):
-                    pieces[(u, s)] = out[r]
+        for Tb, grp in by_bucket.items():
+            Lb = C.HOP * Tb + 80
+            assert self.n_frames(Lb) == Tb
+            i = 0
+            while i < len(grp):
+                n = min(max_batch, len(grp) - i)
+                if pow2_batches:
+                    n = 1 << (n.bit_length() - 1)
+                sub = grp[i:i + n]
+                i += n
+                buf = torch.zeros(len(sub), Lb, device=self.device, dtype=torch.float32)
+                for r, (u, s_, l, _t) in enumerate(sub):
+                    k = min(l, Lb)
+                    buf[r, :k] = wavs[u][s_:s_ + k]
+                exact = all(t == Tb for (_u, _s, _l, t) in sub)
+                lens = None if exact else torch.tensor([t for (_u, _s, _l, t) in sub], dtype=torch.int32).to(self.device, non_blocking=True)
+                out = self.encode_batch(buf, lens)
+                for r, (u, s_, _l, t) in enumerate(sub):
+                    pieces[(u, s_)] = out[r, :t]
         res = []
         for u, w in enumerate(wavs):
-            parts = [pieces[(u, s)] for (s, _l, _p) in chunk_plan(w.numel())]
+            parts = [pieces[(u, s_)] for (s_, _l, _p) in chunk_plan(w.numel())]
             res.append(torch.cat(parts, 0) if parts else torch.empty(0, self.E, device=self.device))
         return res

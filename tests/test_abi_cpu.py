@@ -40,11 +40,11 @@ def test_conv_desc_layout_matches_header():
         decl = decl.strip()
         if not decl:
             continue
-        m = re.match(r"(const float\*|const void\*|float\*|int64_t|int32_t|float)\s+(\w+)$", decl)
+        m = re.match(r"(const float\*|const void\*|const int32_t\*|float\*|int64_t|int32_t|float)\s+(\w+)$", decl)
         assert m, decl
         fields.append((m.group(2), m.group(1)))
     assert [f for f, _ in fields] == [f for f, _ in ConvDesc._fields_]
-    cmap = {"const float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int64_t": ctypes.c_int64,
+    cmap = {"const float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int64_t": ctypes.c_int64,
             "int32_t": ctypes.c_int32, "float": ctypes.c_float}
     for (name, ctype), (pname, ptype) in zip(fields, ConvDesc._fields_):
         assert cmap[ctype] is ptype, (name, ctype, ptype)

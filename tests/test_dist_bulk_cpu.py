@@ -38,7 +38,7 @@ class FakeEncoder:
     def weights_fingerprint(self):
         return "fake"
 
-    def encode_many(self, wavs, max_batch=8):
+    def encode_many(self, wavs, max_batch=8, pow2_batches=False):
         from knn_svc_amd.wavlm import chunk_plan
         out = []
         for w in wavs:

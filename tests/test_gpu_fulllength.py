@@ -139,3 +139,67 @@ def test_additive_synth_1500_frames_gliding_f0_vs_oracle():
     assert float(d[-16000:].max()) < 2e-5 and float(d[:16000].max()) < 2e-5
     ref_cond = F.conv1d(ref[None, None], pw[:, None, :], pb, padding=1)[0].T
     assert float((cond.cpu() - ref_cond).abs().max()) < 1e-4
+
+
+def test_wavlm_bucketed_ragged_chunks_equal_exact_length():
+    """Dataset mode: utterances of different lengths share ONE (batch, bucket) shape — each is zero-padded up to its
+    bucket and masked with WavLM's own padding-mask semantics (wavlm/WavLM.py:311-321, 353, 574-575: padded frames are
+    zeroed in front of the positional conv and excluded as attention keys).  Rows below a chunk's own frame count must be
+    BIT-IDENTICAL to encoding the chunk alone at its exact length, and match the oracle."""
+    from knn_svc_amd.wavlm import WavLMEncoder
+    from oracle import wavlm_ref
+    cfg = C.WAVLM_LARGE
+    sd = S.seeded_state(S.wavlm_param_spec(cfg, 3), seed=1)
+    enc = WavLMEncoder(sd, cfg, DEV, n_layers=3)
+    lens = [16000 * 5 + 123, 16000 * 5 + 9000, 16000 * 5 + 15999, 16000 * 6 - 300, 321, 16000 * 30 + 5000]
+    wavs = [torch.from_numpy(S.synth_clip(n, 40 + i)[0]).to(DEV) for i, n in enumerate(lens)]
+    got = enc.encode_many(wavs, pow2_batches=True)
+    # the 5.x s utterances fall into the same 300-frame bucket and were encoded as one masked batch
+    frames = [enc.n_frames(l + 320 - l % 320) if l <= 480000 else None for l in lens]
+    assert len({enc.bucket_frames(f) for f in frames[:4]}) == 1 and frames[0] != frames[2]
+    enc.use_graphs = False
+    for w, out in zip(wavs, got):
+        # exact-length reference path: every chunk alone, its own padded length, no mask
+        parts = []
+        from knn_svc_amd.wavlm import chunk_plan
+        for (s_, l, p) in chunk_plan(w.numel()):
+            buf = torch.zeros(1, l + p, device=DEV); buf[0, :l] = w[s_:s_ + l]
+            parts.append(enc.encode_batch(buf)[0])
+        exact = torch.cat(parts, 0)
+        assert out.shape == exact.shape and torch.equal(out, exact), (w.numel(), float((out - exact).abs().max()))
+    ref = wavlm_ref.full_features(sd, cfg, wavs[1].cpu(), 3)
+    assert float((got[1].cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    # and through the graphs: second sight captures, third replays — same bits
+    enc.use_graphs = True
+    again = [enc.encode_many(wavs, pow2_batches=True) for _ in range(3)][-1]
+    assert all(torch.equal(a, b) for a, b in zip(again, got))
+    assert any(k[2] for k in enc._graphs) and len(enc._graphs) <= 6          # masked buckets were captured; few shapes
+
+
+def test_vocoder_bucket_graph_equals_exact_length():
+    """Generator frame-count buckets: one hipGraph per 25-frame bucket; every launch inside takes its lengths from a
+    device-side frame count (rows past the valid length read as the convolutions' zero padding).  Different lengths of one
+    bucket through the same graph must equal the eager exact-length run bit for bit, and match the oracle."""
+    from knn_svc_amd.vocoder import Vocoder
+    from oracle import vocoder_ref
+    for kind, hcfg in (("mix", C.HIFIGAN_V1), ("f0", C.HIFIGAN_TINY)):
+        sd = S.seeded_state(S.generator_param_spec(hcfg, kind), 2)
+        voc = Vocoder(sd, hcfg, kind, DEV)
+        g = torch.Generator().manual_seed(3)
+        hub = hcfg.get("hubert_dim", 1024)
+        outs = {}
+        for N in (103, 111, 125, 103, 111, 125, 101):          # one bucket (125): eager first sights, capture, replays
+            c = torch.randn(N, hub, generator=torch.Generator().manual_seed(N)).to(DEV)
+            _, f0 = S.synth_clip(N * 320, N); f0 = torch.from_numpy(f0[:N].copy()).to(DEV)
+            harm = (torch.rand(N, 49, generator=torch.Generator().manual_seed(N + 1)) * 0.02).to(DEV) if kind == "mix" else None
+            y = voc.forward(c, f0, harm)
+            voc.use_graphs = False
+            ye = voc.forward(c, f0, harm)
+            voc.use_graphs = True
+            assert y.numel() == N * 320 and torch.equal(y, ye), (kind, N, float((y - ye).abs().max()))
+            outs[N] = (c, f0, harm, y)
+        assert list(voc._graphs) == [125]
+        if kind == "mix":
+            c, f0, harm, y = outs[111]
+            ref = vocoder_ref.synthesizer(sd, hcfg, kind, c.cpu()[None], f0.cpu()[None, :, None], harm.cpu()[None])[0, 0]
+            assert float((y.cpu() - ref).pow(2).mean().sqrt()) < 2e-6
