@@ -151,7 +151,7 @@ def test_wavlm_bucketed_ragged_chunks_equal_exact_length():
     cfg = C.WAVLM_LARGE
     sd = S.seeded_state(S.wavlm_param_spec(cfg, 3), seed=1)
     enc = WavLMEncoder(sd, cfg, DEV, n_layers=3)
-    lens = [16000 * 5 + 123, 16000 * 5 + 9000, 16000 * 5 + 15999, 16000 * 6 - 300, 321, 16000 * 30 + 5000]
+    lens = [81700, 88000, 94401, 95999, 321, 16000 * 30 + 5000]        # 255 / 275 / 295 / 299 frames: one 300-frame bucket
     wavs = [torch.from_numpy(S.synth_clip(n, 40 + i)[0]).to(DEV) for i, n in enumerate(lens)]
     got = enc.encode_many(wavs, pow2_batches=True)
     # the 5.x s utterances fall into the same 300-frame bucket and were encoded as one masked batch

@@ -12,8 +12,8 @@ cfg = C.WAVLM_LARGE
 sd = S.seeded_state(S.wavlm_param_spec(cfg, nl), seed=1)
 if os.environ.get("STRESS") == "1":      # the outlier-weight state of tests/test_gpu_range.py (needs nl >= 3)
     for k, f in {"encoder.layers.1.final_layer_norm.weight": 60.0, "encoder.layers.1.fc1.weight": 40.0, "encoder.layers.1.fc2.weight": 1.0 / 2400.0,
-                 "encoder.layers.0.self_attn.k_proj.weight": 3000.0, "encoder.layers.0.self_attn.q_proj.weight": 1.0 / 3000.0,
-                 "encoder.layers.0.self_attn.q_proj.bias": 1.0 / 3000.0,
+                 "encoder.layers.0.self_attn.k_proj.weight": 200.0, "encoder.layers.0.self_attn.q_proj.weight": 1.0 / 200.0,
+                 "encoder.layers.0.self_attn.q_proj.bias": 1.0 / 200.0,
                  "encoder.layers.2.self_attn_layer_norm.weight": 1500.0, "encoder.layers.2.self_attn.v_proj.weight": 1.0 / 1500.0,
                  "encoder.layers.2.self_attn.q_proj.weight": 1.0 / 1500.0, "encoder.layers.2.self_attn.k_proj.weight": 1.0 / 1500.0}.items():
         sd[k] = sd[k] * f
