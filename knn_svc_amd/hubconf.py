@@ -75,7 +75,9 @@ def wavlm_large(pretrained=True, progress=True, device="cuda", weights="auto", c
         cfg = dict(cfg or C.WAVLM_LARGE)
         sd = S.seeded_state(S.wavlm_param_spec(cfg, n_layers), seed=1)
     else:
-        ck = torch.hub.load_state_dict_from_url(WAVLM_URL, map_location="cpu", progress=progress)
+        local = os.environ.get("KNNSVC_WAVLM_PT")          # an explicit file instead of the torch.hub cache / URL
+        ck = (torch.load(local, map_location="cpu") if local else
+              torch.hub.load_state_dict_from_url(WAVLM_URL, map_location="cpu", progress=progress))
         cfg = dict(C.WAVLM_LARGE, **ck["cfg"])
         sd = ck["model"]
         print("Pretrained WavLM loaded")

@@ -1,5 +1,7 @@
 """GPU: model-level parity of the HIP path (through the C ABI) against the golden fixtures
 captured from the reference and against the CPU oracle at full model dimensions."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -482,3 +484,32 @@ def test_prematch_cli_entry_point(tmp_path, monkeypatch):
     assert prematch.main(["--librispeech_path", str(root), "--out_path", str(out), "--save_pool_only"]) == 0
     assert (out / "singerA" / "pool_f0.npy").is_file() and np.load(out / "singerB" / "pool_spec.npy").shape[1] == 200
     matching._POOL_CACHE = None
+
+
+def test_released_checkpoints_reproduce_the_reference_sample_output(tmp_path):
+    """BASELINE cfg 2 with the RELEASED weights, when they are present: the reference's own sample pair (60 s each, with its
+    harvest f0 caches) through ddsp_inference's single-file path, against the output the reference ships for exactly that
+    call (sample_content/..._knn_mix_post_opt_0.2.wav, PCM_32).  Bar: 1e-4 RMS (north_star).  The checkpoints cannot be
+    fetched offline: looked for in $KNNSVC_CKPT_DIR (a '*mix*' generator, {'generator': state_dict}, ddsp_hubconf.py:85-94)
+    and $KNNSVC_WAVLM_PT or the torch.hub cache (WavLM-Large.pt, {'cfg','model'}, :113-123); skipped otherwise."""
+    import shutil
+    from pathlib import Path
+    from knn_svc_amd import hubconf
+    ckpt_dir = os.environ.get("KNNSVC_CKPT_DIR", hubconf.DEFAULT_CKPT_DIR)
+    hub_pt = os.path.join(torch.hub.get_dir(), "checkpoints", "WavLM-Large.pt")
+    wavlm_pt = os.environ.get("KNNSVC_WAVLM_PT") or (hub_pt if os.path.isfile(hub_pt) else None)
+    if not (os.path.isdir(ckpt_dir) and hubconf.scan_checkpoint(ckpt_dir, "mix") and wavlm_pt):
+        pytest.skip("released checkpoints not present (WavLM-Large.pt + a *mix* generator): nothing to compare with")
+    fx = Path(__file__).parent / "golden" / "sample_content_full"
+    src, tgt = "Danakil-voice_resampled_16000_cut", "Tiken_lead_07_resampled_16000_cut"
+    for f in fx.iterdir():
+        if "_to_" not in f.name:
+            shutil.copy(f, tmp_path / f.name)
+    os.environ["KNNSVC_WAVLM_PT"] = wavlm_pt
+    knn = hubconf.knn_vc(ckpt_type="mix", device="cuda", local_ckpt_dir=ckpt_dir, weights="released")
+    y = knn.special_match(str(tmp_path / f"{src}.wav"), str(tmp_path / f"{tgt}.wav"), ckpt_type="mix", post_opt="post_opt_0.2")
+    ref, sr = audio_io.read_wav(str(fx / f"{src}_to_{tgt}_knn_mix_post_opt_0.2.wav"))
+    assert sr == 16000 and y.numel() == ref.shape[1] == 960320
+    r = _rms(y, ref[0])
+    print(f"released checkpoints, cfg 2 sample pair: waveform rms error {r:.2e}")
+    assert r < 1e-4
