@@ -209,6 +209,24 @@ int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const 
                       int64_t mask_lo, int64_t mask_hi,
                       int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
 
+/* Fused route for large query sets (no [nq, np] dot matrix in HBM; lib_ongaku_test.py:148-175 + ddsp_prematch_dataset.py:1195-1210
+ * at BASELINE cfg 5 sizes).  knnsvc_knn_screen: q.p^T on the f16x2 matrix-core path (both operands pre-split by
+ * knnsvc_split_f16x2_dyn with the range slots q_absmax / p_absmax) with every product screened in registers against
+ * thr[row] — a distance the row's k-th best is known not to exceed, e.g. its exact k-th distance over a sample of the pool —
+ * using a conservative margin; surviving (pool index, dot) pairs are appended to cand[row][0 .. cap) (8 bytes each),
+ * cand_count[row] counts them (caller zeroes cand_count and overflow_flag).  overflow_flag != 0 afterwards: some row had
+ * more than cap survivors (or one 256x256 tile more than 4096) — the caller must fall back to the dot-matrix route.
+ * knnsvc_knn_refine: the reference's distance formula on the candidates, ascending top-k with knnsvc_knn_select's keys,
+ * NaN flag, mask and idx_offset semantics: identical results to evaluating every pair.
+ * nq * dim and np * dim below 2^28 per call (chunk larger searches). */
+int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
+                      const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
+                      int32_t dim, const float* thr, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count, void* cand,
+                      int32_t cap, int32_t* overflow_flag, void* stream);
+int knnsvc_knn_refine(const int32_t* cand_count, const void* cand, int32_t cap, const float* q_norm, const float* q_sq,
+                      int64_t nq, const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                      int64_t mask_lo, int64_t mask_hi, int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
+
 /* Merge `parts` per-shard top-k lists ([parts][nq][k], e.g. after an RCCL all-gather) into one. */
 int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx, int32_t parts, int64_t nq,
                      int32_t k, int64_t* out_idx, float* out_dist, void* stream);

@@ -10,6 +10,7 @@
 // ties resolve to the lower pool index on every device count.
 #include <stdlib.h>
 #include "gemm_core.h"
+#include "gemm2_core.h"
 
 namespace {
 
@@ -369,6 +370,170 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Fused route for LARGE query sets (BASELINE cfg 5: 24 000+ query frames per search): no [Nq, Np] dot matrix.
+//   pass 1 (host, existing kernels): exact top-k against a SAMPLE of the pool -> thr[row] = a distance the row's k-th best
+//           cannot exceed;
+//   pass 2 (knn_screen_kernel): q.p^T on the 256x256 / 128x128-wave-tile f16x2 main loop (Gemm2QuadR, the fastest loop of
+//           the library at K = 1024: no output to store here), each accumulator element screened IN REGISTERS against its
+//           row's thr with the same conservative margin as knn_select_kernel; the few survivors (pool index, dot) are
+//           compacted per row into a candidate buffer — LDS-staged per tile, one global atomic per (tile, row);
+//   pass 3 (knn_refine_kernel): the reference's distance formula on the candidates only, top-k with the same keys.
+// The candidate set is a superset of the true top-k (thr is an exact k-th distance over a subset; the margin covers the
+// screen's rounding), so the result is identical to evaluating the formula on every pair.  Traffic: 8 B per survivor
+// (~0.4 % of the pairs at a 1/22 sample) instead of 8 B per pair.
+// -------------------------------------------------------------------------------------------------
+typedef unsigned kn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t knn_rsrc(const void* p, int bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    bytes = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float knn_pick_scale(float absmax) {          // == kn_pick_scale of conv_gemm.hip
+    unsigned e = (__float_as_uint(absmax) >> 23) & 0xFFu;
+    e = e < 87u ? 87u : e;
+    return __uint_as_float((268u - e) << 23);
+}
+
+using QG = Gemm2QuadR;
+constexpr int SCR_LIST = 4096;                       // survivors one 256x256 tile can stage in LDS
+
+__global__ __launch_bounds__(256, 1) void knn_screen_kernel(
+    const float* __restrict__ q2, const float* __restrict__ q_absmax, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
+    const unsigned short* __restrict__ p2, const float* __restrict__ p_absmax, const float* __restrict__ pn, const float* __restrict__ psq,
+    long np, int dim, const float* __restrict__ thr, long mask_lo, long mask_hi,
+    int* __restrict__ cand_count, unsigned* __restrict__ cand, int cap, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware order as conv_gemm2quad_kernel: 8 row tiles x 4 column tiles per patch
+    const int gy = (int)((np + 255) / 256);
+    const int gx8 = (int)gridDim.x / gy;
+    constexpr int CW = 4;
+    int L = blockIdx.x;
+    const int full = (gy / CW) * CW * gx8;
+    int c0, cw;
+    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
+    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
+    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
+    const int m0 = (grp * 8 + (rem & 7)) * 256, n0 = (c0 + (rem >> 3)) * 256;
+    if (m0 >= nq) return;
+
+    f32x16 acc[QG::TM][QG::TN];
+#pragma unroll
+    for (int i = 0; i < QG::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < QG::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int M = (int)nq, row_bytes = dim * 4;
+    auto row_off = [&](int m) -> int { return m < M ? m * row_bytes : QG::OOB_OFF; };
+    auto step = [&](int kt) -> int { return kt * 128; };
+    QG::mainloop(lds, dim / 32, row_off, step, knn_rsrc(q2, (int)(nq * row_bytes)), knn_rsrc(p2, (int)(np * (long)(dim / 32) * 128)),
+                 (int)np, dim, m0, n0, acc);
+    __syncthreads();                                   // the operand stages are free: row data, counters and the survivor list
+
+    float* s_thr = lds;                                // [256] thr, 1/|q|, |q|^2
+    float* s_rq = s_thr + 256;
+    float* s_qsq = s_rq + 256;
+    int* s_cnt = (int*)(s_qsq + 256);                  // [256] survivors per row of this tile
+    int* s_base = s_cnt + 256;                         // [256] their first slot in the row's global candidate list
+    int* s_n = s_base + 256;                           // [1] entries in the tile list
+    unsigned* s_list = (unsigned*)(s_n + 4);           // [SCR_LIST][3]: row << 16 | position in row, pool index, dot bits
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const long r = (long)m0 + tid;
+        const bool v = r < nq;
+        s_thr[tid] = v ? thr[r] : -__builtin_inff();                   // rows past nq: nothing survives (a >= -inf + g)
+        s_rq[tid] = v ? __builtin_amdgcn_rcpf(qn[r]) : 0.f;
+        s_qsq[tid] = v ? qsq[r] : 0.f;
+        s_cnt[tid] = 0;
+        if (tid == 0) s_n[0] = 0;
+    }
+    __syncthreads();
+    const float out_scale = 1.0f / (knn_pick_scale(*q_absmax) * knn_pick_scale(*p_absmax));
+    const bool masked = mask_lo < mask_hi;
+    bool spill = false;
+#pragma unroll
+    for (int j = 0; j < QG::TN; ++j) {
+        const int col = QG::acc_col(wave, lane, j);
+        const long p = (long)n0 + col;
+        const bool pv = p < np;
+        const float v_rp = pv ? __builtin_amdgcn_rcpf(pn[p]) : 0.f, v_psq = pv ? psq[p] : 0.f;
+        const bool in_mask = masked && p >= mask_lo && p < mask_hi;
+#pragma unroll
+        for (int i = 0; i < QG::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = QG::acc_row(wave, lane, i, r);
+                const float dot = acc[i][j][r] * out_scale;            // power of two: exact
+                // the screen of knn_select_kernel: approx = 1 - dot / (|q||p|), margin 64 eps (1 + (|q|^2 + |p|^2) / (|q||p|));
+                // NaN / inf anywhere makes the comparison false and the pair a candidate (the exact pass then flags it)
+                const float c = s_rq[row] * v_rp;
+                const float a = 1.0f - dot * c;
+                const float g = fmaf((s_qsq[row] + v_psq) * c, 3.8e-6f, 3.8e-6f);
+                bool need = pv && !(a >= s_thr[row] + g);
+                if (in_mask) need = need || !(1.0f > s_thr[row]);     // a masked row competes at exactly 1
+                if (need) {
+                    const int lp = atomicAdd(&s_cnt[row], 1);
+                    const int e = atomicAdd(&s_n[0], 1);
+                    if (e < SCR_LIST && lp < 65536) {
+                        s_list[e * 3] = ((unsigned)row << 16) | (unsigned)lp;
+                        s_list[e * 3 + 1] = (unsigned)p;
+                        s_list[e * 3 + 2] = __float_as_uint(dot);
+                    } else spill = true;
+                }
+            }
+    }
+    if (spill) atomicOr(overflow, 1);
+    __syncthreads();
+    { const int c = s_cnt[tid]; s_base[tid] = c ? atomicAdd(&cand_count[m0 + tid], c) : 0; }      // one global atomic per (tile, row)
+    __syncthreads();
+    const int n = s_n[0] < SCR_LIST ? s_n[0] : SCR_LIST;
+    for (int e = tid; e < n; e += 256) {
+        const unsigned rl = s_list[e * 3];
+        const int row = (int)(rl >> 16), slot = s_base[row] + (int)(rl & 0xFFFFu);
+        if (slot < cap) {
+            unsigned* dst = cand + ((long)(m0 + row) * cap + slot) * 2;
+            dst[0] = s_list[e * 3 + 1]; dst[1] = s_list[e * 3 + 2];
+        } else atomicOr(overflow, 1);
+    }
+}
+
+// one wave per query row: exact distances of its candidates, ascending top-k (same keys / order as knn_select_kernel)
+__global__ __launch_bounds__(256) void knn_refine_kernel(const int* __restrict__ cand_count, const unsigned* __restrict__ cand, int cap,
+                                                        const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
+                                                        const float* __restrict__ pn, const float* __restrict__ psq, int k, long idx_offset,
+                                                        long mask_lo, long mask_hi, long* __restrict__ out_idx, float* __restrict__ out_dist,
+                                                        int* nan_flag) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    int cnt = cand_count[row];
+    cnt = cnt < cap ? cnt : cap;
+    const float v_qn = qn[row], v_qsq = qsq[row];
+    const unsigned* cr = cand + row * (long)cap * 2;
+    unsigned long long best = KEY_INF;                                  // lanes < k: the sorted list
+    bool saw_nan = false;
+    for (int base = 0; base < cnt; base += 32) {
+        unsigned long long v = lane < 32 ? best : KEY_INF;
+        if (lane >= 32 && base + lane - 32 < cnt) {
+            const unsigned p = cr[(base + lane - 32) * 2];
+            const float dot = __uint_as_float(cr[(base + lane - 32) * 2 + 1]);
+            float d = ref_distance(dot, v_qsq, psq[p], v_qn, pn[p]);
+            if (d != d) saw_nan = true;
+            if ((long)p >= mask_lo && (long)p < mask_hi) d = 1.f;
+            if (d < __builtin_inff()) v = ((unsigned long long)sortable(d) << 32) | p;      // NaN / +inf never enter
+        }
+        v = wave_sort64(v, lane);
+        best = lane < k ? v : KEY_INF;
+    }
+    if (__ballot(saw_nan)) { if (lane == 0) atomicOr(nan_flag, 1); }
+    if (lane < k) {
+        out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull) + idx_offset;
+        out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
+    }
+}
+
 int split_count(long nq, long np) {
     // The kernel needs 109 KB of LDS, so one block is resident per CU: aim for ONE wave of <= 256 blocks and let
     // every block walk as many 128-row pool tiles as possible — the first tile of a block pays a full top-32
@@ -460,4 +625,39 @@ extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_n
         hipLaunchKernelGGL(knn_select_kernel<true>, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
                            (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi, (long*)out_idx, out_dist, nan_flag);
     return knnsvc_check_launch("knn_select");
+}
+
+
+extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
+                                 const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
+                                 int32_t dim, const float* thr, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count, void* cand,
+                                 int32_t cap, int32_t* overflow_flag, void* stream) {
+    KN_REQUIRE(q_f16x2 && q_absmax && q_norm && q_sq && p_f16x2 && p_absmax && p_norm && p_sq && thr && cand_count && cand && overflow_flag,
+               "knn_screen: null pointer");
+    KN_REQUIRE(nq > 0 && np > 0 && dim >= 32 && dim % 32 == 0 && cap > 0, "knn_screen: bad sizes (dim must be a multiple of 32)");
+    KN_REQUIRE(nq * (long)dim * 4 < (1L << 30) && np * (long)dim * 4 < (1L << 30), "knn_screen: operands must stay below 1 GiB (chunk the call)");
+    KN_REQUIRE(((uintptr_t)q_f16x2 & 15) == 0 && ((uintptr_t)p_f16x2 & 15) == 0, "knn_screen: 16-byte alignment");
+    static_assert(QG::LDS_BYTES >= (256 * 5 + 4) * 4 + SCR_LIST * 12, "epilogue state fits the operand stages");
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)knn_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QG::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "knn_screen: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    const long gx8 = cdiv64(cdiv64(nq, 256), 8) * 8;
+    hipLaunchKernelGGL(knn_screen_kernel, dim3((unsigned)(gx8 * cdiv64(np, 256))), dim3(256), QG::LDS_BYTES, (hipStream_t)stream,
+                       (const float*)q_f16x2, q_absmax, q_norm, q_sq, (long)nq, (const unsigned short*)p_f16x2, p_absmax, p_norm, p_sq,
+                       (long)np, dim, thr, (long)mask_lo, (long)mask_hi, cand_count, (unsigned*)cand, cap, overflow_flag);
+    return knnsvc_check_launch("knn_screen");
+}
+
+extern "C" int knnsvc_knn_refine(const int32_t* cand_count, const void* cand, int32_t cap, const float* q_norm, const float* q_sq,
+                                 int64_t nq, const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                                 int64_t mask_lo, int64_t mask_hi, int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream) {
+    KN_REQUIRE(cand_count && cand && q_norm && q_sq && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_refine: null pointer");
+    KN_REQUIRE(nq > 0 && np > 0 && cap > 0 && k >= 1 && k <= KMAX, "knn_refine: bad sizes");
+    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream, cand_count,
+                       (const unsigned*)cand, cap, q_norm, q_sq, (long)nq, p_norm, p_sq, k, (long)idx_offset, (long)mask_lo, (long)mask_hi,
+                       (long*)out_idx, out_dist, nan_flag);
+    return knnsvc_check_launch("knn_refine");
 }

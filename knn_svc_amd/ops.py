@@ -378,7 +378,7 @@ def prepare_knn_pool(pool, k=32, p_stats=None):
     return chunks
 
 
-def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None):
+def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None, allow_fused=True):
     """Two-kernel route: dot products on the f16x2 GEMM (pool rows = pre-split "weights"), then the reference's distance
     formula + selection (knnsvc_knn_select).  Both operands are scaled by device-chosen powers of two (range slots, see
     prepare_knn_pool) — exact, so the dots do not depend on the scale.  Pool and query are chunked so that every buffer
@@ -398,23 +398,76 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
     if nq >= 128 and os.environ.get("KNNSVC_KNN_A2", "1") != "0":
         q2 = torch.empty(nq, dim, device=dev, dtype=torch.float32)
         check(lib.knnsvc_split_f16x2_dyn(_p(q), nq, dim, _p(q_slot), _p(q2), _stream()), "split_queries")
+    fused = allow_fused and knn_fused_on() and q2 is not None and nq >= KNN_FUSED_MIN_Q
     for p0, pc, p2, p_slot in (prepared if prepared is not None else prepare_knn_pool(pool, k, (pn, ps))):
         npc = pc.shape[0]
         idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
         dist = torch.empty(nq, k, device=dev, dtype=torch.float32)
-        q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npc, 1) // 128 * 128))
-        for q0 in range(0, nq, q_rows):
-            qc = (q2 if q2 is not None else q)[q0:q0 + q_rows]
-            m = qc.shape[0]
-            dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
-            conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, w2=p2, x_split=q2 is not None, x_absmax=q_slot, w_absmax=p_slot)
-            check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
-                                        idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
-                                        _stream()), "knn_select")
+        done = False
+        if fused and npc >= KNN_FUSED_MIN_P:
+            done = _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn[p0:], ps[p0:], k, idx_offset + p0,
+                                    (mask[0] - p0, mask[1] - p0), idx, dist, flag)
+        if not done:
+            q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npc, 1) // 128 * 128))
+            for q0 in range(0, nq, q_rows):
+                qc = (q2 if q2 is not None else q)[q0:q0 + q_rows]
+                m = qc.shape[0]
+                dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
+                conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, w2=p2, x_split=q2 is not None, x_absmax=q_slot, w_absmax=p_slot)
+                check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
+                                            idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
+                                            _stream()), "knn_select")
         parts_i.append(idx); parts_d.append(dist)
     if len(parts_i) == 1:
         return parts_i[0], parts_d[0]
     return knn_merge(torch.stack(parts_d), torch.stack(parts_i))
+
+
+KNN_FUSED_MIN_Q, KNN_FUSED_MIN_P = 4096, 32768      # below these the dot matrix is small and the two-kernel route is as fast
+KNN_FUSED_SAMPLE, KNN_FUSED_CAP = 8192, 4096
+
+
+def knn_fused_on() -> bool:
+    import os
+    return os.environ.get("KNNSVC_KNN_FUSED", "1") != "0"
+
+
+def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offset, mask, idx_out, dist_out, flag) -> bool:
+    """Large query sets against one pool chunk without a [nq, np] dot matrix (knnsvc_knn_screen / knnsvc_knn_refine):
+    thr = each row's exact k-th distance over an evenly strided SAMPLE of the chunk (the existing two-kernel route on
+    ~8 k pool rows), then the whole chunk through the screening GEMM with those thresholds, then the reference formula on
+    the survivors.  Returns False (nothing written) when a row has more survivors than the candidate buffer holds — the
+    caller then takes the dot-matrix route for this chunk.  One host read of the overflow flag per call."""
+    lib = _lib.load()
+    nq, dim = q.shape
+    npc = pc.shape[0]
+    dev = q.device
+    stride = max(1, npc // KNN_FUSED_SAMPLE)
+    sample = pc[::stride].contiguous()
+    sn, ss = row_norms(sample)
+    sflag = torch.zeros(1, device=dev, dtype=torch.int32)
+    # sampled rows inside the masked range must compete at 1 here as they do globally (unmasked, a query's own frames would
+    # pull thr below its true k-th distance): sample row j is pool row j * stride
+    smask = (-(-max(mask[0], 0) // stride), -(-max(mask[1], 0) // stride)) if mask[0] < mask[1] else (0, 0)
+    _si, sd = _knn_topk_gemm(q, sample, k, 0, qn, qs, sn, ss, sflag, smask, None, allow_fused=False)
+    thr = sd[:, k - 1].contiguous()
+    q_rows = max(256, min(nq, ((1 << 28) - 1) // dim // 256 * 256, (1 << 30) // (KNN_FUSED_CAP * 8) // 256 * 256))
+    over = torch.zeros(1, device=dev, dtype=torch.int32)
+    idx_tmp = torch.empty_like(idx_out); dist_tmp = torch.empty_like(dist_out)
+    nan_tmp = torch.zeros(1, device=dev, dtype=torch.int32)
+    for q0 in range(0, nq, q_rows):
+        m = min(q_rows, nq - q0)
+        cnt = torch.zeros(m, device=dev, dtype=torch.int32)
+        cand = torch.empty(m * KNN_FUSED_CAP * 2, device=dev, dtype=torch.int32)
+        check(lib.knnsvc_knn_screen(_p(q2[q0:]), _p(q_slot), _p(qn[q0:]), _p(qs[q0:]), m, _p(p2), _p(p_slot), _p(pn), _p(ps), npc, dim,
+                                    _p(thr[q0:]), mask[0], mask[1], _p(cnt), _p(cand), KNN_FUSED_CAP, _p(over), _stream()), "knn_screen")
+        check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn), _p(ps), npc, k, idx_offset,
+                                    mask[0], mask[1], _p(idx_tmp[q0:]), _p(dist_tmp[q0:]), _p(nan_tmp), _stream()), "knn_refine")
+    if int(over.item()) != 0:
+        return False
+    idx_out.copy_(idx_tmp); dist_out.copy_(dist_tmp)
+    flag.copy_(torch.maximum(flag, torch.maximum(nan_tmp, sflag)))
+    return True
 
 
 def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False, mask=None,

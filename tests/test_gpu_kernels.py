@@ -577,6 +577,39 @@ def test_knn_screen_is_exact(scale_q, scale_p, monkeypatch):
     assert torch.equal(a[0], b[0])
 
 
+def test_knn_fused_route_equals_dot_matrix_route(monkeypatch):
+    """Large query sets take the fused route (knnsvc_knn_screen + knnsvc_knn_refine: threshold from a strided pool sample,
+    products screened in the GEMM's registers, reference formula on the survivors only — no [Nq, Np] dot matrix).  Its
+    result must be IDENTICAL to the dot-matrix route: same indices, same distance bits — plain, with a self-mask that covers
+    sampled rows, with an offset, and when the candidate buffer overflows (fallback)."""
+    from knn_svc_amd import ops
+    nq, npool = 4096 + 37, 40000 + 123
+    q = S.clustered_features(nq, 1024, 51, n_centres=60)
+    p = S.clustered_features(npool, 1024, 52, n_centres=60)
+    p[5000:5000 + nq // 8] = q[: nq // 8]                      # exact duplicates of some queries inside the pool (distance ~0)
+    qd, pd = q.to(DEV), p.to(DEV)
+
+    def run(fused, **kw):
+        monkeypatch.setenv("KNNSVC_KNN_FUSED", "1" if fused else "0")
+        return ops.knn_topk(qd, pd, 32, **kw)
+    for kw in (dict(), dict(mask=(4990, 5600), idx_offset=777)):
+        i0, d0 = run(False, **kw)
+        i1, d1 = run(True, **kw)
+        assert torch.equal(i0, i1) and torch.equal(d0, d1), kw
+    # the fused route really ran (no dot matrix): its kernels leave the candidate counts behind a small buffer; check via cap
+    monkeypatch.setattr(ops, "KNN_FUSED_CAP", 8)               # every row overflows -> fallback to the dot-matrix route
+    i2, d2 = run(True)
+    i0, d0 = run(False)
+    assert torch.equal(i0, i2) and torch.equal(d0, d2)
+    # NaN in a query row is reported by either route
+    from knn_svc_amd._lib import KnnSvcError
+    qn_ = qd.clone(); qn_[100, 7] = float("nan")
+    monkeypatch.setattr(ops, "KNN_FUSED_CAP", 4096)
+    monkeypatch.setenv("KNNSVC_KNN_FUSED", "1")
+    with pytest.raises(KnnSvcError):
+        ops.knn_topk(qn_, pd, 32)
+
+
 @pytest.mark.parametrize("sr,n", [(44100, 44100 + 37), (48000, 30001), (8000, 12345), (22050, 22050), (24000, 7)])
 def test_resample_matches_torchaudio_restatement(sr, n):
     """features.resample (GPU, one framed-signal GEMM) against the oracle's restatement of torchaudio's sinc_interp_hann

@@ -13,4 +13,5 @@ for nq, npool in ((1500, 30000), (300, 30000), (6000, 30000), (24000, 180000)):
     for _ in range(n): ops.knn_topk(q, p, 32, q_stats=qs, p_stats=ps, check_nan=False)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print(f"Nq={nq:6d} Np={npool:7d}: {ms:8.3f} ms  {nq / ms * 1e3:12.0f} query frames/s  {2.0 * nq * npool * 1024 / ms / 1e9:7.1f} TFLOP/s")
+    print(f"Nq={nq:6d} Np={npool:7d}: {ms:8.3f} ms  {nq / ms * 1e3:12.0f} query frames/s  {2.0 * nq * npool * 1024 / ms / 1e9:7.1f} TFLOP/s"
+          f"  (fused route: {'on' if ops.knn_fused_on() and nq >= ops.KNN_FUSED_MIN_Q and npool >= ops.KNN_FUSED_MIN_P else 'off'})")
