@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
 // one wave per query row: exact distances of its candidates, ascending top-k (same keys / order as knn_select_kernel)
 __global__ __launch_bounds__(256) void knn_refine_kernel(const int* __restrict__ cand_count, const unsigned* __restrict__ cand, int cap,
                                                         const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
-                                                        const float* __restrict__ pn, const float* __restrict__ psq, int k, long idx_offset,
+                                                        const float* __restrict__ pn, const float* __restrict__ psq, long np, int k, long idx_offset,
                                                         long mask_lo, long mask_hi, long* __restrict__ out_idx, float* __restrict__ out_dist,
                                                         int* nan_flag) {
     const int lane = threadIdx.x & 63;
@@ -516,7 +516,9 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(const int* __restrict__
     bool saw_nan = false;
     for (int base = 0; base < cnt; base += 32) {
         unsigned long long v = lane < 32 ? best : KEY_INF;
-        if (lane >= 32 && base + lane - 32 < cnt) {
+        // (p < np: when the screen overflowed, reserved slots may never have been written — the caller discards the result then,
+        //  but nothing may be read through a garbage index)
+        if (lane >= 32 && base + lane - 32 < cnt && (long)cr[(base + lane - 32) * 2] < np) {
             const unsigned p = cr[(base + lane - 32) * 2];
             const float dot = __uint_as_float(cr[(base + lane - 32) * 2 + 1]);
             float d = ref_distance(dot, v_qsq, psq[p], v_qn, pn[p]);
@@ -657,7 +659,7 @@ extern "C" int knnsvc_knn_refine(const int32_t* cand_count, const void* cand, in
     KN_REQUIRE(cand_count && cand && q_norm && q_sq && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_refine: null pointer");
     KN_REQUIRE(nq > 0 && np > 0 && cap > 0 && k >= 1 && k <= KMAX, "knn_refine: bad sizes");
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream, cand_count,
-                       (const unsigned*)cand, cap, q_norm, q_sq, (long)nq, p_norm, p_sq, k, (long)idx_offset, (long)mask_lo, (long)mask_hi,
+                       (const unsigned*)cand, cap, q_norm, q_sq, (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi,
                        (long*)out_idx, out_dist, nan_flag);
     return knnsvc_check_launch("knn_refine");
 }

@@ -98,6 +98,7 @@ def _inject():
     matching.side_features = _cpu_side_features
     matching.match_features = _cpu_match_features
     matching.prepare_pool = lambda P, split=True: None
+    matching.batched_knn = lambda q_all, P, prep: (_cpu_local_topk(q_all, P, 32, 0)[0], None)
     kd._hip_local_topk = _cpu_local_topk
     kd._hip_merge = _cpu_merge
     matching._POOL_CACHE = None
@@ -163,6 +164,7 @@ def test_bulk_match_pool_shard_and_pair_share_equal_single_process(tmp_path, mon
     monkeypatch.delenv("KNNSVC_POOL_SHARD", raising=False)
     from knn_svc_amd import dist as kd, matching
     saved = (matching.side_features, matching.match_features, matching.prepare_pool, kd._hip_local_topk, kd._hip_merge)
+    saved_bk = matching.batched_knn
     try:
         _inject()
         FakeEncoder.encoded = 0
@@ -170,6 +172,7 @@ def test_bulk_match_pool_shard_and_pair_share_equal_single_process(tmp_path, mon
         enc_single = FakeEncoder.encoded
     finally:
         matching.side_features, matching.match_features, matching.prepare_pool, kd._hip_local_topk, kd._hip_merge = saved
+        matching.batched_knn = saved_bk
         matching._POOL_CACHE = None
     assert len(single) == 3 * 2 * 4                                       # 6 ordered pairs x 4 utterances
     ref = _read_all(single)
