@@ -78,15 +78,22 @@ typedef struct knnsvc_conv_desc {
     int32_t out_f16x2;                 /* 1: write out in the f16x2 split layout (scale 16) for the next GEMM;      */
                                        /* c >= 32 (multiple of 32): only columns >= c are split (QKV: K,V blocks)   */
     /* Range of the f16x2 path without host round trips (all optional, NULL / 0 = off; ignored by the fp32 / bf16x3 paths):
-     *   x_absmax / w_absmax: DEVICE floats holding an upper bound of |x| over the A operand / of |w| over the split
+     * A RANGE SLOT is 16 consecutive DEVICE floats (64 bytes): producers fold max|.| into stripe (block id % 16) of it,
+     * consumers use the maximum of the 16.  Its content is a pure function of the data (max is order-independent).
+     *   x_absmax / w_absmax: range slots holding an upper bound of |x| over the A operand / of |w| over the split
      *     weights; the kernel then derives the operand's power-of-two scale itself — the largest s with bound * s < 2^15
      *     (knnsvc_split_f16x2_dyn splits with the same rule, so a pre-split operand and its consumer agree by sharing a
      *     slot) — instead of a_f16x2_scale / w_f16x2_scale.  No activation range can overflow fp16 this way, and tiny
      *     tensors are lifted into the range instead of losing bits.
-     *   out_absmax: DEVICE float; the epilogue folds max|out| over everything this launch stores into it with atomicMax
-     *     (on the bit pattern: a NaN output makes the slot NaN).  The caller zeroes it; it is the next launch's x_absmax.
+     *   out_absmax: range slot; the epilogue folds max|out| over everything this launch stores into it with atomicMax
+     *     (on the bit pattern: a NaN output makes the slot NaN).  The caller zeroes all 16 floats; it is the next launch's
+     *     x_absmax.
      *   out_f16x2_scale: scale of the split layout written under out_f16x2 (0 = 16); the consumer passes the same value
-     *     as its a_f16x2_scale. */
+     *     as its a_f16x2_scale.
+     *   x_bound_mul / x_bound_add (0 / 0 = 1 / 0): the A operand's bound is x_bound_mul * max(x_absmax) + x_bound_add — for an
+     *     input that was not measured itself but whose bound follows from ITS producer's measured input and weights
+     *     (|conv(x)| <= max_n sum_k |w[n,k]| * max|x| + max|b|; activations that do not grow their argument change nothing):
+     *     publishing costs short-lived blocks ~1 us each, so only every other tensor of a conv chain is measured. */
     const float* x_absmax; const float* w_absmax; float* out_absmax; float out_f16x2_scale;
     /* Dynamic length (optional; NULL = off): n_dyn is a DEVICE int32 holding a count n (frames); the kernel then uses
      *   t_in = n * dyn_t_in_mul + dyn_t_in_add,  m = n * dyn_m_mul + dyn_m_add,  t_out = n * dyn_t_out_mul (transposed mode)
@@ -95,6 +102,7 @@ typedef struct knnsvc_conv_desc {
      * One launch — one captured hipGraph — thus serves every sequence length up to its bucket with the results of an
      * exact-length launch: the generator's frame-count buckets (hifigan/ddsp_models.py:176-233 is fully convolutional). */
     const int32_t* n_dyn; int32_t dyn_t_in_mul; int32_t dyn_t_in_add; int32_t dyn_m_mul; int32_t dyn_m_add; int32_t dyn_t_out_mul;
+    float x_bound_mul; float x_bound_add;
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
@@ -114,13 +122,13 @@ int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* ou
  * below ~0.2 / a_f16x2_scale lose relative accuracy (absolute floor 3e-8 / a_f16x2_scale per element). */
 int knnsvc_split_weight_f16x2(const float* w, int64_t rows, int32_t K, float scale, void* out, void* stream);
 
-/* The same split with the scale taken from a device slot: scale = the largest power of two with *absmax * scale < 2^15
+/* The same split with the scale taken from a range slot (16 floats, see knnsvc_conv_desc): scale = the largest power of two with max(slot) * scale < 2^15
  * (what knnsvc_conv_gemm derives from x_absmax / w_absmax).  For operands whose range is only known on the device — the
  * kNN's query and pool features (lib_ongaku_test.py:148-175 takes whatever WavLM produced). */
 int knnsvc_split_f16x2_dyn(const float* w, int64_t rows, int32_t K, const float* absmax, void* out, void* stream);
 
-/* slot = max(slot, max |x[r, c]|) over a [rows, cols] matrix with row pitch ld (atomicMax on the bit pattern, NaN wins);
- * the caller zeroes the slot.  Feeds x_absmax / w_absmax for tensors that no GEMM epilogue produced. */
+/* Folds max |x[r, c]| over a [rows, cols] matrix with row pitch ld into the range slot (16 floats; atomicMax on the bit
+ * pattern, NaN wins); the caller zeroes the slot.  Feeds x_absmax / w_absmax for tensors that no GEMM epilogue produced. */
 int knnsvc_absmax(const float* x, int64_t rows, int32_t cols, int32_t ld, float* slot, void* stream);
 
 /* Activations in the f16x2 split layout ("A2"): a [rows, C] matrix (C % 32 == 0, row pitch ld floats, ld % 32 == 0)
@@ -181,7 +189,7 @@ int knnsvc_mask_rows(float* x, int32_t batches, int32_t T, int32_t dim, int32_t 
  * driver loop ddsp_prematch_dataset.py:1195-1210).
  * ------------------------------------------------------------------------------------------ */
 /* norm[r] = sqrt(sum x^2) (torch.norm, lib_ongaku_test.py:150-151); sq[r] = sum x^2 (cdist's own term).
- * max_slot (may be NULL): DEVICE float, folded with the largest row norm (atomicMax on the bit pattern; the caller
+ * max_slot (may be NULL): range slot (16 DEVICE floats), folded with the largest row norm (atomicMax on the bit pattern; the caller
  * zeroes it) — an upper bound of max|x| that costs no extra pass: the range slot the kNN's f16x2 GEMM scales by. */
 int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, float* norm, float* sq, float* max_slot,
                      void* stream);

@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("x_f16x2", i32), ("out_f16x2", i32),
         ("x_absmax", vp), ("w_absmax", vp), ("out_absmax", vp), ("out_f16x2_scale", f32),
         ("n_dyn", vp), ("dyn_t_in_mul", i32), ("dyn_t_in_add", i32), ("dyn_m_mul", i32), ("dyn_m_add", i32), ("dyn_t_out_mul", i32),
+        ("x_bound_mul", f32), ("x_bound_add", f32),
     ]
 
 

@@ -31,6 +31,7 @@ struct ConvArgs {
     // dynamic range of the f16x2 path (include/knnsvc_hip.h, "Range"): device slots holding an upper bound of |x| / |w|;
     // when set, the kernel derives the power-of-two operand scale from the slot (kn_pick_scale) instead of a_scale / w_scale
     const float* x_absmax; const float* w_absmax;
+    float x_bound_mul, x_bound_add;   // bound of |x| = x_bound_mul * max(x_absmax slot) + x_bound_add (1, 0 = the slot itself)
     float* out_absmax;          // optional: atomicMax of |out| over everything this launch stores (a later launch's x_absmax)
     float w_scale;              // f16x2 path: the scale the weights were split with
     float split_scale;          // scale of the split layout written by the epilogue (out_split)
@@ -51,6 +52,24 @@ __device__ __host__ __forceinline__ float kn_pick_scale(float absmax) {
     return s;
 }
 
+// A range slot is KN_SLOT_W = 16 consecutive floats (64 bytes): producers fold max|.| into stripe (block id % 16), consumers
+// take the maximum of the 16 (one s_load_dwordx16).  A slot's content is a pure function of the data (max is
+// order-independent), so results do not depend on scheduling or on what ran before.
+// Producer protocol (measured on the generator, 7.1 ms per 1500-frame forward without range slots): a wave first loads its
+// stripe and sends its atomicMax only when it would raise it — the load costs every short-lived block ~1 us at the end of
+// its life (+0.9 ms with all ~105 launches publishing), but unconditional atomics are far worse (+2.5 ms: even spread over
+// 128 stripes they queue up behind each other in a few L2 cache lines), and a value fetched at kernel start is stale for
+// the whole first round of blocks (+2.7 ms).  So the number of PUBLISHING launches is what is kept small: a tensor whose
+// bound follows from its producer's input bound and weights (knnsvc_conv_desc.x_bound_mul / x_bound_add) is not measured.
+constexpr int KN_SLOT_W = 16;
+__device__ __forceinline__ int kn_stripe() { return blockIdx.x & (KN_SLOT_W - 1); }
+__device__ __forceinline__ float kn_slot_max(const float* slot) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < KN_SLOT_W; ++i) { const unsigned v = __float_as_uint(slot[i]) & 0x7FFFFFFFu; m = v > m ? v : m; }
+    return __uint_as_float(m);
+}
+
 // the kernel parameter struct is a by-value copy: patch the run-time quantities in place before anything reads them
 // (uniform scalar loads): the valid sequence length of a launch captured for a whole length bucket, then the operand scales
 __device__ __forceinline__ void resolve_dyn(ConvArgs& a) {
@@ -63,19 +82,19 @@ __device__ __forceinline__ void resolve_dyn(ConvArgs& a) {
 }
 __device__ __forceinline__ void resolve_scales(ConvArgs& a) {
     resolve_dyn(a);
-    if (a.x_absmax) a.a_scale = kn_pick_scale(*a.x_absmax);
-    if (a.w_absmax) a.w_scale = kn_pick_scale(*a.w_absmax);
+    if (a.x_absmax) a.a_scale = kn_pick_scale(fmaf(kn_slot_max(a.x_absmax), a.x_bound_mul, a.x_bound_add));
+    if (a.w_absmax) a.w_scale = kn_pick_scale(kn_slot_max(a.w_absmax));
     if (a.x_absmax || a.w_absmax) a.out_scale = 1.0f / (a.a_scale * a.w_scale);
+    if (a.out_absmax) a.out_absmax += kn_stripe();
 }
 
 // |v| as ordered bits: NaN sorts above inf, so a NaN anywhere in the output reaches the slot (fmaxf would drop it)
 __device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
-// One atomic per wave at most — and none when the slot already holds a larger value (a relaxed load first: tens of
-// thousands of same-address atomics per launch would serialise in L2; a stale smaller value only costs the atomic).
-__device__ __forceinline__ void publish_absmax(float* slot, unsigned m) {
+// one atomic per wave at most, and only when it raises the stripe (fresh load first, see above)
+__device__ __forceinline__ void publish_absmax(float* stripe, unsigned m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n((const unsigned*)slot, __ATOMIC_RELAXED)) atomicMax((unsigned*)slot, m);
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load((const unsigned*)stripe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned*)stripe, m);
 }
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
@@ -537,6 +556,7 @@ template <class G, int VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     resolve_dyn(a);
+    if (a.out_absmax) a.out_absmax += kn_stripe();
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
@@ -568,6 +588,7 @@ template <class G>
 __global__ __launch_bounds__(256, 3) void conv_gemm3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     resolve_dyn(a);
+    if (a.out_absmax) a.out_absmax += kn_stripe();
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
@@ -951,7 +972,7 @@ __global__ void split_weight2_kernel(const float* __restrict__ w, long n, int K,
                                      unsigned short* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long groups_per_row = K / 4;
-    if (absmax) scale = kn_pick_scale(*absmax);
+    if (absmax) scale = kn_pick_scale(kn_slot_max(absmax));
     if (i >= n * groups_per_row) return;
     const long row = i / groups_per_row; const int k = (int)(i - row * groups_per_row) * 4;
     g2_u32x2 hi, lo;
@@ -1083,7 +1104,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.w3 = (const unsigned short*)d->w_bf16x3;
     a.w2 = (const unsigned short*)d->w_f16x2;
     a.out_scale = 1.0f; a.a_scale = 1.0f; a.w_scale = 1.0f;
-    a.x_absmax = nullptr; a.w_absmax = nullptr; a.out_absmax = d->out_absmax;
+    a.x_absmax = nullptr; a.w_absmax = nullptr; a.out_absmax = d->out_absmax; a.x_bound_mul = 1.0f; a.x_bound_add = 0.f;
     a.n_dyn = d->n_dyn; a.dyn_tin_mul = d->dyn_t_in_mul; a.dyn_tin_add = d->dyn_t_in_add; a.dyn_m_mul = d->dyn_m_mul;
     a.dyn_m_add = d->dyn_m_add; a.dyn_tout_mul = d->dyn_t_out_mul;
     if (d->n_dyn) KN_REQUIRE(d->dyn_t_in_mul >= 0 && d->dyn_m_mul >= 0 && d->dyn_t_in_add >= 0 && d->dyn_m_add >= 0 && d->batches == 1,
@@ -1122,6 +1143,8 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         { int e2 = 0; KN_REQUIRE(frexpf(a.a_scale, &e2) == 0.5f && frexpf(a.w_scale, &e2) == 0.5f, "conv_gemm: f16x2 scales must be powers of two"); }
         a.out_scale = 1.0f / (a.a_scale * a.w_scale);
         a.x_absmax = d->x_absmax; a.w_absmax = d->w_absmax;      // device-side scales override the two above
+        a.x_bound_mul = d->x_bound_mul > 0.f ? d->x_bound_mul : 1.0f; a.x_bound_add = d->x_bound_add;
+        KN_REQUIRE(d->x_bound_add >= 0.f && d->x_bound_mul >= 0.f, "conv_gemm: x_bound_mul / x_bound_add must be non-negative");
         // 256x256 double-buffered tile with LDS-DMA weights (one block per CU): fewer L2/LDS bytes per MFMA and a
         // higher sustained clock (1.65 vs 1.39 GHz) — 279 vs 242 TFLOP/s on an isolated long-K GEMM (FFN2), but a lone
         // block per CU cannot hide its prologue/epilogue and loses when other streams share the chip (end-to-end bench:
@@ -1240,6 +1263,7 @@ namespace {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long rows, int cols, int ld, int vec,
                                                      float* __restrict__ slot) {
     const int c4 = vec ? cols >> 2 : 0;
+    slot += kn_stripe();
     unsigned m = 0;
     const long n4 = rows * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

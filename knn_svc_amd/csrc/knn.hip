@@ -363,9 +363,10 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
         if (norm) norm[row] = nr;
         // range slot: max row norm >= max |x| (bit-pattern max: a NaN row makes the slot NaN); relaxed pre-check keeps
         // the same-address atomics to the few rows that raise the maximum
-        if (max_slot) {
+        if (max_slot) {       // a range slot is 16 floats; stripe by block, fresh load before the atomic (conv_gemm.hip)
+            unsigned* st = (unsigned*)max_slot + (blockIdx.x & 15);
             const unsigned b = __float_as_uint(nr) & 0x7FFFFFFFu;
-            if (b > __atomic_load_n((const unsigned*)max_slot, __ATOMIC_RELAXED)) atomicMax((unsigned*)max_slot, b);
+            if (b > __hip_atomic_load((const unsigned*)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st, b);
         }
     }
 }
@@ -390,8 +391,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t knn_rsrc(const void* p, int by
     bytes = __builtin_amdgcn_readfirstlane(bytes);
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ float knn_pick_scale(float absmax) {          // == kn_pick_scale of conv_gemm.hip
-    unsigned e = (__float_as_uint(absmax) >> 23) & 0xFFu;
+__device__ __forceinline__ float knn_pick_scale(const float* slot) {      // == kn_pick_scale(kn_slot_max(slot)) of conv_gemm.hip
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const unsigned v = __float_as_uint(slot[i]) & 0x7FFFFFFFu; m = v > m ? v : m; }
+    unsigned e = (m >> 23) & 0xFFu;
     e = e < 87u ? 87u : e;
     return __uint_as_float((268u - e) << 23);
 }
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         if (tid == 0) s_n[0] = 0;
     }
     __syncthreads();
-    const float out_scale = 1.0f / (knn_pick_scale(*q_absmax) * knn_pick_scale(*p_absmax));
+    const float out_scale = 1.0f / (knn_pick_scale(q_absmax) * knn_pick_scale(p_absmax));
     const bool masked = mask_lo < mask_hi;
     bool spill = false;
 #pragma unroll

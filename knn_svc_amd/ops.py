@@ -157,7 +157,7 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
               convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False,
-              w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0, dyn=None):
+              w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0, dyn=None, x_bound=None):
     """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr).
     ``x_absmax`` / ``w_absmax`` / ``out_absmax``: one-element device tensors (range slots of the f16x2 path, see the
     header): bound of |x| / |w| the kernel derives its operand scales from, and where this launch folds max|out|."""
@@ -188,10 +188,15 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.out_f16x2 = int(out_split) if (out_split is not True and out_split is not False) else (1 if out_split else 0)   # True / first split column
     if not x_split and (x_absmax is not None or out_absmax is not None) and not range_slots_on():
         x_absmax = out_absmax = None            # A/B aid: fixed activation scale 16 (a pre-split operand keeps its slot)
+    if _SLOT_DBG and not x_split:          # timing aid: KNNSVC_SLOT_DBG=x keeps only the consumer side, =o only the producer side
+        if _SLOT_DBG == "x": out_absmax = None
+        if _SLOT_DBG == "o": x_absmax = None
     d.x_absmax = x_absmax.data_ptr() if x_absmax is not None else None
     d.w_absmax = w_absmax.data_ptr() if w_absmax is not None else None
     d.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
     d.out_f16x2_scale = out_split_scale
+    if x_bound is not None:            # (mul, add): |x| <= mul * max(x_absmax slot) + add — an input that was not measured itself
+        d.x_bound_mul, d.x_bound_add = float(x_bound[0]), float(x_bound[1])
     if dyn is not None:
         # dyn = (device int32 count n, the bucket's count Nb): t_in / m / t_out of THIS call are what they are at n = Nb; each is
         # affine in the count with an offset in [0, Nb) (the generator's lengths: Nb * factor, + 1 or + taps - 1), recovered here
@@ -213,7 +218,7 @@ def absmax(x2d, slot=None):
     if not range_slots_on() and slot is not None:
         return slot
     if slot is None:
-        slot = torch.zeros(1, device=x2d.device, dtype=torch.float32)
+        slot = new_slot(x2d.device)
     if x2d.dim() == 1:
         x2d = x2d[None]
     if x2d.stride(1) != 1:
@@ -221,6 +226,13 @@ def absmax(x2d, slot=None):
     check(_lib.load().knnsvc_absmax(_p(x2d), x2d.shape[0], x2d.shape[1], x2d.stride(0) if x2d.shape[0] > 1 else x2d.shape[1],
                                     _p(slot), _stream()), "absmax")
     return slot
+
+
+SLOT_W = 16          # a range slot is 16 floats: producers stripe their atomics over it, consumers take the maximum
+
+
+def new_slot(device) -> torch.Tensor:
+    return torch.zeros(SLOT_W, device=device, dtype=torch.float32)
 
 
 def pick_scale(bound: float) -> float:
@@ -319,6 +331,10 @@ def wavlm_attention(qkv, gate, table, batches, T, heads, out_split=False, kv_spl
 
 
 # ------------------------------------------------------------------ kNN
+import os as _os
+_SLOT_DBG = _os.environ.get("KNNSVC_SLOT_DBG", "")
+
+
 def range_slots_on() -> bool:
     """KNNSVC_RANGE_SLOTS=0 (A/B aid): f16x2 GEMMs fall back to the fixed activation scale 16 (|x| < 4094)."""
     import os
@@ -332,7 +348,7 @@ def row_norms(x2d):
     rows, dim = x2d.shape
     norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
     sq = torch.empty(rows, device=x2d.device, dtype=torch.float32)
-    slot = torch.zeros(1, device=x2d.device, dtype=torch.float32)
+    slot = new_slot(x2d.device)
     check(_lib.load().knnsvc_row_norms(_p(x2d), rows, dim, x2d.stride(0), _p(norm), _p(sq), _p(slot), _stream()), "row_norms")
     norm._slot = slot
     return norm, sq

@@ -67,7 +67,11 @@ class Vocoder:
                 nm = f"dec.resblocks.{i * nk + j}"
                 convs = []
                 for m, d in enumerate(dil):
-                    convs.append(dict(w1=f(ops.pack_conv_weight(_fold(state, f"{nm}.convs1.{m}"))), b1=f(state[f"{nm}.convs1.{m}.bias"]),
+                    w1_ = _fold(state, f"{nm}.convs1.{m}")
+                    convs.append(dict(w1=f(ops.pack_conv_weight(w1_)), b1=f(state[f"{nm}.convs1.{m}.bias"]),
+                                      # |convs1(lrelu(x)) + b1| <= max_n sum_k |w1[n, k]| * max|x| + max|b1|: the inner tensor of a
+                                      # ResBlock pair is bounded through its input's range slot, not measured (see _forward)
+                                      t1_bound=(float(w1_.abs().sum(dim=(1, 2)).max()), float(state[f"{nm}.convs1.{m}.bias"].abs().max())),
                                       w2=f(ops.pack_conv_weight(_fold(state, f"{nm}.convs2.{m}"))), b2=f(state[f"{nm}.convs2.{m}.bias"]),
                                       d=d))
                 blocks.append(dict(k=k_r, convs=convs))
@@ -139,17 +143,17 @@ class Vocoder:
         hop, n_up, uic = self.hop, self.n_up, self.uic
         L = N * hop
         new = lambda r, ch: torch.empty(r, ch, device=dev, dtype=torch.float32)
-        # Range slots of the f16x2 GEMMs (include/knnsvc_hip.h, "Range"): one device float per logical tensor.  Every
-        # producer folds max|out| into its output's slot (out_absmax), every consumer derives its activation scale from its
-        # input's slot (x_absmax) — the generator's activations have no a-priori bound (residual sums over 4 x 9 ResBlock
-        # convs, arbitrary trained weights), and this way no range can overflow fp16 and small-amplitude stages keep their
-        # bits, with no host round trip (the whole forward stays one hipGraph).
-        slots = torch.zeros(512, device=dev, dtype=torch.float32)
+        # Range slots of the f16x2 GEMMs (include/knnsvc_hip.h, "Range"): one slot per logical tensor.  Every producer folds
+        # max|out| into its output's slot (out_absmax), every consumer derives its activation scale from its input's slot
+        # (x_absmax) — the generator's activations have no a-priori bound (residual sums over 4 x 9 ResBlock convs, arbitrary
+        # trained weights), and this way no range can overflow fp16 and small-amplitude stages keep their bits, with no host
+        # round trip (the whole forward stays one hipGraph).
+        slots = torch.zeros(256 * ops.SLOT_W, device=dev, dtype=torch.float32)
         n_slot = [0]
 
         def slot():
             n_slot[0] += 1
-            return slots[n_slot[0] - 1:n_slot[0]]
+            return slots[(n_slot[0] - 1) * ops.SLOT_W:n_slot[0] * ops.SLOT_W]
         # lengths of the time axis at each level of the side path: lens[0] = L ... lens[n_up] = N
         lens = [L]
         for i in range(n_up):
@@ -222,21 +226,22 @@ class Vocoder:
                 cur, s_cur = xc, s_xc
                 for m, cv in enumerate(blk["convs"]):
                     d = cv["d"]
-                    s_t1 = slot()
+                    # t1 = lrelu(convs1(lrelu(cur)) + b1) is not measured: its consumer bounds it by t1_bound applied to cur's slot
+                    # (leaky ReLUs do not grow their argument) — one publishing launch per ResBlock pair instead of two
                     self._conv(cur, cv["w1"], t1, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, dil=d,
                                pad=(kr * d - d) // 2, bias=cv["b1"], a_slope=LRELU, act=ops.ACT_LRELU, act_slope=LRELU,
-                               x_absmax=s_cur, out_absmax=s_t1)
+                               x_absmax=s_cur)
                     last = m == len(blk["convs"]) - 1
                     dst = xs if last else (ra if cur is not ra else rb_)
                     s_dst = s_xs if last else slot()
                     self._conv(t1, cv["w2"], dst, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, pad=(kr - 1) // 2,
                                bias=cv["b2"], resid=cur, ldr=cout,
                                accumulate=(last and j > 0), div=(float(nblk) if (last and j == nblk - 1) else 1.0),
-                               x_absmax=s_t1, out_absmax=s_dst)
+                               x_absmax=s_cur, x_bound=cv["t1_bound"], out_absmax=s_dst)
                     cur, s_cur = dst, s_dst
             x, s_x, t_cur = xs, s_xs, t_out
         y = new(t_cur, 1)
         self._conv(x, self.post_w, y, T_in=t_cur, cin=x.shape[1], cout=1, k=7, m=t_cur, pad=3, a_slope=0.01,
                    act=ops.ACT_TANH, x_absmax=s_x)
-        assert n_slot[0] <= slots.numel()
+        assert n_slot[0] * ops.SLOT_W <= slots.numel()
         return y.reshape(-1)

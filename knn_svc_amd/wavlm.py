@@ -250,7 +250,7 @@ class WavLMEncoder:
             tap["conv"] = x.clone()
         f_sp = sp(cin, plan["feats"])
         feats = ops.layernorm(x, self.ln_g, self.ln_b, out_split=f_sp)
-        x_slot = torch.zeros(1, device=dev, dtype=torch.float32) if dyn else None
+        x_slot = ops.new_slot(dev) if dyn else None
         x = ops.linear(feats, self.proj_w, self.proj_b, x_split=f_sp, x_absmax=None if f_sp else slot_of(feats),
                        out_absmax=x_slot)             # [B*T, E]
         E, H, G, K = self.E, self.H, self.G, self.Kpos
@@ -282,7 +282,7 @@ class WavLMEncoder:
             e2_sp = sp(E, pl["xn2"])
             xn = ops.layernorm(x, ly["ln2_g"], ly["ln2_b"], out_split=e2_sp)
             h_sp = sp(hdim, pl["h"])
-            h_slot = torch.zeros(1, device=dev, dtype=torch.float32) if (dyn and not h_sp) else None
+            h_slot = ops.new_slot(dev) if (dyn and not h_sp) else None
             hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU, x_split=e2_sp, out_split=h_sp,
                               x_absmax=None if e2_sp else slot_of(xn), out_absmax=h_slot)
             x = ops.linear(hmid, ly["w2"], ly["b2"], resid=x, x_split=h_sp, x_absmax=h_slot)

@@ -39,15 +39,15 @@ def test_linear_outlier_channels_with_range_slot(M, K, N):
     xd, wd, bd = x.to(DEV), ops.attach_split(w.to(DEV)), b.to(DEV)
     assert float(x.abs().max()) > 4094 * 4                        # far outside the fixed-scale range
     slot = ops.absmax(xd)
-    assert float(slot) == float(x.abs().max())
-    out_slot = torch.zeros(1, device=DEV)
+    assert float(slot.max()) == float(x.abs().max())
+    out_slot = ops.new_slot(DEV)
     out = ops.linear(xd, wd, bd, x_absmax=slot, out_absmax=out_slot)
     rms, mx = _rel(out, ref)
     print(f"linear with outlier channels ({M}x{K}x{N}): rel rms {rms:.2e} max {mx:.2e}")
     assert bool(torch.isfinite(out).all()) and rms < 1.5e-6 and mx < 5e-6      # fp32-GEMM accuracy (fp32 accumulation over K)
     # the epilogue's fold of max|out| is a bound of what was stored (rows past M may add |bias|: still a bound)
     true_max = float(out.abs().max())
-    assert true_max <= float(out_slot) <= max(true_max, float(b.abs().max())) * (1 + 1e-6)
+    assert true_max <= float(out_slot.max()) <= max(true_max, float(b.abs().max())) * (1 + 1e-6)
     # the fixed default scale cannot hold these activations: documented as loud (NaN), never silently wrong
     bad = ops.linear(xd, wd, bd)
     assert not bool(torch.isfinite(bad).all())
@@ -78,7 +78,7 @@ def test_range_slot_results_do_not_depend_on_the_bound():
     xd, wd = x.to(DEV), ops.attach_split(w.to(DEV))
     a = ops.linear(xd, wd)
     b = ops.linear(xd, wd, x_absmax=ops.absmax(xd))
-    c = ops.linear(xd, wd, x_absmax=torch.full((1,), 8.0 * float(x.abs().max()), device=DEV))
+    c = ops.linear(xd, wd, x_absmax=torch.full((ops.SLOT_W,), 8.0 * float(x.abs().max()), device=DEV))
     assert float((b - c).abs().max()) < 2e-7 * float(b.abs().max())
     ea, eb = _rel(a, ref)[0], _rel(b, ref)[0]
     print(f"rel rms vs fp64: fixed scale 16 {ea:.3e}, slot-driven {eb:.3e}")
