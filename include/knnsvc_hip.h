@@ -78,15 +78,17 @@ typedef struct knnsvc_conv_desc {
     int32_t out_f16x2;                 /* 1: write out in the f16x2 split layout (scale 16) for the next GEMM;      */
                                        /* c >= 32 (multiple of 32): only columns >= c are split (QKV: K,V blocks)   */
     /* Range of the f16x2 path without host round trips (all optional, NULL / 0 = off; ignored by the fp32 / bf16x3 paths):
-     * A RANGE SLOT is 16 consecutive DEVICE floats (64 bytes): producers fold max|.| into stripe (block id % 16) of it,
-     * consumers use the maximum of the 16.  Its content is a pure function of the data (max is order-independent).
+     * A RANGE SLOT is 2048 DEVICE floats (8 KiB) used as 64 stripes of one 128-byte cache line each (float 32 i is stripe i):
+     * a producer block folds max|.| into stripe (block id % 64) with one atomicMax — atomics that meet on a cache line
+     * serialise, and a launch's first round of blocks all find the slot empty — and consumers use the maximum of the 64.
+     * Its content is a pure function of the data (max is order-independent).
      *   x_absmax / w_absmax: range slots holding an upper bound of |x| over the A operand / of |w| over the split
      *     weights; the kernel then derives the operand's power-of-two scale itself — the largest s with bound * s < 2^15
      *     (knnsvc_split_f16x2_dyn splits with the same rule, so a pre-split operand and its consumer agree by sharing a
      *     slot) — instead of a_f16x2_scale / w_f16x2_scale.  No activation range can overflow fp16 this way, and tiny
      *     tensors are lifted into the range instead of losing bits.
      *   out_absmax: range slot; the epilogue folds max|out| over everything this launch stores into it with atomicMax
-     *     (on the bit pattern: a NaN output makes the slot NaN).  The caller zeroes all 16 floats; it is the next launch's
+     *     (on the bit pattern: a NaN output makes the slot NaN).  The caller zeroes the slot; it is the next launch's
      *     x_absmax.
      *   out_f16x2_scale: scale of the split layout written under out_f16x2 (0 = 16); the consumer passes the same value
      *     as its a_f16x2_scale.
@@ -122,12 +124,12 @@ int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* ou
  * below ~0.2 / a_f16x2_scale lose relative accuracy (absolute floor 3e-8 / a_f16x2_scale per element). */
 int knnsvc_split_weight_f16x2(const float* w, int64_t rows, int32_t K, float scale, void* out, void* stream);
 
-/* The same split with the scale taken from a range slot (16 floats, see knnsvc_conv_desc): scale = the largest power of two with max(slot) * scale < 2^15
+/* The same split with the scale taken from a range slot (8 KiB, see knnsvc_conv_desc): scale = the largest power of two with max(slot) * scale < 2^15
  * (what knnsvc_conv_gemm derives from x_absmax / w_absmax).  For operands whose range is only known on the device — the
  * kNN's query and pool features (lib_ongaku_test.py:148-175 takes whatever WavLM produced). */
 int knnsvc_split_f16x2_dyn(const float* w, int64_t rows, int32_t K, const float* absmax, void* out, void* stream);
 
-/* Folds max |x[r, c]| over a [rows, cols] matrix with row pitch ld into the range slot (16 floats; atomicMax on the bit
+/* Folds max |x[r, c]| over a [rows, cols] matrix with row pitch ld into the range slot (8 KiB; atomicMax on the bit
  * pattern, NaN wins); the caller zeroes the slot.  Feeds x_absmax / w_absmax for tensors that no GEMM epilogue produced. */
 int knnsvc_absmax(const float* x, int64_t rows, int32_t cols, int32_t ld, float* slot, void* stream);
 
@@ -189,7 +191,7 @@ int knnsvc_mask_rows(float* x, int32_t batches, int32_t T, int32_t dim, int32_t 
  * driver loop ddsp_prematch_dataset.py:1195-1210).
  * ------------------------------------------------------------------------------------------ */
 /* norm[r] = sqrt(sum x^2) (torch.norm, lib_ongaku_test.py:150-151); sq[r] = sum x^2 (cdist's own term).
- * max_slot (may be NULL): range slot (16 DEVICE floats), folded with the largest row norm (atomicMax on the bit pattern; the caller
+ * max_slot (may be NULL): range slot (8 KiB), folded with the largest row norm (atomicMax on the bit pattern; the caller
  * zeroes it) — an upper bound of max|x| that costs no extra pass: the range slot the kNN's f16x2 GEMM scales by. */
 int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, float* norm, float* sq, float* max_slot,
                      void* stream);

@@ -52,21 +52,20 @@ __device__ __host__ __forceinline__ float kn_pick_scale(float absmax) {
     return s;
 }
 
-// A range slot is KN_SLOT_W = 16 consecutive floats (64 bytes): producers fold max|.| into stripe (block id % 16), consumers
-// take the maximum of the 16 (one s_load_dwordx16).  A slot's content is a pure function of the data (max is
-// order-independent), so results do not depend on scheduling or on what ran before.
-// Producer protocol (measured on the generator, 7.1 ms per 1500-frame forward without range slots): a wave first loads its
-// stripe and sends its atomicMax only when it would raise it — the load costs every short-lived block ~1 us at the end of
-// its life (+0.9 ms with all ~105 launches publishing), but unconditional atomics are far worse (+2.5 ms: even spread over
-// 128 stripes they queue up behind each other in a few L2 cache lines), and a value fetched at kernel start is stale for
-// the whole first round of blocks (+2.7 ms).  So the number of PUBLISHING launches is what is kept small: a tensor whose
-// bound follows from its producer's input bound and weights (knnsvc_conv_desc.x_bound_mul / x_bound_add) is not measured.
-constexpr int KN_SLOT_W = 16;
-__device__ __forceinline__ int kn_stripe() { return blockIdx.x & (KN_SLOT_W - 1); }
+// A range slot is KN_STRIPES = 64 floats, one per 128-byte cache line (8 KiB): a producer BLOCK folds its maximum into stripe
+// (block id % 64) with one fire-and-forget atomicMax; consumers take the maximum of the 64 (scalar loads, cached per CU).
+// Why this shape (generator at 1500 frames, 7.0 ms per forward without range slots): atomics that meet on one cache line
+// serialise at ~25 ns each, and the blocks of a launch's first round all finish at about the same time — every one of them
+// still sees an empty slot.  One float per slot with a load-and-compare first: +15..20 us per launch (+1.5 ms per forward);
+// unconditional per-wave atomics on 16 or 128 adjacent floats: +2.5 ms; a pre-check value fetched at kernel start: +2.7 ms.
+// With one atomic per block and 64 separate lines a launch of 3750 blocks queues ~60 atomics per line (~1.5 us), nothing
+// loads, nothing waits, and the slot's content is a pure function of the data (max is order-independent).
+constexpr int KN_STRIPES = 64, KN_STRIPE_FLOATS = 32;
+__device__ __forceinline__ float* kn_stripe(float* slot) { return slot + (blockIdx.x & (KN_STRIPES - 1)) * KN_STRIPE_FLOATS; }
 __device__ __forceinline__ float kn_slot_max(const float* slot) {
     unsigned m = 0;
 #pragma unroll
-    for (int i = 0; i < KN_SLOT_W; ++i) { const unsigned v = __float_as_uint(slot[i]) & 0x7FFFFFFFu; m = v > m ? v : m; }
+    for (int i = 0; i < KN_STRIPES; ++i) { const unsigned v = __float_as_uint(slot[i * KN_STRIPE_FLOATS]) & 0x7FFFFFFFu; m = v > m ? v : m; }
     return __uint_as_float(m);
 }
 
@@ -85,16 +84,23 @@ __device__ __forceinline__ void resolve_scales(ConvArgs& a) {
     if (a.x_absmax) a.a_scale = kn_pick_scale(fmaf(kn_slot_max(a.x_absmax), a.x_bound_mul, a.x_bound_add));
     if (a.w_absmax) a.w_scale = kn_pick_scale(kn_slot_max(a.w_absmax));
     if (a.x_absmax || a.w_absmax) a.out_scale = 1.0f / (a.a_scale * a.w_scale);
-    if (a.out_absmax) a.out_absmax += kn_stripe();
+    if (a.out_absmax) a.out_absmax = kn_stripe(a.out_absmax);
 }
 
 // |v| as ordered bits: NaN sorts above inf, so a NaN anywhere in the output reaches the slot (fmaxf would drop it)
 __device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
-// one atomic per wave at most, and only when it raises the stripe (fresh load first, see above)
+// block-level fold: wave maxima meet in LDS, thread 0 sends the block's ONE atomic (zero is never sent: the slot starts there)
 __device__ __forceinline__ void publish_absmax(float* stripe, unsigned m) {
+    __shared__ unsigned s_wave_max[16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load((const unsigned*)stripe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned*)stripe, m);
+    if ((threadIdx.x & 63) == 0) s_wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned bm = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) bm = s_wave_max[w] > bm ? s_wave_max[w] : bm;
+        if (bm) atomicMax((unsigned*)stripe, bm);
+    }
 }
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
@@ -556,7 +562,7 @@ template <class G, int VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     resolve_dyn(a);
-    if (a.out_absmax) a.out_absmax += kn_stripe();
+    if (a.out_absmax) a.out_absmax = kn_stripe(a.out_absmax);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
@@ -588,7 +594,7 @@ template <class G>
 __global__ __launch_bounds__(256, 3) void conv_gemm3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     resolve_dyn(a);
-    if (a.out_absmax) a.out_absmax += kn_stripe();
+    if (a.out_absmax) a.out_absmax = kn_stripe(a.out_absmax);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
     const int m0 = blockIdx.x * G::BM, n0 = blockIdx.y * G::BN;
@@ -1263,7 +1269,7 @@ namespace {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long rows, int cols, int ld, int vec,
                                                      float* __restrict__ slot) {
     const int c4 = vec ? cols >> 2 : 0;
-    slot += kn_stripe();
+    slot = kn_stripe(slot);
     unsigned m = 0;
     const long n4 = rows * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

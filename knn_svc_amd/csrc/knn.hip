@@ -363,10 +363,9 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
         if (norm) norm[row] = nr;
         // range slot: max row norm >= max |x| (bit-pattern max: a NaN row makes the slot NaN); relaxed pre-check keeps
         // the same-address atomics to the few rows that raise the maximum
-        if (max_slot) {       // a range slot is 16 floats; stripe by block, fresh load before the atomic (conv_gemm.hip)
-            unsigned* st = (unsigned*)max_slot + (blockIdx.x & 15);
+        if (max_slot) {       // a range slot is 64 stripes of one cache line each (conv_gemm.hip): one fire-and-forget atomic per row
             const unsigned b = __float_as_uint(nr) & 0x7FFFFFFFu;
-            if (b > __hip_atomic_load((const unsigned*)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st, b);
+            if (b) atomicMax((unsigned*)max_slot + (blockIdx.x & 63) * 32, b);
         }
     }
 }
@@ -394,7 +393,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t knn_rsrc(const void* p, int by
 __device__ __forceinline__ float knn_pick_scale(const float* slot) {      // == kn_pick_scale(kn_slot_max(slot)) of conv_gemm.hip
     unsigned m = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const unsigned v = __float_as_uint(slot[i]) & 0x7FFFFFFFu; m = v > m ? v : m; }
+    for (int i = 0; i < 64; ++i) { const unsigned v = __float_as_uint(slot[i * 32]) & 0x7FFFFFFFu; m = v > m ? v : m; }
     unsigned e = (m >> 23) & 0xFFu;
     e = e < 87u ? 87u : e;
     return __uint_as_float((268u - e) << 23);

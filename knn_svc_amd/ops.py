@@ -228,7 +228,7 @@ def absmax(x2d, slot=None):
     return slot
 
 
-SLOT_W = 16          # a range slot is 16 floats: producers stripe their atomics over it, consumers take the maximum
+SLOT_W = 64 * 32     # a range slot is 64 stripes of one 128-byte cache line each (float 32 i = stripe i): include/knnsvc_hip.h
 
 
 def new_slot(device) -> torch.Tensor:
