@@ -476,12 +476,18 @@ def main():
                            "t_hbm_floor_ms": round(min_bytes / 8e12 * 1e3, 4),
                            "note": "whole stage incl. norms, operand splits, top-32 selection and the RCCL all-gather merge; "
                                    "query_frames_per_s counts every rank's frames resolved against the whole pool"}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.isfile(pmc):      # measured offline with rocprofv3 --pmc (tools/pmc_traffic.py); bench.py cannot read PMCs itself
+        # measured offline with rocprofv3 --pmc (tools/pmc_traffic.py, tools/refresh_profiles.sh); bench.py cannot read PMCs itself.
+        # Newest round's file whose kernel is the one reported above.
+        import glob
+        want = "quad" if dom_tags[0] == "Q256" else "Gemm2Tile<128, 128" if dom_tags[0].startswith("F128") else None
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             t = json.load(open(pmc))
-            line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes"
-            line["roofline"]["algorithmic_bytes_per_launch"] = int(4 * dom_floats / max(1, n_launch))
+            if want and want in t.get("kernel", ""):
+                line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc)}: 2*FETCH_SIZE + WRITE_SIZE per launch, "
+                                                      "separate rocprofv3 --pmc passes")
+                line["roofline"]["algorithmic_bytes_per_launch"] = int(4 * dom_floats / max(1, n_launch))
+                break
         if ws == 1 and not a.no_cpu_baseline:
             L = step.last
             c = lambda x: x.detach().cpu()
