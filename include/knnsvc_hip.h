@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 8
+#define KNNSVC_ABI_VERSION 9
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -300,6 +300,20 @@ int knnsvc_amp_ratio(const float* spec_q, int32_t ld_q, const float* spec_pool, 
  * ------------------------------------------------------------------------------------------ */
 int knnsvc_f0_yin(const float* x, int64_t L, int32_t sample_rate, int32_t hop, float f0_floor, float f0_ceil,
                   float threshold, float zero_below, float* f0, int64_t n_frames, void* stream);
+
+/* Harvest (M. Morise, Interspeech 2017) — what pyworld.harvest computes where the reference calls it
+ * (ddsp_prematch_dataset.py:121-128: fs = 16000, f0_floor = 65, f0_ceil = 1047, frame_period = 20 ms, then `f0[f0 < 80] = 0`;
+ * :376-379 when `<stem>_f0.npy` is missing).  x: [L] fp32 at 16 kHz on the device; f0: [n_frames] fp32,
+ * n_frames = (int)(1000 L / fs / frame_period) + 1, 0 = unvoiced.  All stages run in fp64 on `stream` inside `workspace`
+ * (256-byte aligned device memory of at least the size knnsvc_f0_harvest_workspace reports: ~35 MB per second of audio);
+ * no host synchronisation.  status (device int32, may be NULL): 0, or a bit mask if a fixed-capacity list overflowed
+ * (1: more than 16 candidates in a frame, 2 / 4: section storage) — the track is then incomplete.
+ * Restates the published algorithm, pinned by oracle/f0_ref.py on the reference's two shipped harvest tracks. */
+int knnsvc_f0_harvest_workspace(int64_t L, int32_t sample_rate, float f0_floor, float f0_ceil, float frame_period,
+                                int64_t* n_frames, int64_t* bytes);
+int knnsvc_f0_harvest(const float* x, int64_t L, int32_t sample_rate, float f0_floor, float f0_ceil, float frame_period,
+                      float zero_below, float* f0, int64_t n_frames, void* workspace, int64_t workspace_bytes,
+                      int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pool side features and the additive synthesiser.

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -71,6 +71,8 @@ SIGNATURES = {
     "knnsvc_round_f16": (i32, [vp, i64, vp, vp]),
     "knnsvc_amp_ratio": (i32, [vp, i32, vp, i32, i64, vp, i64, i32, i32, vp, vp]),
     "knnsvc_f0_yin": (i32, [vp, i64, i32, i32, f32, f32, f32, f32, vp, i64, vp]),
+    "knnsvc_f0_harvest_workspace": (i32, [i64, i32, f32, f32, f32, vp, vp]),
+    "knnsvc_f0_harvest": (i32, [vp, i64, i32, f32, f32, f32, f32, vp, i64, vp, i64, vp, vp]),
     "knnsvc_reflect_pad": (i32, [vp, i64, i32, vp, vp]),
     "knnsvc_complex_mag": (i32, [vp, i64, i32, i32, vp, vp]),
     "knnsvc_harmonic_amps": (i32, [vp, vp, i64, i32, i32, vp, vp]),

@@ -54,15 +54,17 @@ def load_utterance(pth):
                               C.SAMPLE_RATE).cpu().numpy()[None]
     f0_path = os.path.splitext(str(pth))[0] + "_f0.npy"
     if not os.path.isfile(f0_path):
-        if os.environ.get("KNNSVC_F0") != "yin":
-            raise FileNotFoundError(
-                f"{f0_path} not found.  The reference would run pyworld.harvest here (ddsp_prematch_dataset.py:121-128, "
-                "376-379); pyworld is not available in this build — provide the f0 cache next to the audio file, or set "
-                "KNNSVC_F0=yin to generate it with the GPU YIN estimator (same interface and cache file; NOT Harvest: "
-                "the track, and with it the conversion, will differ from the reference's).")
-        # same bookkeeping as the reference (:376-379): compute, warn, write the cache next to the audio
-        print(f"WARNING: {f0_path} not exists, generating (GPU YIN estimator, not pyworld.harvest)...")
-        f0_new = ops.f0_yin(torch.from_numpy(np.ascontiguousarray(x[0], dtype=np.float32)).cuda()).cpu().numpy()
+        # same bookkeeping as the reference (:376-379): warn, compute, write the cache next to the audio.  The reference runs
+        # pyworld.harvest on the host here (:121-128); this build runs Harvest on the GPU (csrc/harvest.hip, fp64, pinned on
+        # the reference's own shipped tracks).  KNNSVC_F0=yin selects the YIN estimator of round 1 instead (a different,
+        # cheaper algorithm: the track, and with it the conversion, then differs from the reference's).
+        xg = torch.from_numpy(np.ascontiguousarray(x[0], dtype=np.float32)).cuda()
+        if os.environ.get("KNNSVC_F0") == "yin":
+            print(f"WARNING: {f0_path} not exists, generating (GPU YIN estimator, not harvest)...")
+            f0_new = ops.f0_yin(xg).cpu().numpy()
+        else:
+            print(f"WARNING: {f0_path} not exists, generating...")
+            f0_new = ops.f0_harvest(xg).cpu().numpy()
         np.save(f0_path, f0_new)
     f0 = np.asarray(np.load(f0_path, allow_pickle=True), dtype=np.float32)
     return np.ascontiguousarray(x[0], dtype=np.float32), f0

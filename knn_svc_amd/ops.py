@@ -643,6 +643,30 @@ def f0_yin(wav_1d, sample_rate=16000, hop=320, f0_floor=65.0, f0_ceil=1047.0, th
     return out
 
 
+def f0_harvest(wav_1d, sample_rate=16000, f0_floor=65.0, f0_ceil=1047.0, frame_period=20.0, zero_below=80.0, check_status=True):
+    """Harvest f0 track exactly as the reference asks pyworld for it (ddsp_prematch_dataset.py:121-128):
+    [L] fp32 at 16 kHz -> [int(1000 L / fs / frame_period) + 1] fp32, 0 = unvoiced, values below 80 Hz zeroed.  All stages
+    on the GPU in fp64 (csrc/harvest.hip); check_status reads the overflow flag back (one host sync)."""
+    import ctypes
+    _need(wav_1d, name="f0_harvest.wav")
+    wav_1d = wav_1d.contiguous()
+    lib = _lib.load()
+    n, nbytes = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.knnsvc_f0_harvest_workspace(wav_1d.numel(), int(sample_rate), float(f0_floor), float(f0_ceil), float(frame_period),
+                                          ctypes.byref(n), ctypes.byref(nbytes)), "f0_harvest_workspace")
+    ws = torch.empty(nbytes.value, device=wav_1d.device, dtype=torch.uint8)
+    out = torch.empty(n.value, device=wav_1d.device, dtype=torch.float32)
+    status = torch.zeros(1, device=wav_1d.device, dtype=torch.int32)
+    check(lib.knnsvc_f0_harvest(_p(wav_1d), wav_1d.numel(), int(sample_rate), float(f0_floor), float(f0_ceil), float(frame_period),
+                                float(zero_below), _p(out), n.value, _p(ws), nbytes.value, _p(status), _stream()), "f0_harvest")
+    if check_status:
+        flags = int(status.item())
+        if flags:
+            raise RuntimeError(f"f0_harvest: a fixed-capacity list overflowed (flags {flags:#x}: 1 candidates per frame, "
+                               "2 / 4 section storage); the track is incomplete")
+    return out
+
+
 # ------------------------------------------------------------------ side features + synth
 def reflect_pad(x1d, pad, extra=0):
     """-> [n + 2 pad (+ extra zeros at the end)]"""

@@ -651,20 +651,26 @@ def test_f0_yin_tracks_synthetic_ground_truth(seed):
         assert float(np.mean(est[gaps] == 0)) > 0.9                                      # unvoiced stays unvoiced
 
 
-def test_missing_f0_cache_raises_or_generates(tmp_path, monkeypatch):
-    """Without `<stem>_f0.npy` the build raises (pyworld is absent) unless KNNSVC_F0=yin opts into the GPU estimator, which
-    then writes the cache next to the audio exactly as the reference does (ddsp_prematch_dataset.py:376-379)."""
+def test_missing_f0_cache_is_generated_next_to_the_audio(tmp_path, monkeypatch):
+    """Without `<stem>_f0.npy` the track is computed (Harvest on the GPU; KNNSVC_F0=yin selects the YIN estimator) and written
+    next to the audio exactly as the reference does (ddsp_prematch_dataset.py:376-379); the second load reads the cache."""
     from knn_svc_amd import audio_io, matching
     wav, f0_true = S.synth_clip(2 * 16000, 9)
-    p = tmp_path / "a.wav"
-    audio_io.write_wav_pcm16(str(p), wav, 16000)
-    monkeypatch.delenv("KNNSVC_F0", raising=False)
-    with pytest.raises(FileNotFoundError):
-        matching.load_utterance(p)
-    monkeypatch.setenv("KNNSVC_F0", "yin")
-    w, f0 = matching.load_utterance(p)
-    assert (tmp_path / "a_f0.npy").is_file() and f0.shape == (len(w) // 320 + 1,) and f0.dtype == np.float32
-    assert np.array_equal(np.load(tmp_path / "a_f0.npy"), f0)
+    for sub, env in (("h", None), ("y", "yin")):
+        d = tmp_path / sub; d.mkdir()
+        p = d / "a.wav"
+        audio_io.write_wav_pcm16(str(p), wav, 16000)
+        if env is None:
+            monkeypatch.delenv("KNNSVC_F0", raising=False)
+        else:
+            monkeypatch.setenv("KNNSVC_F0", env)
+        w, f0 = matching.load_utterance(p)
+        assert (d / "a_f0.npy").is_file() and f0.shape == (len(w) // 320 + 1,) and f0.dtype == np.float32
+        assert np.array_equal(np.load(d / "a_f0.npy"), f0)
+        v = (f0_true[:len(f0)] > 0) & (f0 > 0)
+        assert v.sum() > 20 and np.median(np.abs(f0[v] - f0_true[:len(f0)][v]) / f0_true[:len(f0)][v]) < 0.02
+        w2, f02 = matching.load_utterance(p)
+        assert np.array_equal(f0, f02)
 
 
 def test_f0_yin_against_the_reference_samples_harvest_tracks():
