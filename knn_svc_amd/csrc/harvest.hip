@@ -452,23 +452,29 @@ __device__ __forceinline__ double hv_search_score(double f, const double* __rest
 
 __global__ __launch_bounds__(1024) void hv_merge_kernel(const double* __restrict__ s2, const double* __restrict__ cand,
                                                        const double* __restrict__ score, long nfr, const int* __restrict__ st,
-                                                       const int* __restrict__ xst, const int* __restrict__ xed, const int* __restrict__ keep,
+                                                       const int* __restrict__ xst, const int* __restrict__ xed, int* __restrict__ keep_kk,
                                                        const long* __restrict__ woff, const double* __restrict__ chan,
                                                        int* __restrict__ order, double* __restrict__ s3, double* __restrict__ s4,
                                                        int* __restrict__ gst, int* __restrict__ ged, int cap, long* __restrict__ soff,
                                                        long scratch_cap, int gap, int* __restrict__ info) {
     __shared__ int sh[16];
     __shared__ double p1[16], p2[16];
-    __shared__ int nk_s, b0_s, b1_s, mode_s;
+    __shared__ int nk_s, mode_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nsec = info[0];
-    if (tid == 0) {                                   // kept sections, stable order by extended start
+    // MergeF0 as the library does it, quirks included (the reference's shipped tracks depend on them): the order comes from an
+    // insertion pass that moves a new element at most ONE place forward, the merge starts from the first kept channel
+    // whatever the order says, and the running bounds live in that channel's slots of the (mutable) boundary list.
+    int* kk = keep_kk;                                // kept section ids, in place over the keep flags
+    int* bst = gst; int* bed = ged;                   // mutable bounds of the kept sections (the lists are rebuilt below)
+    if (tid == 0) {
         int nk = 0;
-        for (int k = 0; k < nsec; ++k) if (keep[k]) {
-            int j = nk++;
-            while (j > 0 && xst[order[j - 1]] > xst[k]) { order[j] = order[j - 1]; --j; }
-            order[j] = k;
-        }
+        for (int k = 0; k < nsec; ++k) if (keep_kk[k]) { bst[nk] = xst[k]; bed[nk] = xed[k]; kk[nk] = k; ++nk; }
+        for (int i = 0; i < nk; ++i) order[i] = i;
+        for (int i = 1; i < nk; ++i)
+            for (int j = i - 1; j >= 0; --j) {
+                if (bst[order[j]] > bst[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; } else break;
+            }
         nk_s = nk; info[1] = nk;
     }
     __syncthreads();
@@ -480,20 +486,19 @@ __global__ __launch_bounds__(1024) void hv_merge_kernel(const double* __restrict
         for (long i = tid; i < nfr; i += blockDim.x) s3[i] = 0;
         __syncthreads();
         {
-            const int k = order[0]; const double* ch = CH(k);
+            const int k = kk[0]; const double* ch = CH(k);
             const long ws = st[k] - HV_MARG > 0 ? st[k] - HV_MARG : 0;
             const long we = ws + (woff[k + 1] - woff[k]) - 1;
             for (long i = ws + tid; i <= we; i += blockDim.x) s3[i] = ch[i];
-            if (tid == 0) { b0_s = xst[k]; b1_s = xed[k]; }
         }
         __syncthreads();
         for (int q = 1; q < nk; ++q) {
-            const int k = order[q]; const double* ch = CH(k);
-            const int a = xst[k], e = xed[k], b0 = b0_s, b1 = b1_s;
+            const int o = order[q], k = kk[o]; const double* ch = CH(k);
+            const int a = bst[o], e = bed[o], b0 = bst[0], b1 = bed[0];
             __syncthreads();
             if (a - b1 > 0) {
                 for (long i = a + tid; i <= e; i += blockDim.x) s3[i] = ch[i];
-                if (tid == 0) { b0_s = a; b1_s = e; }
+                if (tid == 0) { bst[0] = a; bed[0] = e; }
             } else if (b0 <= a && b1 >= e) {
                 // inside what is already merged
             } else {
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(1024) void hv_merge_kernel(const double* __restrict
                 __syncthreads();
                 const long from = mode_s ? b1 : a;
                 for (long i = from + tid; i <= e; i += blockDim.x) s3[i] = ch[i];
-                if (tid == 0) b1_s = e;
+                if (tid == 0) bed[0] = e;
             }
             __syncthreads();
         }
@@ -700,7 +705,7 @@ extern "C" int knnsvc_f0_harvest(const float* x, int64_t L, int32_t sample_rate,
     HV_LAUNCH(hv_extend_kernel, (256), (256), (const double*)D(p.o_s2), (const double*)D(p.o_cand2), p.nfr, (const int*)I(p.o_st),
               (const int*)I(p.o_ed), (const long*)LL(p.o_woff), D(p.o_chan), I(p.o_xst), I(p.o_xed), I(p.o_keep), (const int*)I(p.o_info), 0.18);
     HV_LAUNCH(hv_merge_kernel, (1), (1024), (const double*)D(p.o_s2), (const double*)D(p.o_cand2), (const double*)D(p.o_score2), p.nfr,
-              (const int*)I(p.o_st), (const int*)I(p.o_xst), (const int*)I(p.o_xed), (const int*)I(p.o_keep), (const long*)LL(p.o_woff),
+              (const int*)I(p.o_st), (const int*)I(p.o_xst), (const int*)I(p.o_xed), I(p.o_keep), (const long*)LL(p.o_woff),
               (const double*)D(p.o_chan), I(p.o_order), D(p.o_s3), D(p.o_s4), I(p.o_gst), I(p.o_ged), p.scap, LL(p.o_soff), p.scratch_cap, 9, I(p.o_info));
     if (hipMemsetAsync(ws + p.o_sm, 0, p.nfr * 8, st) != hipSuccess) return knnsvc_fail(KNNSVC_EHIP, "f0_harvest: memset failed");
     HV_LAUNCH(hv_smooth_kernel, ((unsigned)cdiv64(p.scap, 64)), (64), (const double*)D(p.o_s4), p.nfr, (const int*)I(p.o_gst),

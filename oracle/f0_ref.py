@@ -4,9 +4,11 @@
 pyworld (WORLD, M. Morise; pinned ``^0.3.5`` in the reference's pyproject.toml) is a third-party dependency that is ABSENT
 offline, so this is a restatement of the published algorithm (M. Morise, "Harvest: A high-performance fundamental frequency
 estimator from speech signals", Interspeech 2017, and the structure of WORLD's harvest.cpp) — NOT a port validated against the
-library itself.  PARITY PARTIALLY PINNED: the only pyworld outputs available are the two harvest tracks the reference ships
-next to its sample clips (``sample_content/*_f0.npy``, 3002 frames each, committed under tests/golden/sample_content_full/);
-tests/test_oracle_golden.py measures voicing agreement and pitch deviation against them.
+library itself.  PINNED on the only pyworld outputs available: the two harvest tracks the reference ships next to its sample
+clips (``sample_content/*_f0.npy``, 3002 frames each, committed under tests/golden/sample_content_full/).  On the full
+minute of both clips this restatement gives the same voicing decision and the same pitch (to the fixtures' fp32 rounding,
+1.5e-5 Hz) on all 6004 frames; tests/test_oracle_golden.py checks 12 s heads on the CPU, tests/test_gpu_f0.py the full clips
+through the GPU front end, which in turn is compared with this file.
 
 Pipeline: decimate to 8 kHz (zero-phase IIR) and remove DC -> bank of Nuttall-windowed band-pass filters, 40 per octave ->
 per channel, f0 from four kinds of zero-crossing intervals -> per frame (1 ms), candidates = channel runs of >= 10 agreeing
@@ -246,22 +248,34 @@ def _fix_contour(cand, score, allowed1=0.008, vmin=6, allowed=0.18, gap=9):
         if m > 0 and 2200.0 / m < ed2 - st2:
             chans.append((st2, ed2, ch))
     if chans:
-        chans.sort(key=lambda t: t[0])
+        # MergeF0 as the library does it, quirks included (the shipped tracks depend on them): the order comes from an
+        # insertion pass that moves a new element at most ONE place forward; the merge starts from channel 0 whatever the
+        # order says; and the running bounds live in channel 0's slots of the boundary list.
+        bl = [[c[0], c[1]] for c in chans]
+        order = list(range(len(chans)))
+        for i in range(1, len(chans)):
+            for j in range(i - 1, -1, -1):
+                if bl[order[j]][0] > bl[order[i]][0]:
+                    order[i], order[j] = order[j], order[i]
+                else:
+                    break
         merged = chans[0][2].copy()
-        b0, b1 = chans[0][0], chans[0][1]
-        for st, ed, ch in chans[1:]:
+        for i in range(1, len(chans)):
+            st, ed = bl[order[i]]
+            ch = chans[order[i]][2]
+            b0, b1 = bl[0]
             if st - b1 > 0:
-                merged[st:ed + 1] = ch[st:ed + 1]; b0, b1 = st, ed
+                merged[st:ed + 1] = ch[st:ed + 1]; bl[0] = [st, ed]
             elif b0 <= st and b1 >= ed:
                 pass
             else:
-                sc1 = sum(_search_score(merged[i], cand[i], score[i]) for i in range(st, b1 + 1))
-                sc2 = sum(_search_score(ch[i], cand[i], score[i]) for i in range(st, b1 + 1))
+                sc1 = sum(_search_score(merged[i2], cand[i2], score[i2]) for i2 in range(st, b1 + 1))
+                sc2 = sum(_search_score(ch[i2], cand[i2], score[i2]) for i2 in range(st, b1 + 1))
                 if sc1 > sc2:
                     merged[b1:ed + 1] = ch[b1:ed + 1]
                 else:
                     merged[st:ed + 1] = ch[st:ed + 1]
-                b1 = ed
+                bl[0][1] = ed
         out = merged
     # step 4: short gaps
     s4 = out.copy()
