@@ -396,7 +396,8 @@ __device__ __forceinline__ double hv_select(double ref, const double* __restrict
 // one wave per section: copy the section into its window of `chan`, extend forward then backward, decide whether to keep it
 __global__ __launch_bounds__(256) void hv_extend_kernel(const double* __restrict__ s2, const double* __restrict__ cand, long nfr,
                                                        const int* __restrict__ st, const int* __restrict__ ed, const long* __restrict__ woff,
-                                                       double* __restrict__ chan, int* __restrict__ xst, int* __restrict__ xed,
+                                                       const double* __restrict__ score, double* __restrict__ chan,
+                                                       double* __restrict__ chs, int* __restrict__ xst, int* __restrict__ xed,
                                                        int* __restrict__ keep, const int* __restrict__ info, double allowed) {
     const int lane = threadIdx.x & 63;
     const int nsec = info[0];
@@ -438,29 +439,28 @@ __global__ __launch_bounds__(256) void hv_extend_kernel(const double* __restrict
         sum = wave_sum_d(sum);
         const double m = so_f > so_b ? sum / (double)(so_f - so_b) : 0.0;
         if (lane == 0) { xst[k] = so_b; xed[k] = so_f; keep[k] = (m > 0 && 2200.0 / m < (double)(so_f - so_b)) ? 1 : 0; }
+        // SearchScore of every value of the channel (best score among the frame's candidates equal to it): the merge sums these
+        double* cs = chs + woff[k] - ws;
+        for (long j = ws + lane; j <= we; j += 64) {
+            const double f = ch[j]; double b = 0;
+            if (f != 0) { const double* c = cand + j * HV_NS; const double* sc = score + j * HV_NS;
+                          for (int q = 0; q < HV_NS; ++q) if (c[q] == f && sc[q] > b) b = sc[q]; }
+            cs[j] = b;
+        }
     }
 }
 
-// score of value f among the candidates of one frame (exact match), by one wave
-__device__ __forceinline__ double hv_search_score(double f, const double* __restrict__ c, const double* __restrict__ s, int lane) {
-    double b = 0;
-    for (int j = lane; j < HV_NS; j += 64) if (c[j] == f && s[j] > b) b = s[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(b, o, 64); b = t > b ? t : b; }
-    return b;
-}
-
-__global__ __launch_bounds__(1024) void hv_merge_kernel(const double* __restrict__ s2, const double* __restrict__ cand,
-                                                       const double* __restrict__ score, long nfr, const int* __restrict__ st,
+__global__ __launch_bounds__(1024) void hv_merge_kernel(const double* __restrict__ s2, const double* __restrict__ chs,
+                                                       double* __restrict__ ms, long nfr, const int* __restrict__ st,
                                                        const int* __restrict__ xst, const int* __restrict__ xed, int* __restrict__ keep_kk,
                                                        const long* __restrict__ woff, const double* __restrict__ chan,
                                                        int* __restrict__ order, double* __restrict__ s3, double* __restrict__ s4,
                                                        int* __restrict__ gst, int* __restrict__ ged, int cap, long* __restrict__ soff,
                                                        long scratch_cap, int gap, int* __restrict__ info) {
     __shared__ int sh[16];
-    __shared__ double p1[16], p2[16];
+    __shared__ double p1[1024], p2[1024];
     __shared__ int nk_s, mode_s;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const int nsec = info[0];
     // MergeF0 as the library does it, quirks included (the reference's shipped tracks depend on them): the order comes from an
     // insertion pass that moves a new element at most ONE place forward, the merge starts from the first kept channel
@@ -480,43 +480,39 @@ __global__ __launch_bounds__(1024) void hv_merge_kernel(const double* __restrict
     __syncthreads();
     const int nk = nk_s;
     auto CH = [&](int k) { const long ws = st[k] - HV_MARG > 0 ? st[k] - HV_MARG : 0; return chan + woff[k] - ws; };
+    auto CS = [&](int k) { const long ws = st[k] - HV_MARG > 0 ? st[k] - HV_MARG : 0; return chs + woff[k] - ws; };
     if (nk == 0) {
         for (long i = tid; i < nfr; i += blockDim.x) s3[i] = s2[i];
     } else {
-        for (long i = tid; i < nfr; i += blockDim.x) s3[i] = 0;
+        for (long i = tid; i < nfr; i += blockDim.x) { s3[i] = 0; ms[i] = 0; }
         __syncthreads();
         {
-            const int k = kk[0]; const double* ch = CH(k);
+            const int k = kk[0]; const double* ch = CH(k); const double* cs = CS(k);
             const long ws = st[k] - HV_MARG > 0 ? st[k] - HV_MARG : 0;
             const long we = ws + (woff[k + 1] - woff[k]) - 1;
-            for (long i = ws + tid; i <= we; i += blockDim.x) s3[i] = ch[i];
+            for (long i = ws + tid; i <= we; i += blockDim.x) { s3[i] = ch[i]; ms[i] = cs[i]; }
         }
         __syncthreads();
         for (int q = 1; q < nk; ++q) {
-            const int o = order[q], k = kk[o]; const double* ch = CH(k);
+            const int o = order[q], k = kk[o]; const double* ch = CH(k); const double* cs = CS(k);
             const int a = bst[o], e = bed[o], b0 = bst[0], b1 = bed[0];
             __syncthreads();
             if (a - b1 > 0) {
-                for (long i = a + tid; i <= e; i += blockDim.x) s3[i] = ch[i];
+                for (long i = a + tid; i <= e; i += blockDim.x) { s3[i] = ch[i]; ms[i] = cs[i]; }
                 if (tid == 0) { bst[0] = a; bed[0] = e; }
             } else if (b0 <= a && b1 >= e) {
                 // inside what is already merged
             } else {
+                // score sums over the overlap: the same (fixed) association for both, so equal terms give equal sums
                 double a1 = 0, a2 = 0;
-                for (long i = a + wv; i <= b1; i += 16) {
-                    a1 += hv_search_score(s3[i], cand + i * HV_NS, score + i * HV_NS, lane);
-                    a2 += hv_search_score(ch[i], cand + i * HV_NS, score + i * HV_NS, lane);
-                }
-                if (lane == 0) { p1[wv] = a1; p2[wv] = a2; }
+                for (long i = a + tid; i <= b1; i += blockDim.x) { a1 += ms[i]; a2 += cs[i]; }
+                p1[tid] = a1; p2[tid] = a2;
                 __syncthreads();
-                if (tid == 0) {
-                    double t1 = 0, t2 = 0;
-                    for (int w = 0; w < 16; ++w) { t1 += p1[w]; t2 += p2[w]; }
-                    mode_s = t1 > t2 ? 1 : 0;
-                }
+                for (int w = 512; w > 0; w >>= 1) { if (tid < w) { p1[tid] += p1[tid + w]; p2[tid] += p2[tid + w]; } __syncthreads(); }
+                if (tid == 0) mode_s = p1[0] > p2[0] ? 1 : 0;
                 __syncthreads();
                 const long from = mode_s ? b1 : a;
-                for (long i = from + tid; i <= e; i += blockDim.x) s3[i] = ch[i];
+                for (long i = from + tid; i <= e; i += blockDim.x) { s3[i] = ch[i]; ms[i] = cs[i]; }
                 if (tid == 0) bed[0] = e;
             }
             __syncthreads();
@@ -595,7 +591,7 @@ __global__ void hv_sample_kernel(const double* __restrict__ sm, long nfr, double
 struct HvPlan {
     long L, text, ylen, ypad_len, ld, nfr, nout, ecap, chan_cap, scratch_cap; int nch, scap;
     size_t o_t1, o_t2, o_mean, o_ypad, o_bf0, o_hlen, o_filt, o_events, o_ecount, o_raw, o_cand0, o_cand, o_score, o_cand2, o_score2,
-           o_base, o_s1, o_s2, o_s3, o_s4, o_sm, o_st, o_ed, o_xst, o_xed, o_keep, o_order, o_gst, o_ged, o_woff, o_soff, o_chan,
+           o_base, o_s1, o_s2, o_s3, o_s4, o_sm, o_st, o_ed, o_xst, o_xed, o_keep, o_order, o_gst, o_ged, o_woff, o_soff, o_chan, o_chs, o_ms,
            o_scratch, o_info, total;
 };
 
@@ -625,7 +621,7 @@ static HvPlan hv_plan(long L, double fs, double f0_floor, double f0_ceil, double
     // sections after step 2 are >= 7 frames long and >= 1 frame apart; after step 4 >= 7 long and >= 9 apart
     p.chan_cap = p.nfr + (long)(2 * HV_MARG + 1) * (p.nfr / 8 + 1);
     p.scratch_cap = p.nfr + 600 + (long)(2 * HV_SMOOTH_MARG + 1) * (p.nfr / 16 + 2);
-    p.o_chan = take((size_t)p.chan_cap * 8);
+    p.o_chan = take((size_t)p.chan_cap * 8); p.o_chs = take((size_t)p.chan_cap * 8); p.o_ms = take(p.nfr * 8);
     p.o_scratch = take((size_t)p.scratch_cap * 8);
     p.o_info = take(64);
     p.total = o;
@@ -703,8 +699,9 @@ extern "C" int knnsvc_f0_harvest(const float* x, int64_t L, int32_t sample_rate,
     HV_LAUNCH(hv_step2_kernel, (1), (1024), (const double*)D(p.o_s1), D(p.o_s2), p.nfr, 6, I(p.o_st), I(p.o_ed), p.scap, LL(p.o_woff),
               p.chan_cap, I(p.o_info));
     HV_LAUNCH(hv_extend_kernel, (256), (256), (const double*)D(p.o_s2), (const double*)D(p.o_cand2), p.nfr, (const int*)I(p.o_st),
-              (const int*)I(p.o_ed), (const long*)LL(p.o_woff), D(p.o_chan), I(p.o_xst), I(p.o_xed), I(p.o_keep), (const int*)I(p.o_info), 0.18);
-    HV_LAUNCH(hv_merge_kernel, (1), (1024), (const double*)D(p.o_s2), (const double*)D(p.o_cand2), (const double*)D(p.o_score2), p.nfr,
+              (const int*)I(p.o_ed), (const long*)LL(p.o_woff), (const double*)D(p.o_score2), D(p.o_chan), D(p.o_chs), I(p.o_xst), I(p.o_xed), I(p.o_keep),
+              (const int*)I(p.o_info), 0.18);
+    HV_LAUNCH(hv_merge_kernel, (1), (1024), (const double*)D(p.o_s2), (const double*)D(p.o_chs), D(p.o_ms), p.nfr,
               (const int*)I(p.o_st), (const int*)I(p.o_xst), (const int*)I(p.o_xed), I(p.o_keep), (const long*)LL(p.o_woff),
               (const double*)D(p.o_chan), I(p.o_order), D(p.o_s3), D(p.o_s4), I(p.o_gst), I(p.o_ged), p.scap, LL(p.o_soff), p.scratch_cap, 9, I(p.o_info));
     if (hipMemsetAsync(ws + p.o_sm, 0, p.nfr * 8, st) != hipSuccess) return knnsvc_fail(KNNSVC_EHIP, "f0_harvest: memset failed");
