@@ -30,13 +30,29 @@ def world():
     return 0, 1
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """A gloo group given DEVICE tensors: the collective travels through host memory.  This is the rehearsal mode — several
+    ranks sharing one GPU (RCCL refuses two ranks on one device) run the real HIP kernels and the real multi-rank host
+    logic, only the transport differs (tests/test_gpu_dist2.py).  Production groups are "nccl" (= RCCL over xGMI)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_gather_into(out: torch.Tensor, t: torch.Tensor, async_op=False):
+    if _host_staged(t):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, t.contiguous().cpu())
+        out.copy_(o)
+        return None
+    return dist.all_gather_into_tensor(out, t.contiguous(), async_op=async_op)
+
+
 def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
     """Concatenate equal-shaped [n, ...] tensors of every rank along dim 0 (rank order)."""
     _r, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
         return t                      # single process without a process group
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous())
+    _all_gather_into(out, t)
     return out
 
 
@@ -48,8 +64,8 @@ def all_gather_rows_async(t: torch.Tensor):
     if not (dist.is_available() and dist.is_initialized()):
         return t, (lambda: None)
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    work = dist.all_gather_into_tensor(out, t.contiguous(), async_op=True)
-    return out, work.wait
+    work = _all_gather_into(out, t, async_op=True)
+    return out, (work.wait if work is not None else (lambda: None))
 
 
 def shard_rows(n_local: int, device) -> list:
@@ -59,7 +75,7 @@ def shard_rows(n_local: int, device) -> list:
     _r, ws = world()
     mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
     out = torch.empty(ws, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, mine)
+    _all_gather_into(out, mine)
     return [int(v) for v in out.tolist()]
 
 
@@ -96,6 +112,8 @@ def raise_if_any_nan():
     f = torch.stack([x.reshape(()) for x in _NAN_FLAGS]).max().reshape(1)
     _NAN_FLAGS.clear()
     if dist.is_available() and dist.is_initialized():
+        if _host_staged(f):
+            f = f.cpu()
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
     if int(f.item()) != 0:
         from . import ops
@@ -112,6 +130,12 @@ def all_to_all_rows(t: torch.Tensor, send_rows, recv_rows) -> torch.Tensor:
     rows received, [sum(recv_rows), ...], grouped by sender in rank order.  One ``all_to_all_single`` (RCCL: every
     peer pair uses its own xGMI link), so a rank receives only what it asked for."""
     out = torch.empty((int(sum(recv_rows)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if _host_staged(t):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, t.contiguous().cpu(), output_split_sizes=[int(r) for r in recv_rows],
+                               input_split_sizes=[int(r) for r in send_rows])
+        out.copy_(o)
+        return out
     dist.all_to_all_single(out, t.contiguous(), output_split_sizes=[int(r) for r in recv_rows],
                            input_split_sizes=[int(r) for r in send_rows])
     return out
