@@ -57,7 +57,7 @@ class GemmTimer:
         # candidates for "the dominant kernel": both instantiations of conv_gemm2_kernel<Gemm2Tile<128,128,...>> (A fp32 / A
         # pre-split) count as one kernel, conv_gemm2quad_kernel<Gemm2QuadR> (long-K launches) as another; summary() reports the
         # one with more time in the step and carries the other along as `secondary`
-        self.families = {"f16x2": (("F128", "F128a2"), ("Q256",)), "bf16x3": (("H128",),), "fp32": (("G128v8",),)}[ops.gemm_mode()]
+        self.families = {"f16x2": (("F128", "F128a2"), ("Q256S",), ("Q256",)), "bf16x3": (("H128",),), "fp32": (("G128v8",),)}[ops.gemm_mode()]
         self.dominant = tuple(t for fam in self.families for t in fam)
         self.fam_bytes = {}
         self.dom_bytes = 0
@@ -422,6 +422,7 @@ def main():
         value = (1 if STRONG else ws) * SRC_SECONDS * a.steps / dt      # strong: ONE conversion per step, all ranks on it
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak, mfmas, kernel_name = {
+            "Q256S": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2quad_kernel<Gemm2QuadS> (implicit GEMM, 256x256 block / 128x128 wave tiles of v_mfma_f32_16x16x32_f16, fp32 emulated as 3 fp16 MFMAs)"),
             "Q256": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2quad_kernel<Gemm2QuadR> (implicit GEMM, 256x256 block / 128x128 wave tiles, fp32 emulated as 3 fp16 MFMAs)"),
             "F128": (F16X2_PEAK_TFLOPS, 3, "conv_gemm2_kernel<Gemm2Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 3 fp16 MFMAs)"),
             "H128": (BF16X3_PEAK_TFLOPS, 6, "conv_gemm3_kernel<Gemm3Tile<128,128,2,2,2,2>> (implicit GEMM, fp32 emulated as 6 bf16 MFMAs)"),
@@ -492,7 +493,7 @@ def main():
         # measured offline with rocprofv3 --pmc (tools/pmc_traffic.py, tools/refresh_profiles.sh); bench.py cannot read PMCs itself.
         # Newest round's file whose kernel is the one reported above.
         import glob
-        want = "quad" if dom_tags[0] == "Q256" else "Gemm2Tile<128, 128" if dom_tags[0].startswith("F128") else None
+        want = {"Q256S": "Gemm2QuadS", "Q256": "Gemm2QuadR"}.get(dom_tags[0], "Gemm2Tile<128, 128" if dom_tags[0].startswith("F128") else None)
         for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             t = json.load(open(pmc))
             if want and want in t.get("kernel", ""):

@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 9
+#define KNNSVC_ABI_VERSION 10
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -105,6 +105,11 @@ typedef struct knnsvc_conv_desc {
      * exact-length launch: the generator's frame-count buckets (hifigan/ddsp_models.py:176-233 is fully convolutional). */
     const int32_t* n_dyn; int32_t dyn_t_in_mul; int32_t dyn_t_in_add; int32_t dyn_m_mul; int32_t dyn_m_add; int32_t dyn_t_out_mul;
     float x_bound_mul; float x_bound_add;
+    /* 1: always the 128x128-tile kernel, whatever the launch size.  The default picks the 256x256-tile kernel for large
+     * launches; the two sum over K in different groupings, so a row's result would depend (in the last bit) on how many other
+     * rows and columns the launch has.  The distance GEMM of the kNN sets this: a pool shard of any size gives the distances the
+     * whole pool gives (device-count invariance of the sharded search, lib_ongaku_test.py:148-175 is one formula). */
+    int32_t fixed_tile;
 } knnsvc_conv_desc;
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("x_absmax", vp), ("w_absmax", vp), ("out_absmax", vp), ("out_f16x2_scale", f32),
         ("n_dyn", vp), ("dyn_t_in_mul", i32), ("dyn_t_in_add", i32), ("dyn_m_mul", i32), ("dyn_m_add", i32), ("dyn_t_out_mul", i32),
         ("x_bound_mul", f32), ("x_bound_add", f32),
+        ("fixed_tile", i32),
     ]
 
 

@@ -466,8 +466,9 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
                                                    int m0, int n0, int b, int g) {
     typedef __attribute__((address_space(3))) float lds_f;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
-    constexpr int PITCH = G::TN * 32 + 4;                          // floats per patch row (+4: rows 4 apart land on other banks)
-    constexpr int TRIPS = (32 * G::TN * 32 / 4) / 64;              // float4 per lane and band
+    constexpr int ETN = G::NR == 16 ? G::TN : G::TN / 2, ETM = G::NR == 16 ? G::TM : G::TM / 2;   // wave tile in 32 x 32 units
+    constexpr int PITCH = ETN * 32 + 4;                          // floats per patch row (+4: rows 4 apart land on other banks)
+    constexpr int TRIPS = (32 * ETN * 32 / 4) / 64;              // float4 per lane and band
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     lds_f* patch = (lds_f*)lds_generic + wave * (32 * PITCH);
@@ -476,10 +477,10 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
     const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
     const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, ((a.m - 1) * a.ldo + a.n) * 4);
     const __amdgpu_buffer_rsrc_t r_rsrc = uniform_rsrc(rz ? (const void*)rz : (const void*)oz, rz ? ((a.m - 1) * a.ldr + a.n) * 4 : 0);
-    const int wrow0 = m0 + (wave / G::WN) * G::TM * 32, wcol0 = n0 + (wave % G::WN) * G::TN * 32;
+    const int wrow0 = m0 + (wave / G::WN) * ETM * 32, wcol0 = n0 + (wave % G::WN) * ETN * 32;
     // in the read-back loop a lane always owns the same four columns: (lane % 32) * 4 .. + 3 of the wave tile
-    const int c = (lane & (G::TN * 8 - 1)) * 4, n = wcol0 + c;
-    const int row_in_trip = lane / (G::TN * 8);                   // trip `it` covers rows it * (64 / (TN*8)) + this
+    const int c = (lane & (ETN * 8 - 1)) * 4, n = wcol0 + c;
+    const int row_in_trip = lane / (ETN * 8);                   // trip `it` covers rows it * (64 / (TN*8)) + this
     const bool nv = n < a.n;                                       // n % 4 == 0 and a.n % 4 == 0: all four columns or none
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (bz && nv) {
@@ -490,16 +491,26 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
     const int act = a.act;
     unsigned amax = 0;
 #pragma unroll
-    for (int i = 0; i < G::TM; ++i) {
+    for (int i = 0; i < ETM; ++i) {
+        if constexpr (G::NR == 16) {
 #pragma unroll
-        for (int j = 0; j < G::TN; ++j)
+            for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + li] = acc[i][j][r] * a.out_scale;   // power of two: exact
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + li] = acc[i][j][r] * a.out_scale;   // power of two: exact
+        } else {                      // 16x16 tiles: C at col = lane & 15, row = 4 (lane >> 4) + reg; a band is two tile rows
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        patch[(t * 16 + 4 * (lane >> 4) + r) * PITCH + j * 16 + (lane & 15)] = acc[2 * i + t][j][r] * a.out_scale;
+        }
         // the patch is private to this wave and LDS operations of one wave complete in order: no barrier.
         // Software-pipelined by one trip: the LDS read and the residual / accumulate loads of trip it + 1 are in flight while
         // trip it runs its arithmetic and its store (the loop is rolled, so nothing else would hide their latency).
-        const int rstep = 64 / (G::TN * 8);
+        const int rstep = 64 / (ETN * 8);
         const int mrow0 = wrow0 + i * 32 + row_in_trip;
         auto ld_patch = [&](int it) -> f32x4 { return *(const lds_f4*)(patch + (it * rstep + row_in_trip) * PITCH + c); };
         auto ld_res = [&](int it) -> f32x4 {
@@ -724,13 +735,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2dma_kernel(ConvArgs a) {
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
 
-    f32x16 acc[G::TM][G::TN];
+    typename G::acc_t acc[G::TM][G::TN];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i)
 #pragma unroll
         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < G::NR; ++r) acc[i][j][r] = 0.f;
     const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
     auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
     // wave-uniform walk over (tap, channel): 128 bytes per slab inside a tap, then on to the next tap's first channel
@@ -781,13 +792,13 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm2ring_kernel(ConvArgs a) {
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
 
-    f32x16 acc[G::TM][G::TN];
+    typename G::acc_t acc[G::TM][G::TN];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i)
 #pragma unroll
         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < G::NR; ++r) acc[i][j][r] = 0.f;
     const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
     auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
     // wave-uniform walk over (tap, channel): 128 bytes per slab inside a tap, then on to the next tap's first channel
@@ -851,13 +862,13 @@ __global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
 
-    f32x16 acc[G::TM][G::TN];
+    typename G::acc_t acc[G::TM][G::TN];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i)
 #pragma unroll
         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < G::NR; ++r) acc[i][j][r] = 0.f;
     const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
     auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
     int c_in_tap = 0, uoff = 0;
@@ -875,7 +886,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
+              for (int r = 0; r < G::NR; ++r) sink += acc[i][j][r];
       if (sink == 123456.789f) a.out[threadIdx.x] = sink; }
 #else
 #ifdef KN_T_LINEPI         // timing aid: the column-per-lane epilogue instead of the LDS-transposed one
@@ -1043,8 +1054,9 @@ using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
 using D128 = Gemm2Dma<128, 128, 2, 2, 2, 2>;
 using R128 = Gemm2Ring<128, 128, 2, 2, 2, 2>;
 using R128x2 = Gemm2Ring<128, 128, 2, 2, 2, 2, 2>;
-using Q256 = Gemm2QuadR;          // register-staged (default)
+using Q256 = Gemm2QuadR;          // register-staged, 32x32x16 MFMA (KNNSVC_QUAD16=0)
 using Q256D = Gemm2Quad<4>;        // LDS-DMA ring (KNNSVC_QUAD_DMA=1, A/B)
+using Q256S = Gemm2QuadS;          // 16x16x32 MFMA, 32-k slabs (default)
 using R512 = Gemm2Ring<256, 256, 2, 2, 4, 4, 3>;       // 128x128 wave tiles, 256 accumulator registers, one block per CU
 using R256 = Gemm2Ring<256, 128, 2, 2, 4, 2, 3>;       // 128x64 wave tiles, 72 KB ring: two blocks per CU     // 2-stage ring: 32 KB, four blocks per CU
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
@@ -1160,23 +1172,31 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
                 { g_last_kernel = "F256"; return launch2big<F256>(a, d->batches, st); }
         }
-        if (a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
+        if (!d->fixed_tile && a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
             (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
             d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
             d->bias_gstride % 4 == 0) {
-            // 256x256 block, 128x128 wave tiles, hand-pipelined loop (Gemm2QuadR): KNNSVC_QUAD=0 switches it off, =2 forces it
-            // for every qualifying launch.  Default: long-K launches (K >= 1536: FFN2, the conv stack) with at least ~two rounds
-            // of tiles over the chip and no transcendental epilogue.  Measured under sustained load with the real epilogues
-            // (tools/quad_epi_ab.sh): FFN2 372 vs 339 TFLOP/s, conv stack +4..9 %, but FFN1 278 vs 316 and out-proj 254 vs 281 —
-            // one block per CU exposes its whole epilogue (129 M erf evaluations of FFN1 have no other block's MFMAs to hide
-            // under), and a K = 1024 tile spends a third of its life there.
+            // 256x256 block, 128x128 wave tiles, hand-pipelined loop: KNNSVC_QUAD=0 switches it off, =2 forces it for every
+            // qualifying launch.  Default kernel: Gemm2QuadS (v_mfma_f32_16x16x32_f16, 32-k slabs); KNNSVC_QUAD16=0 selects its
+            // predecessor Gemm2QuadR (32x32x16, 16-k half slabs), KNNSVC_QUAD_DMA=1 the LDS-DMA ring.  Default rule: K >= 1024
+            // and at least ~two rounds of tiles over the chip.  Measured under sustained load with the real epilogues
+            // (tools/quad16_ab.sh; QuadS / QuadR / 128x128 kernel, TFLOP/s): FFN2 437 / 381 / 340, QKV 374 / 324 / 328,
+            // FFN1 (GELU) 316 / 283 / 316 — with the 16x16x32 MFMA the quad tile wins or ties everywhere, so every large GEMM of
+            // the encoder takes it (end to end 649 -> 680 xRT).  KNNSVC_QUAD_KMIN / KNNSVC_QUAD_GELU=0 restore the old rule
+            // (K >= 1536, no transcendental epilogue) for A/B runs.
             const char* qe = getenv("KNNSVC_QUAD");      // read per launch: tests and A/B runs switch it inside one process
             const int quad = qe ? atoi(qe) : 1;
             const long tiles = cdiv64(a.m, 256) * cdiv64(d->n, 256) * d->batches * d->groups;
-            if (quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448 && a.K >= 1536 && d->act != KNNSVC_ACT_GELU && d->act != KNNSVC_ACT_TANH)) {
+            const char* qk = getenv("KNNSVC_QUAD_KMIN");
+            const int kmin = qk ? atoi(qk) : 1024;
+            const char* qg = getenv("KNNSVC_QUAD_GELU");
+            const bool transc_ok = !(qg && qg[0] == '0') || (d->act != KNNSVC_ACT_GELU && d->act != KNNSVC_ACT_TANH);
+            if (quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448 && a.K >= kmin && transc_ok)) {
                 const char* qd = getenv("KNNSVC_QUAD_DMA");
                 if (qd && qd[0] == '1') { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
-                g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st);
+                const char* q16 = getenv("KNNSVC_QUAD16");
+                if (q16 && q16[0] == '0') { g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st); }
+                g_last_kernel = "Q256S"; return launch2quad<Q256S>(a, d->batches, st);
             }
         }
         if (d->n > 64 && a.x_split) {

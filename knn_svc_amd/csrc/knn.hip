@@ -399,6 +399,9 @@ __device__ __forceinline__ float knn_pick_scale(const float* slot) {      // == 
     return __uint_as_float((268u - e) << 23);
 }
 
+// Gemm2QuadR, not the faster Gemm2QuadS: its 32x32x16 MFMAs sum over K in the same grouping as the 128x128 kernel of the
+// dot-matrix route, so both routes (and pool shards of any size) give the same dot-product BITS — the distances, and with them
+// the order of near-ties, do not depend on the route (tests: fused == dot-matrix, sharded == unsharded, bit for bit).
 using QG = Gemm2QuadR;
 constexpr int SCR_LIST = 4096;                       // survivors one 256x256 tile can stage in LDS
 
@@ -421,13 +424,13 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     const int m0 = (grp * 8 + (rem & 7)) * 256, n0 = (c0 + (rem >> 3)) * 256;
     if (m0 >= nq) return;
 
-    f32x16 acc[QG::TM][QG::TN];
+    typename QG::acc_t acc[QG::TM][QG::TN];
 #pragma unroll
     for (int i = 0; i < QG::TM; ++i)
 #pragma unroll
         for (int j = 0; j < QG::TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < QG::NR; ++r) acc[i][j][r] = 0.f;
     const int M = (int)nq, row_bytes = dim * 4;
     auto row_off = [&](int m) -> int { return m < M ? m * row_bytes : QG::OOB_OFF; };
     auto step = [&](int kt) -> int { return kt * 128; };
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
 #pragma unroll
         for (int i = 0; i < QG::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < QG::NR; ++r) {
                 const int row = QG::acc_row(wave, lane, i, r);
                 const float dot = acc[i][j][r] * out_scale;            // power of two: exact
                 // the screen of knn_select_kernel: approx = 1 - dot / (|q||p|), margin 64 eps (1 + (|q|^2 + |p|^2) / (|q||p|));

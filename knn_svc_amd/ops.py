@@ -157,7 +157,8 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
               convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False,
-              w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0, dyn=None, x_bound=None):
+              w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0, dyn=None, x_bound=None,
+              fixed_tile=False):
     """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr).
     ``x_absmax`` / ``w_absmax`` / ``out_absmax``: one-element device tensors (range slots of the f16x2 path, see the
     header): bound of |x| / |w| the kernel derives its operand scales from, and where this launch folds max|out|."""
@@ -195,6 +196,7 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.w_absmax = w_absmax.data_ptr() if w_absmax is not None else None
     d.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
     d.out_f16x2_scale = out_split_scale
+    d.fixed_tile = 1 if fixed_tile else 0
     if x_bound is not None:            # (mul, add): |x| <= mul * max(x_absmax slot) + add — an input that was not measured itself
         d.x_bound_mul, d.x_bound_add = float(x_bound[0]), float(x_bound[1])
     if dyn is not None:
@@ -429,7 +431,8 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
                 qc = (q2 if q2 is not None else q)[q0:q0 + q_rows]
                 m = qc.shape[0]
                 dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
-                conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, w2=p2, x_split=q2 is not None, x_absmax=q_slot, w_absmax=p_slot)
+                conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, w2=p2, x_split=q2 is not None, x_absmax=q_slot, w_absmax=p_slot,
+                          fixed_tile=True)      # a shard of any size gives the whole pool's distances
                 check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
                                             idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
                                             _stream()), "knn_select")

@@ -109,7 +109,10 @@ def test_vocoder_30s_deterministic_and_graph_equals_eager():
 
 def test_wavlm_large_chunk_independence_and_ragged_tail():
     """A 30 s chunk encodes to the same 1500 frames alone, in a batch, and in front of a ragged tail;
-    tails of <= 320 samples are dropped (ddsp_prematch_dataset.py:277-285)."""
+    tails of <= 320 samples are dropped (ddsp_prematch_dataset.py:277-285).  "The same" is bit for bit as long as the
+    launches pick the same GEMM kernel; a batch large enough for the 256x256-tile kernel (16x16x32 MFMAs: 32 k per
+    instruction) sums over K in another grouping than the 128x128-tile kernel a lone chunk gets, so across that boundary
+    the frames agree to fp32 accumulation noise (with KNNSVC_QUAD=0 every launch takes the small tile: bit-equal again)."""
     from knn_svc_amd.wavlm import WavLMEncoder, chunk_plan
     cfg = C.WAVLM_LARGE
     enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg, 2), seed=1), cfg, DEV, n_layers=2)
@@ -120,7 +123,19 @@ def test_wavlm_large_chunk_independence_and_ragged_tail():
     alone = enc.full_features(wg[:480000])
     assert alone.shape[0] == 1500 and torch.equal(alone, full[:1500])
     many = enc.encode_many([wg, wg[:480000], wg[:480000 + 300]])
-    assert torch.equal(many[0], full) and torch.equal(many[1], alone)
+    scale = float(full.abs().max())
+    d0, d1 = float((many[0] - full).abs().max()) / scale, float((many[1] - alone).abs().max()) / scale
+    print(f"batched vs lone chunk: max |difference| / max |feature| = {d0:.2e}, {d1:.2e}")
+    assert d0 < 5e-6 and d1 < 5e-6                          # measured 1.3e-6
+    import os
+    os.environ["KNNSVC_QUAD"] = "0"
+    try:
+        enc2 = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg, 2), seed=1), cfg, DEV, n_layers=2)
+        f2 = enc2.full_features(wg)
+        m2 = enc2.encode_many([wg, wg[:480000], wg[:480000 + 300]])
+        assert torch.equal(m2[0], f2) and torch.equal(m2[1], f2[:1500])
+    finally:
+        del os.environ["KNNSVC_QUAD"]
     assert many[2].shape[0] == 1500                       # 300-sample tail dropped
     assert [l for (_s, l, _p) in chunk_plan(480000 + 300)] == [480000]
     assert [l for (_s, l, _p) in chunk_plan(480000 + 321)] == [480000, 321]

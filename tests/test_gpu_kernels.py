@@ -110,12 +110,15 @@ def test_linear_f16x2_big_tile(monkeypatch):
     assert float((o128 - o).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize("M,K,N", [(2048 + 77, 1024, 1024), (700, 2048, 520), (256, 32, 256), (31, 4096, 1028)])
-def test_linear_quad_kernel(M, K, N, monkeypatch):
+@pytest.mark.parametrize("q16", ["0", "1"])
+@pytest.mark.parametrize("M,K,N", [(2048 + 77, 1024, 1024), (700, 2048, 520), (256, 32, 256), (31, 4096, 1028), (300, 96, 260)])
+def test_linear_quad_kernel(M, K, N, q16, monkeypatch):
     """conv_gemm2quad_kernel (256x256 block, 128x128 wave tiles, hand-pipelined 4-stage DMA ring, LDS-transposed
     16-byte epilogue): ragged M and N tails, 1 / 32 / 64 / 128 slabs, every epilogue operand — bias, GELU, residual,
     accumulate, divide, range slot, split-layout output — against fp64 and against the 128x128 kernel."""
     ops = _ops()
+    monkeypatch.setenv("KNNSVC_QUAD16", q16)          # "1": the 16x16x32-MFMA variant (Gemm2QuadS, odd and even slab counts)
+    qname = "Q256S" if q16 == "1" else "Q256"
     g = torch.Generator().manual_seed(17)
     x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
     r = torch.randn(M, N, generator=g)
@@ -128,7 +131,7 @@ def test_linear_quad_kernel(M, K, N, monkeypatch):
     for mode in ("2", "0"):
         monkeypatch.setenv("KNNSVC_QUAD", mode)
         o = ops.linear(xs, wd, b.to(DEV), x_split=True)
-        assert ops.last_conv_kernel() == ("Q256" if mode == "2" else ("F128a2" if M * N >= 256 * 128 * 128 else ops.last_conv_kernel()))
+        assert ops.last_conv_kernel() == (qname if mode == "2" else ("F128a2" if M * N >= 256 * 128 * 128 else ops.last_conv_kernel()))
         outs[mode] = o.cpu()
         e = float((o.cpu().double() - ref).abs().max())
         assert e < 3e-5 * max(1.0, (K / 1024) ** 0.5), (mode, e)
@@ -154,10 +157,12 @@ def test_linear_quad_kernel(M, K, N, monkeypatch):
     assert float((outs["2"] - outs["0"]).abs().max()) < 2e-5 * max(1.0, (K / 1024) ** 0.5)
 
 
-def test_conv_quad_kernel_taps_stride_batches(monkeypatch):
+@pytest.mark.parametrize("q16", ["0", "1"])
+def test_conv_quad_kernel_taps_stride_batches(q16, monkeypatch):
     """The quad kernel on a strided 3-tap convolution over a batch of sequences (WavLM's conv stack shape: A2 input,
     stride 2, per-batch strides) and with conv padding rows, against the 128x128 kernel."""
     ops = _ops()
+    monkeypatch.setenv("KNNSVC_QUAD16", q16)
     g = torch.Generator().manual_seed(19)
     B, T, Cin, Cout, k, st = 3, 2001, 256, 512, 3, 2
     x = torch.randn(B * T, Cin, generator=g)
@@ -172,7 +177,7 @@ def test_conv_quad_kernel_taps_stride_batches(monkeypatch):
         yp = torch.empty(B * T, Cout, device=DEV)
         ops.conv_gemm(xs, w, yp, m=T, n=Cout, cin=Cin, taps=k, stride=1, pad=1, t_in=T, batches=B, x_bstride=T * Cin, o_bstride=T * Cout, x_split=True)
         res[mode] = (y.cpu(), yp.cpu(), ops.last_conv_kernel())
-    assert res["2"][2] == "Q256"
+    assert res["2"][2] == ("Q256S" if q16 == "1" else "Q256")
     ref = torch.nn.functional.conv1d(x.view(B, T, Cin).transpose(1, 2).double(), w.cpu().view(Cout, k, Cin).permute(0, 2, 1).double(), stride=st)
     assert float((res["2"][0].view(B, t_out, Cout).transpose(1, 2).double() - ref).abs().max()) < 2e-5
     assert float((res["2"][0] - res["0"][0]).abs().max()) < 2e-5 and float((res["2"][1] - res["0"][1]).abs().max()) < 2e-5

@@ -18,14 +18,14 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- py
 cp $(ls $O/kts/*/*kernel_stats.csv | head -1) $O/${tag}_bench_n1_sequential_kernel_stats.csv
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmcf.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmcw.log 2>&1
-python3 $R/tools/pmc_traffic.py $(ls $O/pmcf/*/*counter_collection.csv | head -1) $(ls $O/pmcw/*/*counter_collection.csv | head -1) "conv_gemm2quad_kernel<Gemm2QuadR" > $O/${tag}_pmc_traffic.json
+python3 $R/tools/pmc_traffic.py $(ls $O/pmcf/*/*counter_collection.csv | head -1) $(ls $O/pmcw/*/*counter_collection.csv | head -1) "conv_gemm2quad_kernel<Gemm2QuadS" > $O/${tag}_pmc_traffic.json
 python3 $R/tools/pmc_traffic.py $(ls $O/pmcf/*/*counter_collection.csv | head -1) $(ls $O/pmcw/*/*counter_collection.csv | head -1) > $O/${tag}_pmc_traffic_f128.json
 cd $R
 A2=1 KNNSVC_QUAD=0 tools/pmc_cycles.sh f128_$tag 31500 4096 1024 5 > $O/${tag}_pmc_cycles_f128.txt 2>&1
 A2=1 KNNSVC_QUAD=2 tools/pmc_cycles.sh quad_$tag 31500 1024 4096 5 > $O/${tag}_pmc_cycles_quad.txt 2>&1
 python3 tools/knn_bench.py > $O/${tag}_knn_bench.txt 2>&1
 KNNSVC_KNN_FUSED=0 python3 tools/knn_bench.py 2>&1 | tail -1 >> $O/${tag}_knn_bench.txt
-bash tools/quad_epi_ab.sh > $O/${tag}_quad_vs_f128_real_epilogues.txt 2>&1
+bash tools/quad16_ab.sh > $O/${tag}_quad_vs_f128_real_epilogues.txt 2>&1
 python3 tools/gemm_zero.py 31500 1024 4096 > $O/${tag}_gemm_zero_vs_random.txt 2>&1
 python3 tools/layer_error.py 6 6 > $O/${tag}_layer_error.txt 2>&1
 ( python3 tools/vocoder_replay.py; KNNSVC_RANGE_SLOTS=0 python3 tools/vocoder_replay.py ) > $O/${tag}_vocoder_range_slots.txt 2>&1
