@@ -321,6 +321,21 @@ int knnsvc_f0_harvest(const float* x, int64_t L, int32_t sample_rate, float f0_f
                       int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * FLAC container (HOST functions: plain pointers into host memory, no stream, no GPU).  The reference reads .flac through
+ * torchaudio.load (ddsp_prematch_dataset.py:332; its prematch builder globs *.wav and *.flac, :1469-1473) and writes .flac
+ * through pydub / ffmpeg (lib_ongaku_test.py:122-143).  RFC 9639; every frame's CRC-8 / CRC-16 is verified while decoding.
+ * ------------------------------------------------------------------------------------------ */
+/* STREAMINFO of a FLAC file image: sample rate, channels, bits per sample, samples per channel, MD5 of the PCM (16 bytes, may be NULL) */
+int knnsvc_flac_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels, int32_t* bits,
+                     int64_t* total_samples, uint8_t* md5);
+/* decode into out[channels][capacity] (planar, sign-extended to int32); *decoded = samples per channel */
+int knnsvc_flac_decode(const uint8_t* data, int64_t size, int32_t* out, int64_t capacity, int64_t* decoded);
+/* encode pcm[channels][n] (`bits`-bit signed samples in int32; bits in {8, 12, 16, 20, 24}) with fixed predictors + Rice coding,
+ * block size 4096; md5: 16 bytes for STREAMINFO or NULL (= unknown); *size = bytes written to out (capacity: 5 n channels + 8192 is safe) */
+int knnsvc_flac_encode(const int32_t* pcm, int32_t channels, int64_t n, int32_t bits, int32_t sample_rate, const uint8_t* md5,
+                       uint8_t* out, int64_t capacity, int64_t* size);
+
+/* ------------------------------------------------------------------------------------------
  * Pool side features and the additive synthesiser.
  * ------------------------------------------------------------------------------------------ */
 /* reflect-pad by `pad` samples each side (torch.stft center=True) : out[n + 2*pad] */

@@ -72,6 +72,9 @@ SIGNATURES = {
     "knnsvc_round_f16": (i32, [vp, i64, vp, vp]),
     "knnsvc_amp_ratio": (i32, [vp, i32, vp, i32, i64, vp, i64, i32, i32, vp, vp]),
     "knnsvc_f0_yin": (i32, [vp, i64, i32, i32, f32, f32, f32, f32, vp, i64, vp]),
+    "knnsvc_flac_info": (i32, [vp, i64, vp, vp, vp, vp, vp]),
+    "knnsvc_flac_decode": (i32, [vp, i64, vp, i64, vp]),
+    "knnsvc_flac_encode": (i32, [vp, i32, i64, i32, i32, vp, vp, i64, vp]),
     "knnsvc_f0_harvest_workspace": (i32, [i64, i32, f32, f32, f32, vp, vp]),
     "knnsvc_f0_harvest": (i32, [vp, i64, i32, f32, f32, f32, f32, vp, i64, vp, i64, vp, vp]),
     "knnsvc_reflect_pad": (i32, [vp, i64, i32, vp, vp]),

@@ -2,9 +2,11 @@
 
 The reference goes through ``torchaudio.load`` (ddsp_prematch_dataset.py:332) and
 ``soundfile.write(..., subtype='PCM_32')`` (lib_ongaku_test.py:118-120).  Neither
-library is in this image, so WAV is handled here with numpy; other containers
-(.flac/.mp3) are delegated to torchaudio/soundfile when importable and refused
-otherwise.  Sample values follow torchaudio's convention: integer PCM is scaled
+library is in this image, so WAV is handled here with numpy and FLAC (what the
+reference's prematch builder globs next to .wav: LibriSpeech) by the library's own
+RFC 9639 decoder / encoder (csrc/flac.hip, host code: frame CRCs and the stream MD5 are
+verified on every read).  .mp3 is delegated to torchaudio/soundfile when importable and
+refused otherwise.  Sample values follow torchaudio's convention: integer PCM is scaled
 by 2**-(bits-1) to float32 in [-1, 1).
 """
 from __future__ import annotations
@@ -61,11 +63,68 @@ def read_wav(path: str):
     return np.ascontiguousarray(x[:n * ch].reshape(n, ch).T), sr
 
 
+def read_flac_pcm(path: str):
+    """-> (int32 [channels, samples] holding `bits`-bit samples, sample_rate, bits).  Frame CRCs are checked by the decoder, the
+    MD5 of the decoded PCM against STREAMINFO here (skipped when the file carries no MD5)."""
+    import ctypes as C
+    import hashlib
+    from . import _lib
+    from .ops import check
+    lib = _lib.load()
+    with open(path, "rb") as f:
+        data = f.read()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    sr, ch, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    md5 = (C.c_uint8 * 16)()
+    check(lib.knnsvc_flac_info(buf, len(data), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(total), md5), f"flac_info({path})")
+    if total.value <= 0:
+        raise ValueError(f"{path}: FLAC stream without a sample count in STREAMINFO is not supported")
+    out = np.empty((ch.value, total.value), np.int32)
+    done = C.c_int64()
+    check(lib.knnsvc_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), total.value, C.byref(done)), f"flac_decode({path})")
+    want = bytes(md5)
+    if any(want):
+        nb = (bits.value + 7) // 8
+        inter = np.ascontiguousarray(out.T)
+        raw = inter.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :nb].tobytes()
+        if hashlib.md5(raw).digest() != want:
+            raise ValueError(f"{path}: decoded PCM does not match the MD5 in STREAMINFO")
+    return out, sr.value, bits.value
+
+
+def read_flac(path: str):
+    """-> (float32 [channels, samples], sample_rate), scaled like torchaudio.load."""
+    pcm, sr, bits = read_flac_pcm(path)
+    return (pcm.astype(np.float64) / float(1 << (bits - 1))).astype(np.float32), sr
+
+
+def write_flac(path: str, pcm: np.ndarray, sr: int, bits: int = 24) -> None:
+    """pcm: int32 [samples] or [channels, samples] of `bits`-bit samples -> FLAC (fixed predictors + Rice, MD5 set)."""
+    import ctypes as C
+    import hashlib
+    from . import _lib
+    from .ops import check
+    lib = _lib.load()
+    pcm = np.ascontiguousarray(np.atleast_2d(np.asarray(pcm, np.int32)))
+    ch, n = pcm.shape
+    nb = (bits + 7) // 8
+    raw = np.ascontiguousarray(pcm.T).astype("<i4").view(np.uint8).reshape(-1, 4)[:, :nb].tobytes()
+    md5 = (C.c_uint8 * 16).from_buffer_copy(hashlib.md5(raw).digest())
+    cap = 5 * n * ch + 8192
+    out = (C.c_uint8 * cap)()
+    size = C.c_int64()
+    check(lib.knnsvc_flac_encode(pcm.ctypes.data_as(C.c_void_p), ch, n, bits, int(sr), md5, out, cap, C.byref(size)), "flac_encode")
+    with open(path, "wb") as f:
+        f.write(bytes(out[:size.value]) if size.value < (1 << 20) else memoryview(out)[:size.value])
+
+
 def load_audio(path: str):
     """torchaudio.load stand-in: -> (float32 ndarray [channels, samples], sr)."""
     ext = os.path.splitext(path)[-1].lower()
     if ext == ".wav":
         return read_wav(path)
+    if ext == ".flac":
+        return read_flac(path)
     try:                                    # optional decoders; absent in this image
         import soundfile as sf
         x, sr = sf.read(path, dtype="float32", always_2d=True)
@@ -115,8 +174,8 @@ def write_wav_pcm16(path: str, wave: np.ndarray, sr: int) -> None:
 
 
 def save_audio(filename: str, waveform, sample_rate: int) -> str:
-    """lib_ongaku_test.py:89-143: PCM_32 .wav natively; .flac through soundfile when it is importable.  The reference
-    encodes .mp3 / .flac through pydub + ffmpeg; without an encoder for the requested container (dataset mode names
+    """lib_ongaku_test.py:89-143: PCM_32 .wav and 24-bit .flac natively.  The reference
+    encodes .mp3 / .flac through pydub + ffmpeg; without an encoder for the requested container (.mp3; dataset mode names
     its outputs after the source file's extension, ddsp_matcher.py:1133) the audio is written as PCM_32 .wav next to
     the requested name, with a warning, instead of losing a finished conversion.  Returns the path written."""
     wave = np.asarray(waveform)
@@ -124,13 +183,12 @@ def save_audio(filename: str, waveform, sample_rate: int) -> str:
         write_wav_pcm32(filename, wave, sample_rate)
         return filename
     if filename.endswith(".flac"):
-        try:
-            import soundfile as sf
-            pcm = to_pcm32(wave)
-            sf.write(filename, pcm.T if pcm.ndim == 2 else pcm, sample_rate, subtype="PCM_24")
-            return filename
-        except ImportError:
-            pass
+        # the reference hands int32 samples to ffmpeg's FLAC encoder, which keeps their top 24 bits
+        pcm = to_pcm32(wave)
+        if pcm.ndim == 2 and pcm.shape[0] not in (1, 2):
+            pcm = pcm.T
+        write_flac(filename, np.ascontiguousarray(pcm) >> 8, sample_rate, bits=24)
+        return filename
     alt = os.path.splitext(filename)[0] + ".wav"
     import warnings
     warnings.warn(f"{filename}: no encoder for this container in this environment (the reference uses pydub/ffmpeg); "
