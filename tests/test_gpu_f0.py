@@ -106,3 +106,42 @@ def test_harvest_is_deterministic_and_stream_ordered():
         c = ops.f0_harvest(x, check_status=False)
     torch.cuda.current_stream().wait_stream(s)
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_prematch_from_flac_without_f0_caches_equals_wav_with_caches(tmp_path):
+    """The reference's prematch builder on a LibriSpeech-style tree (ddsp_prematch_dataset.py:1469-1473 globs *.flac; :376-379
+    computes a missing f0 with harvest and caches it): the same utterances as 16-bit FLAC files WITHOUT f0 caches give
+    byte-identical pool / neighbour files to PCM_16 WAV files WITH the harvest tracks precomputed — the FLAC decoder returns
+    the same samples, the GPU Harvest the same tracks — and the caches appear next to the audio."""
+    import pickle
+    from knn_svc_amd import config as C, matching, prematch
+    from knn_svc_amd.wavlm import WavLMEncoder
+    ops = _ops()
+    cfg = C.WAVLM_TINY
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg), seed=11), cfg, DEV, n_layers=2)
+    roots = {k: tmp_path / k for k in ("wav", "flac")}
+    for s, spk in enumerate(("spkA", "spkB")):
+        for k in roots:
+            (roots[k] / spk).mkdir(parents=True)
+        for u in range(3):
+            w, _ = S.synth_clip(16000 * 2 + 640 * (s + u) + 17, seed=900 + 10 * s + u)
+            pcm = np.clip(np.round(np.asarray(w, np.float64) * 32768.0), -32768, 32767).astype(np.int32)
+            audio_io.write_wav_pcm16(str(roots["wav"] / spk / f"u{u}.wav"), w, 16000)
+            audio_io.write_flac(str(roots["flac"] / spk / f"u{u}.flac"), pcm, 16000, bits=16)
+            x = (pcm.astype(np.float32) / 32768.0)
+            np.save(roots["wav"] / spk / f"u{u}_f0.npy", ops.f0_harvest(torch.from_numpy(x).to(DEV)).cpu().numpy())
+    matching._POOL_CACHE = None
+    with torch.inference_mode():
+        for k in roots:
+            prematch.per_spk_extract(enc, DEV, roots[k], tmp_path / f"cached_{k}")
+    for spk in ("spkA", "spkB"):
+        for u in range(3):
+            assert (roots["flac"] / spk / f"u{u}_f0.npy").is_file()
+            assert np.array_equal(np.load(roots["flac"] / spk / f"u{u}_f0.npy"), np.load(roots["wav"] / spk / f"u{u}_f0.npy"))
+            with open(tmp_path / "cached_wav" / spk / f"u{u}.pt", "rb") as fa, open(tmp_path / "cached_flac" / spk / f"u{u}.pt", "rb") as fb:
+                da, db = pickle.load(fa), pickle.load(fb)
+            assert set(da) == set(db)
+            for key in da:
+                assert np.array_equal(np.asarray(da[key]), np.asarray(db[key])), (spk, u, key)
+        for name in ("pool.npy", "pool_harmonics.npy"):
+            assert np.array_equal(np.load(tmp_path / "cached_wav" / spk / name), np.load(tmp_path / "cached_flac" / spk / name))
