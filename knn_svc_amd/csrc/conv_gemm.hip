@@ -1060,6 +1060,7 @@ using Q256S = Gemm2QuadS;          // 16x16x32 MFMA, 32-k slabs (default)
 using R512 = Gemm2Ring<256, 256, 2, 2, 4, 4, 3>;       // 128x128 wave tiles, 256 accumulator registers, one block per CU
 using R256 = Gemm2Ring<256, 128, 2, 2, 4, 2, 3>;       // 128x64 wave tiles, 72 KB ring: two blocks per CU     // 2-stage ring: 32 KB, four blocks per CU
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
+using W160 = Gemm2Win<160, 128, 1, 4, 5, 1, 64>;      // 224-row window (32 KB) + 18 KB: still 3 blocks / CU; see the dispatch rule
 using W128S = Gemm2Win<64, 128, 2, 2, 1, 2, 64>;      // short time axes (first generator stage): twice the blocks, 37 KB
 using W64 = Gemm2Win<256, 64, 4, 1, 2, 2, 64>;        // 320 rows (45 KB) + 9 KB
 using W32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // 320 rows + 4.5 KB
@@ -1224,6 +1225,13 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
                     if (small_on && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 512) {
                         g_last_kernel = "W128S"; return launch2win<W128S, 4>(a, d->batches, st);
                     }
+                    // Tile-count quantisation: 768 blocks are resident at once (3 per CU); a launch of 938 128-row tiles (the
+                    // generator's C = 128 stage at 30 s: 120 000 rows) runs two rounds, the second 22 % full.  160-row tiles make
+                    // it 750 — one round.  Pick the height with the fewer (rounds x rows per round).  KNNSVC_WIN160=0: off.
+                    static const bool w160_on = [] { const char* e = getenv("KNNSVC_WIN160"); return !(e && e[0] == '0'); }();
+                    const long z = (long)d->batches * d->groups * cdiv64(d->n, 128);
+                    const long r128 = cdiv64(cdiv64(d->m, 128) * z, 768) * 128, r160 = cdiv64(cdiv64(d->m, 160) * z, 768) * 160;
+                    if (w160_on && r160 < r128) { g_last_kernel = "W160"; return launch2win<W160, 3>(a, d->batches, st); }
                     g_last_kernel = "W128"; return launch2win<W128, 3>(a, d->batches, st);
                 }
                 if (d->n > 32) { g_last_kernel = "W64"; return launch2win<W64, 2>(a, d->batches, st); }
