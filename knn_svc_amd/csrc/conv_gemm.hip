@@ -337,7 +337,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, typename G::acc
                 const long orow = out_row(r);
                 if (orow < 0) continue;
                 float v = fmaf(acc[i][j][r], a.out_scale, bv);      // out_scale is a power of two: exact
-                if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (a.act == KNNSVC_ACT_GELU) v = kn_gelu(v);
                 else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
                 else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
                 if (a.out_split && n >= a.split_from) {
@@ -417,7 +417,7 @@ __device__ __forceinline__ void conv_epilogue_lin(const ConvArgs& a, typename G:
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 float v = fmaf(acc[i][j][r], a.out_scale, bv);      // out_scale is a power of two: exact
-                if (a.act == KNNSVC_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (a.act == KNNSVC_ACT_GELU) v = kn_gelu(v);
                 else if (a.act == KNNSVC_ACT_LRELU) v = lrelu(v, a.act_slope);
                 else if (a.act == KNNSVC_ACT_TANH) v = tanhf(v);
                 const int off = bo + ((r & 3) + 8 * (r >> 2)) * ldo4;
@@ -534,7 +534,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
             }
             if (act == KNNSVC_ACT_GELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+                for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
             } else if (act == KNNSVC_ACT_LRELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.act_slope);

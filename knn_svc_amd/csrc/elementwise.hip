@@ -28,7 +28,7 @@ __device__ __forceinline__ f32x4 load_split4(const float* row, int c) {
 
 __device__ __forceinline__ float gelu_erf(float v) {
 #pragma clang fp contract(off)
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return kn_gelu(v);
 }
 
 // one wave per R rows, rows kept in registers (R * dim <= 2048 floats per wave), two-pass mean / variance.
