@@ -145,3 +145,28 @@ def test_prematch_from_flac_without_f0_caches_equals_wav_with_caches(tmp_path):
                 assert np.array_equal(np.asarray(da[key]), np.asarray(db[key])), (spk, u, key)
         for name in ("pool.npy", "pool_harmonics.npy"):
             assert np.array_equal(np.load(tmp_path / "cached_wav" / spk / name), np.load(tmp_path / "cached_flac" / spk / name))
+
+
+def test_full_size_conversion_from_raw_audio_equals_conversion_with_the_reference_f0_caches(tmp_path, monkeypatch):
+    """BASELINE cfg 2's call on the reference's own 60 s sample pair, WavLM-Large and the 22.9 M-parameter generator with seeded
+    weights: once with the harvest caches the reference ships next to the clips, once from the bare audio (the f0 tracks then
+    come from the GPU Harvest, as ddsp_prematch_dataset.py:376-379 does with pyworld).  Same tracks -> the same waveform, bit
+    for bit; the generated caches equal the shipped ones."""
+    import shutil
+    from knn_svc_amd import hubconf, matching
+    monkeypatch.setenv("KNNSVC_SEEDED_WEIGHTS", "1")
+    monkeypatch.delenv("KNNSVC_F0", raising=False)
+    src, tgt = CLIPS
+    outs = {}
+    for mode in ("cached", "raw"):
+        d = tmp_path / mode; d.mkdir()
+        for name in CLIPS:
+            shutil.copy(FX / f"{name}.wav", d / f"{name}.wav")
+            if mode == "cached":
+                shutil.copy(FX / f"{name}_f0.npy", d / f"{name}_f0.npy")
+        matching._POOL_CACHE = None
+        knn = hubconf.knn_vc(ckpt_type="mix", device="cuda", weights="seeded")
+        outs[mode] = knn.special_match(str(d / f"{src}.wav"), str(d / f"{tgt}.wav"), ckpt_type="mix", post_opt="post_opt_0.2").cpu()
+    for name in CLIPS:
+        assert np.array_equal(np.load(tmp_path / "raw" / f"{name}_f0.npy"), np.load(FX / f"{name}_f0.npy").astype(np.float32))
+    assert outs["raw"].numel() == 960320 and torch.equal(outs["raw"], outs["cached"])
