@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256) void concat_reselect_kernel(
                 }
             }
             int rank = 0;
-            for (int j = 0; j < NC; ++j) {
-                const float tj = __shfl(total, j, 64);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {          // v_readlane (an SGPR broadcast), not a ds_bpermute round trip per candidate
+                const float tj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), j));
                 rank += (tj < total || (tj == total && j < lane)) ? 1 : 0;
             }
             if (lane < NC && rank < KC) {
@@ -300,7 +301,16 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
     }
     __syncthreads();
 
+#ifdef KN_CONCAT_PROF
+    unsigned long long pf[7] = {0, 0, 0, 0, 0, 0, 0}, tq = 0;
+#define KN_TICK(K) { const unsigned long long now = __builtin_readcyclecounter(); pf[K] += now - tq; tq = now; }
+#else
+#define KN_TICK(K)
+#endif
     for (long i = 1; i < nq; ++i) {
+#ifdef KN_CONCAT_PROF
+        tq = __builtin_readcyclecounter();
+#endif
         const int cur = (int)(i & 1), prv = cur ^ 1;
         const long* s_cand = s_candT[cur]; const float* s_cpn = s_cpnT[cur]; const float* s_cf0 = s_cf0T[cur];
         const int* s_coff = s_coffT[cur];
@@ -309,25 +319,27 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
         f32x4 pre[7];
         long my_id = 0, nn_id = 0; float my_pn = 0.f, my_f0 = 0.f; int my_kind = -1;   // per-thread scalar prefetch (tid < 13)
         {
-            // row list r = 0..12: 0-3 -> A[i+1], 4 -> q[i+1], 5-12 -> successors of cand[0..7]
+            // row list r = 2 t + half: 0-3 -> A[i+1], 4 -> q[i+1], 5-12 -> successors of cand[0..7], 13 -> nothing.
+            // Every load is UNCONDITIONAL (rows that are not needed read a harmless row and are dropped in (d)): with the loads
+            // inside branches each one sat in its own basic block and waited for its predecessor — 3700 cycles per frame just to
+            // issue seven loads (in-kernel cycle counters, tools/concat_prof.py), the largest single item of a 12 500-cycle frame.
 #pragma unroll
             for (int t = 0; t < 7; ++t) {
                 const int r = 2 * t + half;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (colok && r < 13) {
-                    if (r < 4) { if (more) v = *(const f32x4*)(pool + (i == 1 ? idx_in[2 * KC + r] : s_idNext[prv][r]) * (long)D + col); }
-                    else if (r == 4) { if (more) v = *(const f32x4*)(q + (i + 1) * (long)D + col); }
-                    else { long sid = s_cand[r - 5] + 1; if (sid >= np) sid = np - 1; v = *(const f32x4*)(pool + sid * (long)D + col); }
-                }
-                pre[t] = v;
+                const int ra = r < 4 ? r : 0, rs = (r >= 5 && r < 13) ? r - 5 : 0;
+                const long ida = more ? s_idNext[prv][ra] : 0;
+                long sid = s_cand[rs] + 1; sid = sid >= np ? np - 1 : sid;
+                const float* src = r < 4 ? pool + ida * (long)D : (r == 4 ? q + (more ? i + 1 : 0) * (long)D : pool + sid * (long)D);
+                pre[t] = *(const f32x4*)(src + (colok ? col : 0));
             }
             if (tid < 13) {
                 if (tid < 4) { if (i + 2 < nq) nn_id = idx_in[(i + 2) * KC + tid];
-                               if (more) { my_id = (i == 1 ? idx_in[2 * KC + tid] : s_idNext[prv][tid]); my_pn = pn[my_id]; my_f0 = use_f0 ? pf0[my_id] : 0.f; my_kind = 0; } }
+                               if (more) { my_id = s_idNext[prv][tid]; my_pn = pn[my_id]; my_f0 = use_f0 ? pf0[my_id] : 0.f; my_kind = 0; } }
                 else if (tid == 4) { if (more) { my_pn = qn[i + 1]; my_f0 = use_f0 ? sf0[i + 1] : 0.f; my_kind = 1; } }
                 else { long sid = s_cand[tid - 5] + 1; if (sid >= np) sid = np - 1; my_id = sid; my_pn = pn[sid]; my_f0 = use_f0 ? pf0[sid] : 0.f; my_kind = 2; }
             }
         }
+        KN_TICK(0)
         // ---- (b) distances: wave b owns candidate b ---------------------------------------------------
         {
             const int coff = s_coff[wave];
@@ -364,7 +376,9 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 if (wave == 0) s_base = cos_from_cd(a5, s_qn[prv], s_qn[cur]) * 2.0f;
             }
         }
+        KN_TICK(1)
         __syncthreads();
+        KN_TICK(2)
         // ---- (c) costs, lower median over the previous selection, 4 smallest.  Every wave evaluates the
         // same 8-lane decision redundantly (it only reads LDS), so no barrier is needed before (d). ------
         int my_slot = -1;                       // lane < 8: rank of candidate `lane` if kept
@@ -389,8 +403,9 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 if (use_f0) total = total + fabsf(s_cf0[lane] - s_sf0[cur]);      // both already log2(f0 + 1e-5)
             }
             int rank = 0;
-            for (int j = 0; j < NC; ++j) {
-                const float tj = __shfl(total, j, 64);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {          // v_readlane (an SGPR broadcast), not a ds_bpermute round trip per candidate
+                const float tj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), j));
                 rank += (tj < total || (tj == total && j < lane)) ? 1 : 0;
             }
             if (lane < NC && rank < KC) my_slot = rank;
@@ -406,6 +421,7 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
             const unsigned long long bal = __ballot(my_slot == r);
             kept[r] = (int)__builtin_ctzll(bal);
         }
+        KN_TICK(3)
         // ---- (d) kept rows -> P, prefetched registers -> A[next], Q[next], S[cur] -----------------------
         f32x4 keep[2];
         if (colok) {
@@ -423,6 +439,7 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 else if (r < 13) *(lf4*)&L[offS + (cur * 8 + (r - 5)) * D + col] = pre[t];
             }
         }
+        KN_TICK(4)
         if (use_f0 && my_kind >= 0) my_f0 = log2_rn(my_f0 + 1e-5f);      // one evaluation per new row, 13 lanes of wave 0
         // next frame's candidate table, straight from the prefetch registers of wave 0 (lanes 0..12):
         // slots 0-3 = its kNN rows, slots 4-7 = successors of the rows kept now
@@ -451,8 +468,14 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
         if (my_kind == 0) { s_idA[prv][tid] = my_id; s_pnA[prv][tid] = my_pn; s_f0A[prv][tid] = my_f0; }
         else if (my_kind == 1) { s_qn[prv] = my_pn; s_sf0[prv] = my_f0; }
         else if (my_kind == 2) { s_idS[cur][tid - 5] = my_id; s_pnS[cur][tid - 5] = my_pn; s_f0S[cur][tid - 5] = my_f0; }
+        KN_TICK(5)
         __syncthreads();
+        KN_TICK(6)
     }
+#ifdef KN_CONCAT_PROF
+    if (tid == 0) printf("concat prof (cycles/frame, wave 0): prefetch-issue %.0f  distances %.0f  barrier1 %.0f  select %.0f  stage(wait loads) %.0f  table %.0f  barrier2 %.0f\n",
+                         (double)pf[0] / nq, (double)pf[1] / nq, (double)pf[2] / nq, (double)pf[3] / nq, (double)pf[4] / nq, (double)pf[5] / nq, (double)pf[6] / nq);
+#endif
 }
 
 }  // namespace
