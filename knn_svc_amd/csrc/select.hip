@@ -243,6 +243,14 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // ---------------------------------------------------------------------------------------------
 constexpr int CT = 512;
 
+// buffer resource over a whole array (< 4 GiB: the dispatcher sends larger pools to the generic kernel)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sel_rsrc(const void* p, unsigned long long bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)nb, 0x00020000);
+}
+
 __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
     const long* __restrict__ idx_in, const float* __restrict__ q, const float* __restrict__ qn, long nq,
     const float* __restrict__ pool, const float* __restrict__ pn, long np, int dim,
@@ -301,6 +309,10 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
     }
     __syncthreads();
 
+    typedef unsigned g2u4 __attribute__((ext_vector_type(4)));
+    const unsigned row_bytes = (unsigned)D * 4u;
+    const int whalf = __builtin_amdgcn_readfirstlane(half);                    // waves 0-3: 0, waves 4-7: 1
+    const __amdgpu_buffer_rsrc_t p_rsrc = sel_rsrc(pool, (unsigned long long)np * row_bytes), q_rsrc = sel_rsrc(q, (unsigned long long)nq * row_bytes);
 #ifdef KN_CONCAT_PROF
     unsigned long long pf[7] = {0, 0, 0, 0, 0, 0, 0}, tq = 0;
 #define KN_TICK(K) { const unsigned long long now = __builtin_readcyclecounter(); pf[K] += now - tq; tq = now; }
@@ -323,20 +335,46 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
             // Every load is UNCONDITIONAL (rows that are not needed read a harmless row and are dropped in (d)): with the loads
             // inside branches each one sat in its own basic block and waited for its predecessor — 3700 cycles per frame just to
             // issue seven loads (in-kernel cycle counters, tools/concat_prof.py), the largest single item of a 12 500-cycle frame.
+            // Addresses cost no vector work either: lane r of every wave turns row r's id into a 32-bit byte offset once, the
+            // offset travels to an SGPR (v_readlane) and the load is buffer_load_dwordx4 v, col * 4, rsrc, soffset.
+            unsigned my_off = 0;
+            if (lane < 4) my_off = more ? (unsigned)s_idNext[prv][lane] * row_bytes : 0u;
+            else if (lane == 4) my_off = more ? (unsigned)(i + 1) * row_bytes : 0u;
+            else if (lane < 13) { long sid = s_cand[lane - 5] + 1; sid = sid >= np ? np - 1 : sid; my_off = (unsigned)sid * row_bytes; }
+            const int voff = (colok ? col : 0) * 4;
 #pragma unroll
             for (int t = 0; t < 7; ++t) {
-                const int r = 2 * t + half;
-                const int ra = r < 4 ? r : 0, rs = (r >= 5 && r < 13) ? r - 5 : 0;
-                const long ida = more ? s_idNext[prv][ra] : 0;
-                long sid = s_cand[rs] + 1; sid = sid >= np ? np - 1 : sid;
-                const float* src = r < 4 ? pool + ida * (long)D : (r == 4 ? q + (more ? i + 1 : 0) * (long)D : pool + sid * (long)D);
-                pre[t] = *(const f32x4*)(src + (colok ? col : 0));
+                const int r0 = 2 * t, r1 = 2 * t + 1 < 13 ? 2 * t + 1 : 12;             // this wave's row is r0 (half 0) or r1 (half 1)
+                const unsigned o0 = __builtin_amdgcn_readlane(my_off, r0), o1 = __builtin_amdgcn_readlane(my_off, r1);
+                const unsigned so = whalf ? o1 : o0;
+#ifdef KN_CONCAT_NOLOAD        // what-if: no row loads at all (results are garbage)
+                pre[t] = (f32x4){(float)so, 0.f, 0.f, 0.f};
+                continue;
+#endif
+                if (t == 2) {                            // r0 = 4 is the query row (its own resource), r1 = 5 a pool row
+                    const g2u4 vq = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, voff, o0, 0);
+                    const g2u4 vp = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, voff, o1, 0);
+                    pre[t] = __builtin_bit_cast(f32x4, whalf ? vp : vq);
+                } else {
+                    pre[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, voff, so, 0));
+                }
             }
-            if (tid < 13) {
-                if (tid < 4) { if (i + 2 < nq) nn_id = idx_in[(i + 2) * KC + tid];
-                               if (more) { my_id = s_idNext[prv][tid]; my_pn = pn[my_id]; my_f0 = use_f0 ? pf0[my_id] : 0.f; my_kind = 0; } }
-                else if (tid == 4) { if (more) { my_pn = qn[i + 1]; my_f0 = use_f0 ? sf0[i + 1] : 0.f; my_kind = 1; } }
-                else { long sid = s_cand[tid - 5] + 1; if (sid >= np) sid = np - 1; my_id = sid; my_pn = pn[sid]; my_f0 = use_f0 ? pf0[sid] : 0.f; my_kind = 2; }
+            // The per-row scalars (norm, f0, the kNN ids two frames ahead) of lanes 0..12 of wave 0, branch-free for the same
+            // reason: inside `if (tid < 4) .. else if ..` the compiler put s_waitcnt vmcnt(0) at the joins, and wave 0 sat out
+            // the full latency of the row loads it had just issued — with every other wave waiting for it at the barrier.
+            if (wave == 0) {                         // wave-uniform: only wave 0 keeps these values
+                const int l = tid < 13 ? tid : 12;
+                const long kid = more ? s_idNext[prv][l & 3] : 0;                              // kind 0: a kNN row of frame i + 1
+                long sid = s_cand[l >= 5 ? l - 5 : 0] + 1; sid = sid >= np ? np - 1 : sid;      // kind 2: a successor row
+                const long row = l < 4 ? kid : (l == 4 ? (more ? i + 1 : 0) : sid);
+                const float* pnp = l == 4 ? qn : pn;
+                const float* pfp = use_f0 ? (l == 4 ? sf0 : pf0) : pnp;                         // any valid address when f0 is off
+                // issued here, first touched at the end of the frame: any use of the loaded values up here (even a select) makes
+                // the compiler wait for them on the spot — behind the eight row loads, which return in order
+                my_pn = pnp[row]; my_f0 = pfp[row];
+                nn_id = idx_in[(i + 2 < nq ? (i + 2) * KC : 0) + (l & 3)];
+                my_kind = tid < 13 ? (l < 4 ? (more ? 0 : -1) : (l == 4 ? (more ? 1 : -1) : 2)) : -1;
+                my_id = (my_kind == 0 || my_kind == 2) ? row : 0;
             }
         }
         KN_TICK(0)
@@ -440,6 +478,8 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
             }
         }
         KN_TICK(4)
+        if (my_kind < 0) { my_pn = 0.f; my_f0 = 0.f; }                   // lanes / rows without a row this frame: as if never loaded
+        if (!use_f0) my_f0 = 0.f;
         if (use_f0 && my_kind >= 0) my_f0 = log2_rn(my_f0 + 1e-5f);      // one evaluation per new row, 13 lanes of wave 0
         // next frame's candidate table, straight from the prefetch registers of wave 0 (lanes 0..12):
         // slots 0-3 = its kNN rows, slots 4-7 = successors of the rows kept now
@@ -511,7 +551,7 @@ extern "C" int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, con
     KN_REQUIRE(nq > 0 && np > 0 && dim > 0 && dim % 4 == 0, "concat_reselect: bad sizes");
     KN_REQUIRE(!use_f0 || (shifted_f0 && pool_f0), "concat_reselect: f0 variant needs both f0 arrays");
     KN_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)pool & 15) == 0, "concat_reselect: 16-byte alignment");
-    if (dim <= 1024) {
+    if (dim <= 1024 && (unsigned long long)np * dim * 4 < 0xFFFFFFFFull && (unsigned long long)nq * dim * 4 < 0xFFFFFFFFull) {
         const size_t pl = (size_t)30 * dim * 4;
         static size_t pattr = 0;
         if (pl > pattr) {
