@@ -373,7 +373,8 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
             r0 += n
     body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
                                        harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
-    lanes = min(3, len(items)) if matching_list.is_cuda else 1        # (CPU tensors: injected kernels in the gloo tests)
+    # match bodies in flight at once (each is a chain of single-workgroup recurrences: more lanes = more of them side by side)
+    lanes = min(int(os.environ.get("KNNSVC_MATCH_LANES", "3")), len(items)) if matching_list.is_cuda else 1   # (CPU tensors: injected kernels in the gloo tests)
     if vocode_fn is not None and len(items) > 0:
         assert waves_out is not None
         tail = lambda item, r: r + (vocode_fn(r[0], r[2], r[1]),)
