@@ -10,6 +10,7 @@ only host work is file I/O and the chunk bookkeeping.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from pathlib import Path
 
@@ -196,11 +197,69 @@ def prepare_pool(matching_list, split=True):
     return dict(stats=stats, split=ops.prepare_knn_pool(P, C.KNN_K, stats) if split else None)
 
 
+# query frames per grouped search in dataset mode.  Measured (tools/knn_group_ab.sh; cfg 5 share, xRT): 1500 -> 2321, 3000 -> 2349,
+# 8192 -> 1884, everything in one search -> 1864; cfg 3 is flat (1331-1351).  Groups large enough for the fused screen + refine route
+# (>= 4096 rows) LOSE inside a pipeline: its one-block-per-CU, 128 KB-LDS launches leave no room next to them for the single-workgroup
+# recurrences and the generator of the other items.  3000 frames keeps the searches on the 128x128 kernel and ahead of the lanes.
+KNN_GROUP_FRAMES = int(os.environ.get("KNNSVC_KNN_GROUP_FRAMES", "3000"))
+_KNN_STREAMS = {}
+
+
+def _knn_stream(device) -> "torch.cuda.Stream":
+    """The stream the grouped kNN searches of dataset mode run on (ahead of the lanes that consume their results)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _KNN_STREAMS:
+        _KNN_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _KNN_STREAMS[key]
+
+
 def batched_knn(q_all, matching_list, prep):
     """Top-32 of the stacked frames of many query utterances against one prepared pool -> (idx [sum Nq, 32], NaN flag)."""
     idx, _d, fl = ops.knn_topk(q_all, matching_list, C.KNN_K, p_stats=prep["stats"], prepared=prep["split"],
                                check_nan=False, return_flag=True)
     return idx, fl
+
+
+def grouped_knn(items, query_pool, matching_list, prep, flags):
+    """Top-32 of every item's frames against one prepared pool, searched in GROUPS of at least KNN_GROUP_FRAMES query frames
+    one after the other on a stream of their own: group g + 1 is searched while the match bodies and the generator of group g
+    run, instead of one search of everything in front of the whole pipeline (32 x 30 s sources against a 60-minute pool:
+    16.1 -> 12.8 ms per source).  -> (nn: item -> [Nq, 32] indices, ready: item -> event a consumer
+    on another stream has to wait for; empty without a kNN stream).  Results do not depend on the grouping."""
+    nn, nn_ready = {}, {}
+    groups, cur_g, cur_n = [], [], 0
+    for it in items:
+        cur_g.append(it); cur_n += query_pool[it].shape[0]
+        if cur_n >= KNN_GROUP_FRAMES:
+            groups.append(cur_g); cur_g, cur_n = [], 0
+    if cur_g:
+        groups.append(cur_g)
+    main = torch.cuda.current_stream(matching_list.device) if matching_list.is_cuda else None
+    ks = _knn_stream(matching_list.device) if main is not None and len(groups) > 1 else None
+    if ks is not None:
+        ks.wait_stream(main)
+    for grp in groups:
+        ctx = torch.cuda.stream(ks) if ks is not None else contextlib.nullcontext()
+        with ctx:
+            q_all = torch.cat([query_pool[it] for it in grp], 0).contiguous()
+            idx_all, fl = batched_knn(q_all, matching_list, prep)
+            parts = [t.contiguous() for t in idx_all.split([query_pool[it].shape[0] for it in grp])]
+            ev = ks.record_event() if ks is not None else None
+        if fl is not None:
+            flags.append(fl)
+        for it, t in zip(grp, parts):
+            nn[it] = t
+            if ev is not None:
+                nn_ready[it] = ev
+    return nn, nn_ready
+
+
+def wait_for_neighbours(nn_item, ready_event, device):
+    """Make the current stream wait for a grouped search's result (no-op without an event)."""
+    if ready_event is not None:
+        st = torch.cuda.current_stream(device)
+        st.wait_event(ready_event)
+        nn_item.record_stream(st)
 
 
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
@@ -334,6 +393,7 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
              if required_subset is None or
              os.path.basename(item).split(".")[0] + "/" + os.path.basename(ref_wav_file) in required_subset]
     nn = {}
+    nn_ready = {}                 # item -> event of the kNN-stream search that produced nn[item]
     if shard is not None and share_items:
         # one search of ALL items' frames in every shard, one all-to-all: each rank gets the lists of its own items
         rank, ws = kdist.world()
@@ -359,20 +419,15 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     flags = []
     prep = prepare_pool(matching_list, split=shard is None) if len(items) > 1 else None
     if shard is None and len(items) > 1:
-        # ONE search for the frames of all items (the reference searches 20 rows at a time, ddsp_prematch_dataset.py:1195-1206;
-        # rows are independent): a [sum Nq, 1024] x [Np, 1024] product runs the matrix cores 3-4 x as efficiently as one
-        # ~300-row search per utterance, and large sets take the fused route that never writes the dot matrix
-        q_all = torch.cat([query_pool[it] for it in items], 0).contiguous()
-        idx_all, fl = batched_knn(q_all, matching_list, prep)
-        if fl is not None:
-            flags.append(fl)
-        r0 = 0
-        for it in items:
-            n = query_pool[it].shape[0]
-            nn[it] = idx_all[r0:r0 + n].contiguous()
-            r0 += n
-    body = lambda item: match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
-                                       harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
+        # searches over the frames of SEVERAL items at a time (the reference searches 20 rows at a time,
+        # ddsp_prematch_dataset.py:1195-1206; rows are independent): a [~3000, 1024] x [Np, 1024] product runs the matrix cores
+        # 3-4 x as efficiently as one ~300-row search per utterance
+        g_nn, g_ready = grouped_knn(items, query_pool, matching_list, prep, flags)
+        nn.update(g_nn); nn_ready.update(g_ready)
+    def body(item):
+        wait_for_neighbours(nn.get(item), nn_ready.get(item), matching_list.device)      # a group search on the kNN stream
+        return match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
+                              harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
     # match bodies in flight at once (each is a chain of single-workgroup recurrences: more lanes = more of them side by side)
     lanes = min(int(os.environ.get("KNNSVC_MATCH_LANES", "3")), len(items)) if matching_list.is_cuda else 1   # (CPU tensors: injected kernels in the gloo tests)
     if vocode_fn is not None and len(items) > 0:

@@ -15,7 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from knn_svc_amd import config as C, ops, synthetic as S          # noqa: E402
-from knn_svc_amd.matching import match_features, prepare_pool, side_features   # noqa: E402
+from knn_svc_amd.matching import grouped_knn, match_features, prepare_pool, side_features, wait_for_neighbours   # noqa: E402
 from knn_svc_amd.pipeline import LanePipeline                      # noqa: E402
 from knn_svc_amd.vocoder import Vocoder                            # noqa: E402
 from knn_svc_amd.wavlm import WavLMEncoder                         # noqa: E402
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=3)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--sequential", action="store_true", help="one item after the other on the current stream")
+    ap.add_argument("--per-item-knn", action="store_true", help="one kNN call per source (1500 queries each) instead of one for all")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -60,7 +61,17 @@ def main():
             flags = []
             q = enc.encode_many(src_w, max_batch=32)
             qf0 = [side_features(w, f, ft.shape[0])[0] for w, f, ft in zip(src_w, src_f, q)]     # as get_complete_spk_pool does
-            head = lambda i: match_features(q[i], qf0[i], P, Pf0, Ph, "mix", "post_opt_0.2", nan_flags=flags, pool_prep=prep)
+            # as the dataset-mode path does (matching.grouped_knn): frames of several items per search (fused screen + refine route),
+            # group after group on a stream of its own, each item waiting only for its group
+            if a.per_item_knn:
+                nn = [None] * a.sources
+            else:
+                nn, ready = grouped_knn(list(range(a.sources)), q, P, prep, flags)
+
+            def head(i):
+                if not a.per_item_knn:
+                    wait_for_neighbours(nn[i], ready.get(i), dev)
+                return match_features(q[i], qf0[i], P, Pf0, Ph, "mix", "post_opt_0.2", nan_flags=flags, pool_prep=prep, nn32=nn[i])
             tail = lambda i, r: voc.forward(r[0], r[2], r[1])
             if a.sequential:
                 ys = [tail(i, head(i)) for i in range(a.sources)]
