@@ -698,3 +698,29 @@ def test_f0_yin_against_the_reference_samples_harvest_tracks():
         print(f"{name}: voicing agreement with harvest {agree:.3f}, median pitch deviation {np.median(rel):.4f}, "
               f"deviations > 30 %: {int((rel > 0.3).sum())} of {int(both.sum())}")
         assert agree > 0.75 and np.median(rel) < 0.03 and (rel > 0.3).mean() < 0.15
+
+
+def test_grouped_knn_results_do_not_depend_on_the_grouping(monkeypatch):
+    """Dataset mode searches the frames of several items per kNN call, group after group on a stream of its own
+    (matching.grouped_knn): whatever the group size — one item per search, a few, everything at once (large enough for the fused
+    screen + refine route) — every item gets the same neighbours as from a search of its own, and a consumer on another stream
+    sees them after waiting for the group's event."""
+    from knn_svc_amd import matching
+    ops = _ops()
+    P = S.clustered_features(20000, 1024, 5, n_centres=50).to(DEV)
+    lens = [300, 1500, 77, 2600, 900, 1, 1200]
+    qs = {i: S.clustered_features(n, 1024, 40 + i, n_centres=50).to(DEV) for i, n in enumerate(lens)}
+    prep = matching.prepare_pool(P)
+    want = {i: ops.knn_topk(q, P, 32, check_nan=False, return_flag=True)[0] for i, q in qs.items()}
+    for gf in (1, 1000, 3000, 10 ** 9):
+        monkeypatch.setattr(matching, "KNN_GROUP_FRAMES", gf)
+        flags = []
+        nn, ready = matching.grouped_knn(list(qs), qs, P, prep, flags)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for i in qs:
+                matching.wait_for_neighbours(nn[i], ready.get(i), DEV)
+                assert torch.equal(nn[i], want[i]), (gf, i)
+        torch.cuda.current_stream().wait_stream(side)
+        for f in flags:
+            ops.raise_if_nan(f)
