@@ -238,13 +238,16 @@ def grouped_knn(items, query_pool, matching_list, prep, flags):
     ks = _knn_stream(matching_list.device) if main is not None and len(groups) > 1 else None
     if ks is not None:
         ks.wait_stream(main)
+    prod = ks if ks is not None else main          # the stream the searches are enqueued on (None: CPU stand-ins in the gloo tests)
     for grp in groups:
         ctx = torch.cuda.stream(ks) if ks is not None else contextlib.nullcontext()
         with ctx:
             q_all = torch.cat([query_pool[it] for it in grp], 0).contiguous()
             idx_all, fl = batched_knn(q_all, matching_list, prep)
             parts = [t.contiguous() for t in idx_all.split([query_pool[it].shape[0] for it in grp])]
-            ev = ks.record_event() if ks is not None else None
+            # ALWAYS an ordering token, also for a single group searched on the caller's own stream: the lists are consumed on
+            # lane streams, and a tensor handed out without one is a race waiting for a caller that does not happen to wait
+            ev = prod.record_event() if prod is not None else None
         if fl is not None:
             flags.append(fl)
         for it, t in zip(grp, parts):
@@ -254,12 +257,23 @@ def grouped_knn(items, query_pool, matching_list, prep, flags):
     return nn, nn_ready
 
 
+def ordering_token(device):
+    """Event on the current stream: the token for neighbour lists produced on it (pool-sharded searches)."""
+    return torch.cuda.current_stream(device).record_event()
+
+
 def wait_for_neighbours(nn_item, ready_event, device):
-    """Make the current stream wait for a grouped search's result (no-op without an event)."""
-    if ready_event is not None:
-        st = torch.cuda.current_stream(device)
-        st.wait_event(ready_event)
-        nn_item.record_stream(st)
+    """Make the current stream wait for a neighbour list produced on another stream.  Every device-resident list comes with
+    the event of its producing stream (grouped_knn, ordering_token); a list without one is refused rather than read early."""
+    if nn_item is None:
+        return
+    if ready_event is None:
+        if nn_item.is_cuda:
+            raise RuntimeError("wait_for_neighbours: device-resident neighbour list without an ordering event")
+        return
+    st = torch.cuda.current_stream(device)
+    st.wait_event(ready_event)
+    nn_item.record_stream(st)
 
 
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
@@ -410,10 +424,16 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
                 r0 += n
         kdist.raise_if_any_nan()
         items = owned[rank]
+        if matching_list.is_cuda:
+            tok = ordering_token(matching_list.device)
+            nn_ready.update({it: tok for it in nn})
     elif shard is not None:          # collectives first, in item order on every rank; the match bodies then need none
         for item in items:
             nn[item] = kdist.sharded_knn(query_pool[item].contiguous(), shard, C.KNN_K, replicated=True, counts=counts)[0]
         kdist.raise_if_any_nan()
+        if matching_list.is_cuda:
+            tok = ordering_token(matching_list.device)
+            nn_ready.update({it: tok for it in nn})
     # the per-item bodies are independent chains of mostly single-workgroup kernels: three at a time, each on
     # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
     flags = []

@@ -422,9 +422,11 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
         idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
         dist = torch.empty(nq, k, device=dev, dtype=torch.float32)
         done = False
+        KNN_ROUTE_COUNTS["chunks"] += 1
         if fused and npc >= KNN_FUSED_MIN_P:
             done = _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn[p0:], ps[p0:], k, idx_offset + p0,
                                     (mask[0] - p0, mask[1] - p0), idx, dist, flag)
+        KNN_ROUTE_COUNTS["fused" if done else "dot"] += 1
         if not done:
             q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npc, 1) // 128 * 128))
             for q0 in range(0, nq, q_rows):
@@ -442,6 +444,7 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
     return knn_merge(torch.stack(parts_d), torch.stack(parts_i))
 
 
+KNN_ROUTE_COUNTS = {"chunks": 0, "fused": 0, "dot": 0}     # which route each (search, pool chunk) took: tests assert on it
 KNN_FUSED_MIN_Q, KNN_FUSED_MIN_P = 4096, 32768      # below these the dot matrix is small and the two-kernel route is as fast
 KNN_FUSED_SAMPLE, KNN_FUSED_CAP = 8192, 4096
 

@@ -702,25 +702,43 @@ def test_f0_yin_against_the_reference_samples_harvest_tracks():
 
 def test_grouped_knn_results_do_not_depend_on_the_grouping(monkeypatch):
     """Dataset mode searches the frames of several items per kNN call, group after group on a stream of its own
-    (matching.grouped_knn): whatever the group size — one item per search, a few, everything at once (large enough for the fused
-    screen + refine route) — every item gets the same neighbours as from a search of its own, and a consumer on another stream
-    sees them after waiting for the group's event."""
-    from knn_svc_amd import matching
+    (matching.grouped_knn): whatever the group size — one item per search, a few, everything at once (6578 frames against 40 000
+    pool rows: the fused screen + refine route, asserted through ops.KNN_ROUTE_COUNTS) — every item gets the same neighbours as from
+    a search of its own.  The consumer sits on ANOTHER stream and only waits for the item's event: grouped_knn must hand one out for
+    every item, also when a single group is searched on the caller's own stream (round 2's race)."""
+    from knn_svc_amd import matching, ops as kops
     ops = _ops()
-    P = S.clustered_features(20000, 1024, 5, n_centres=50).to(DEV)
+    P = S.clustered_features(40000, 1024, 5, n_centres=50).to(DEV)
+    assert P.shape[0] >= kops.KNN_FUSED_MIN_P
     lens = [300, 1500, 77, 2600, 900, 1, 1200]
+    assert sum(lens) >= kops.KNN_FUSED_MIN_Q
     qs = {i: S.clustered_features(n, 1024, 40 + i, n_centres=50).to(DEV) for i, n in enumerate(lens)}
     prep = matching.prepare_pool(P)
     want = {i: ops.knn_topk(q, P, 32, check_nan=False, return_flag=True)[0] for i, q in qs.items()}
+    torch.cuda.synchronize()
     for gf in (1, 1000, 3000, 10 ** 9):
         monkeypatch.setattr(matching, "KNN_GROUP_FRAMES", gf)
         flags = []
+        fused0 = kops.KNN_ROUTE_COUNTS["fused"]
         nn, ready = matching.grouped_knn(list(qs), qs, P, prep, flags)
+        assert set(ready) == set(qs), "every item needs an ordering event"
+        sizes, n = [], 0
+        for L in lens:                                      # the grouping rule of grouped_knn
+            n += L
+            if n >= gf:
+                sizes.append(n); n = 0
+        sizes += [n] if n else []
+        assert kops.KNN_ROUTE_COUNTS["fused"] - fused0 == sum(g >= kops.KNN_FUSED_MIN_Q for g in sizes), (gf, sizes)
+        assert gf < 10 ** 9 or sizes == [sum(lens)]
         side = torch.cuda.Stream()
+        got = {}
         with torch.cuda.stream(side):
             for i in qs:
-                matching.wait_for_neighbours(nn[i], ready.get(i), DEV)
-                assert torch.equal(nn[i], want[i]), (gf, i)
+                matching.wait_for_neighbours(nn[i], ready[i], DEV)
+                got[i] = torch.equal(nn[i], want[i])
         torch.cuda.current_stream().wait_stream(side)
+        assert all(got.values()), (gf, got)
         for f in flags:
             ops.raise_if_nan(f)
+    with pytest.raises(RuntimeError):
+        matching.wait_for_neighbours(nn[0], None, DEV)
