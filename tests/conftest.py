@@ -26,8 +26,9 @@ def golden():
 # Order of the GPU suite: the driver runs `pytest -m gpu -x`, so a late failure hides everything behind it.  The tests that compare
 # with reference-generated goldens (models, end-to-end, prematch) run first, then the oracle comparisons at benchmark sizes, then the
 # kernel-level and self-consistency tests.
-_GPU_ORDER = ["test_gpu_models", "test_gpu_fulllength", "test_gpu_fullsize", "test_gpu_f0", "test_gpu_range", "test_gpu_kernels",
-              "test_gpu_product", "test_gpu_dist2"]
+# test_gpu_dist2 has to stay in front: it spawns its ranks and must do so before this interpreter has initialised the GPU.
+_GPU_ORDER = ["test_gpu_dist2", "test_gpu_models", "test_gpu_product", "test_gpu_fulllength", "test_gpu_fullsize", "test_gpu_f0",
+              "test_gpu_range", "test_gpu_kernels"]
 
 
 def pytest_collection_modifyitems(config, items):
