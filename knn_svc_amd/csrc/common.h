@@ -40,6 +40,9 @@ __device__ __forceinline__ float kn_gelu(float x) {
 #ifdef KN_GELU_ERFF
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 #else
+    // contraction off: whether `1 - p * e` became one fma used to depend on the code around the call, so the same activation could
+    // differ by an ulp between two kernels (or two epilogue variants of one kernel); every rounding below is now spelled out
+#pragma clang fp contract(off)
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.39f, z, 1.0f));
     float p = -0.1137684788031453f;                       // 0.5 x the fitted coefficients

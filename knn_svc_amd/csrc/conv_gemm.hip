@@ -569,6 +569,106 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
     if (a.out_absmax) publish_absmax(a.out_absmax, amax);
 }
 
+// Specialised forms of conv_epilogue_wide for the epilogues the encoder's large GEMMs actually have.  An in-kernel phase
+// trace (tools/quad_prof.sh, -DKN_QUAD_PROF) showed where a K = 1024 tile's time went: prologue 2 us, main loop 61 us
+// (= 560 TFLOP/s fp32-equivalent over the chip), epilogue 26-28 us without and 46-47 us with a residual operand — and the
+// cause was not memory: every trip of the rolled loop ran the GENERIC path, if-converted by the compiler — four IEEE
+// divisions by `div` (selected away afterwards), tanh / leaky-ReLU / GELU bodies under exec masks, residual and accumulate
+// selects — ~250 VALU instructions per trip for 4 useful adds, 64 trips per wave; and the residual load was prefetched only
+// one trip ahead, adding one memory latency per trip.  Here the variant is a template parameter:
+//   ACT  0 = none, 1 = GELU;   RES: residual operand (fp32 output);   without RES the output may be split from a wave-tile
+//   column on (a.out_split / a.split_from, wave-uniform).  No accumulate, div == 1, no range slot — anything else takes the
+//   generic form.  With RES the 16 residual pieces of the NEXT band are requested before the current band's trips run.
+template <class G, int ACT, bool RES>
+__device__ __forceinline__ void conv_epilogue_wide_fast(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], float* lds_generic,
+                                                        int m0, int n0, int b, int g) {
+    static_assert(G::NR == 4, "16x16-tile accumulator layout");
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    constexpr int ETN = G::TN / 2, ETM = G::TM / 2;
+    constexpr int PITCH = ETN * 32 + 4;
+    constexpr int TRIPS = (32 * ETN * 32 / 4) / 64;
+    constexpr int RSTEP = 64 / (ETN * 8);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lds_f* patch = (lds_f*)lds_generic + wave * (32 * PITCH);
+    float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
+    const float* rz = RES ? a.resid + b * a.r_bstride + g * a.r_gstride : nullptr;
+    const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
+    const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, ((a.m - 1) * a.ldo + a.n) * 4);
+    const __amdgpu_buffer_rsrc_t r_rsrc = uniform_rsrc(RES ? (const void*)rz : (const void*)oz, RES ? ((a.m - 1) * a.ldr + a.n) * 4 : 0);
+    const int wrow0 = m0 + (wave / G::WN) * ETM * 32, wcol0 = n0 + (wave % G::WN) * ETN * 32;
+    const int c = (lane & (ETN * 8 - 1)) * 4, n = wcol0 + c;
+    const int row_in_trip = lane / (ETN * 8);
+    const bool nv = n < a.n;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (bz && nv) {
+        if (a.bias_period) { for (int e = 0; e < 4; ++e) bias4[e] = bz[(n + e) % a.bias_period]; }
+        else bias4 = *(const f32x4*)(bz + n);
+    }
+    const bool sp = !RES && a.out_split && wcol0 >= a.split_from;          // wave-uniform
+    const float oscale = a.out_scale, sscale = a.split_scale;
+    const int row_pitch_o = a.ldo * 4 * RSTEP, row_pitch_r = RES ? a.ldr * 4 * RSTEP : 0;
+    f32x4 rnext[RES ? TRIPS : 1];
+    auto load_band = [&](int i) {
+        if constexpr (RES) {
+            int off = nv ? ((wrow0 + i * 32 + row_in_trip) * a.ldr + n) * 4 : OOB;
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it) {
+                rnext[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
+                if (nv) off += row_pitch_r;
+            }
+        }
+    };
+    load_band(0);
+#pragma unroll
+    for (int i = 0; i < ETM; ++i) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    patch[(t * 16 + 4 * (lane >> 4) + r) * PITCH + j * 16 + (lane & 15)] = acc[2 * i + t][j][r] * oscale;
+        f32x4 rcur[RES ? TRIPS : 1];
+        if constexpr (RES) {
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it) rcur[it] = rnext[it];
+            if (i + 1 < ETM) load_band(i + 1);
+        }
+        const lds_f* prow = patch + row_in_trip * PITCH + c;
+        const int mrow = wrow0 + i * 32 + row_in_trip;
+        if (sp) {       // f16x2 split layout: (row, n) -> hi at (n/32)*128 + (n%32)*2, lo 64 bytes further
+            int off = nv ? mrow * a.ldo * 4 + (n >> 5) * 128 + (n & 31) * 2 : OOB;
+#pragma unroll 4
+            for (int it = 0; it < TRIPS; ++it) {
+                f32x4 v = *(const lds_f4*)(prow + it * RSTEP * PITCH) + bias4;
+                if constexpr (ACT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
+                }
+                g2_u32x2 hi, lo;
+                f16x2_split4(v, sscale, hi, lo);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, o_rsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(lo, o_rsrc, off, 64, 0);      // OOB + 64 is still out of range
+                if (nv) off += row_pitch_o;
+            }
+        } else {
+            int off = nv ? (mrow * a.ldo + n) * 4 : OOB;
+#pragma unroll 4
+            for (int it = 0; it < TRIPS; ++it) {
+                f32x4 v = *(const lds_f4*)(prow + it * RSTEP * PITCH) + bias4;
+                if constexpr (ACT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
+                }
+                if constexpr (RES) v += rcur[it];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, off, 0, 0);
+                if (nv) off += row_pitch_o;
+            }
+        }
+    }
+}
+
 template <class G, int VEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -840,9 +940,13 @@ int launch2ring(const ConvArgs& a, int batches, hipStream_t st) {
 }
 
 // A2 activations + split weights by LDS-DMA, 256x256 block / 128x128 wave tiles, hand-pipelined loop (gemm2_core.h, Gemm2Quad)
-template <class G>
+// EPI: 0 = generic epilogue (conv_epilogue_wide), 1 = bias (+ split columns), 2 = bias + GELU (+ split columns), 3 = bias + residual
+template <class G, int EPI = 0>
 __global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef KN_QUAD_PROF
+    if (threadIdx.x == 0 && blockIdx.x < 8192) kn_quad_prof_buf[blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
@@ -893,23 +997,34 @@ __global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
     conv_epilogue_lin<G>(a, acc, m0, n0, b, g);
 #else
     __syncthreads();                                  // every wave is done with the ring: its stages become the epilogue patches
-    conv_epilogue_wide<G>(a, acc, lds, m0, n0, b, g);
+#ifdef KN_QUAD_PROF
+    if (threadIdx.x == 0 && blockIdx.x < 8192) kn_quad_prof_buf[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    if constexpr (EPI == 1) conv_epilogue_wide_fast<G, 0, false>(a, acc, lds, m0, n0, b, g);
+    else if constexpr (EPI == 2) conv_epilogue_wide_fast<G, 1, false>(a, acc, lds, m0, n0, b, g);
+    else if constexpr (EPI == 3) conv_epilogue_wide_fast<G, 0, true>(a, acc, lds, m0, n0, b, g);
+    else conv_epilogue_wide<G>(a, acc, lds, m0, n0, b, g);
+#ifdef KN_QUAD_PROF
+    __builtin_amdgcn_s_waitcnt(0);                    // stores acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) kn_quad_prof_buf[blockIdx.x * 4 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 #endif
 }
 
-template <class G>
+template <class G, int EPI = 0>
 int launch2quad(const ConvArgs& a, int batches, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_gemm2quad_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_gemm2quad_kernel<G, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G::LDS_BYTES) != hipSuccess)
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
     const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
     dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2quad_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_gemm2quad_kernel<G, EPI>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2quad");
 }
 
@@ -1197,7 +1312,15 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
                 if (qd && qd[0] == '1') { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
                 const char* q16 = getenv("KNNSVC_QUAD16");
                 if (q16 && q16[0] == '0') { g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st); }
-                g_last_kernel = "Q256S"; return launch2quad<Q256S>(a, d->batches, st);
+                // specialised epilogues (conv_epilogue_wide_fast): bias (+ split), GELU (+ split), residual; KNNSVC_QUAD_EPI=0: generic
+                const char* qf = getenv("KNNSVC_QUAD_EPI");
+                const bool fast_epi = !(qf && qf[0] == '0') && !d->accumulate && a.div == 1.0f && !a.out_absmax &&
+                                      (d->act == KNNSVC_ACT_NONE || d->act == KNNSVC_ACT_GELU) && !(d->resid && d->act != KNNSVC_ACT_NONE);
+                g_last_kernel = "Q256S";
+                if (fast_epi && d->resid) return launch2quad<Q256S, 3>(a, d->batches, st);
+                if (fast_epi && d->act == KNNSVC_ACT_GELU) return launch2quad<Q256S, 2>(a, d->batches, st);
+                if (fast_epi) return launch2quad<Q256S, 1>(a, d->batches, st);
+                return launch2quad<Q256S>(a, d->batches, st);
             }
         }
         if (d->n > 64 && a.x_split) {
@@ -1327,3 +1450,10 @@ extern "C" int knnsvc_absmax(const float* x, int64_t rows, int32_t cols, int32_t
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)rows, cols, ld, vec, slot);
     return knnsvc_check_launch("absmax");
 }
+
+#ifdef KN_QUAD_PROF
+extern "C" int knnsvc_debug_quad_prof(long long* host, int n_blocks) {
+    if (n_blocks > 8192) n_blocks = 8192;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(kn_quad_prof_buf), (size_t)n_blocks * 4 * sizeof(long long)) == hipSuccess ? 0 : 3;
+}
+#endif

@@ -41,6 +41,10 @@ __device__ __forceinline__ void f16x2_split4(f32x4 v, float scale, g2_u32x2& hi,
     lo = (g2_u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 
+#ifdef KN_QUAD_PROF      // timing aid (tools/quad_prof.py): per block start / prologue done / main loop done / epilogue done, 10 ns ticks
+__device__ long long kn_quad_prof_buf[8192 * 4];
+#endif
+
 template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
 struct Gemm2Tile {
     typedef f32x16 acc_t;
@@ -1013,6 +1017,9 @@ struct Gemm2QuadS {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+#ifdef KN_QUAD_PROF
+        if (threadIdx.x == 0 && blockIdx.x < 8192) kn_quad_prof_buf[blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) KN_S_READ_A(0, 0, 0, i)
 #pragma unroll

@@ -155,6 +155,25 @@ def test_linear_quad_kernel(M, K, N, q16, monkeypatch):
             assert float((ops.split_unpack(oh[:, 32:].contiguous().to(DEV)).cpu().double() - ref[:, 32:]).abs().max()) < 3e-5 * max(1.0, (K / 1024) ** 0.5)
     # same products, same order along K inside a tile row: the two kernels agree to fp32 accumulation noise
     assert float((outs["2"] - outs["0"]).abs().max()) < 2e-5 * max(1.0, (K / 1024) ** 0.5)
+    # the specialised epilogues (conv_epilogue_wide_fast: bias, GELU, residual, split columns) against the generic one: same
+    # arithmetic in the same order -> the same bits
+    if q16 == "1":
+        monkeypatch.setenv("KNNSVC_QUAD", "2")
+        res = {}
+        for epi in ("1", "0"):
+            monkeypatch.setenv("KNNSVC_QUAD_EPI", epi)
+            r_ = [ops.linear(xs, wd, b.to(DEV), x_split=True), ops.linear(xs, wd, None, x_split=True),
+                  ops.linear(xs, wd, b.to(DEV), act=ops.ACT_GELU, x_split=True),
+                  ops.linear(xs, wd, b.to(DEV), resid=r.to(DEV), x_split=True)]
+            if N % 128 == 0:
+                r_ += [ops.linear(xs, wd, b.to(DEV), act=ops.ACT_GELU, x_split=True, out_split=True),
+                       ops.linear(xs, wd, b.to(DEV), x_split=True, out_split=128 if N > 128 else True)]
+            assert ops.last_conv_kernel() == "Q256S"
+            res[epi] = [t.cpu() for t in r_]
+        assert float((res["1"][2].double() - torch.nn.functional.gelu(ref)).abs().max()) < 3e-5 * max(1.0, (K / 1024) ** 0.5)
+        for k_, (t1, t0) in enumerate(zip(res["1"], res["0"])):
+            bad = (t1.view(torch.int32) != t0.view(torch.int32))
+            assert not bool(bad.any()), (k_, int(bad.sum()), bad.nonzero()[:4].tolist(), float((t1 - t0).abs().max()))
 
 
 @pytest.mark.parametrize("q16", ["0", "1"])
