@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from knn_svc_amd import config as C, dist as kdist, ops, synthetic as S      # noqa: E402
-from knn_svc_amd.matching import match_features, side_features               # noqa: E402
+from knn_svc_amd.matching import match_features, side_features, side_features_many               # noqa: E402
 from knn_svc_amd.pipeline import LanePipeline                                 # noqa: E402
 from knn_svc_amd.vocoder import Vocoder                                       # noqa: E402
 from knn_svc_amd.wavlm import WavLMEncoder                                    # noqa: E402
@@ -150,12 +150,11 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
         feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
     with torch.cuda.stream(side):
         with stage("side_features"):
-            qf0, _, _ = side_features(src, sf0, 1500)
-            f0s, harms = [], []
-            for w, f in zip(pool_w, pool_f0):
-                a, b, _ = side_features(w, f, 1500)
-                f0s.append(a); harms.append(b)
-            Pf0_loc, Ph_loc = torch.cat(f0s).contiguous(), torch.cat(harms).contiguous()
+            # one batched pass over the source and the 20 pool clips (matching.side_features_many), as get_complete_spk_pool does
+            sides = side_features_many([src] + pool_w, [sf0] + pool_f0, [1500] * (1 + len(pool_w)))
+            qf0 = sides[0][0]
+            Pf0_loc = torch.cat([t[0] for t in sides[1:]]).contiguous()
+            Ph_loc = torch.cat([t[1] for t in sides[1:]]).contiguous()
     qf = feats[-1]
     assert qf.shape[0] == 1500
     P_loc = torch.cat(feats[:-1]).contiguous()

@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 10
+#define KNNSVC_ABI_VERSION 11
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -340,6 +340,15 @@ int knnsvc_flac_encode(const int32_t* pcm, int32_t channels, int64_t n, int32_t 
  * ------------------------------------------------------------------------------------------ */
 /* reflect-pad by `pad` samples each side (torch.stft center=True) : out[n + 2*pad] */
 int knnsvc_reflect_pad(const float* x, int64_t n, int32_t pad, float* out, void* stream);
+/* the same for a batch of signals packed back to back: item b = x[offs[b] .. offs[b+1]) (offs: device int64 [batches+1]) ->
+ * row b of out [batches, stride], zero from n_b + 2*pad on.  One launch per pool instead of one per file
+ * (ddsp_prematch_dataset.py:361 runs torchaudio's Spectrogram file by file). */
+int knnsvc_reflect_pad_batch(const float* x, const int64_t* offs, int32_t batches, int32_t pad, float* out, int64_t stride,
+                             void* stream);
+/* knnsvc_complex_mag + knnsvc_harmonic_amps in one pass over the DFT product (ddsp_prematch_dataset.py:361, 391-404):
+ * reim [rows, ld >= 2*bins], f0 [rows] -> spec [rows, bins], harm [rows, n_harm]; results identical to the two calls. */
+int knnsvc_spec_harm(const float* reim, int64_t rows, int32_t bins, int32_t ld, const float* f0, int32_t n_harm,
+                     float* spec, float* harm, void* stream);
 /* |re + i im| of a [rows, 2*bins] (cos block | sin block) DFT product -> [rows, bins] */
 int knnsvc_complex_mag(const float* reim, int64_t rows, int32_t bins, int32_t ld, float* out, void* stream);
 /* harmonic amplitudes (ddsp_prematch_dataset.py:391-404): spec [T,200], f0 [T] -> harm [T,49] */

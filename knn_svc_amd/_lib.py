@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -78,6 +78,8 @@ SIGNATURES = {
     "knnsvc_f0_harvest_workspace": (i32, [i64, i32, f32, f32, f32, vp, vp]),
     "knnsvc_f0_harvest": (i32, [vp, i64, i32, f32, f32, f32, f32, vp, i64, vp, i64, vp, vp]),
     "knnsvc_reflect_pad": (i32, [vp, i64, i32, vp, vp]),
+    "knnsvc_reflect_pad_batch": (i32, [vp, vp, i32, i32, vp, i64, vp]),
+    "knnsvc_spec_harm": (i32, [vp, i64, i32, i32, vp, i32, vp, vp, vp]),
     "knnsvc_complex_mag": (i32, [vp, i64, i32, i32, vp, vp]),
     "knnsvc_harmonic_amps": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "knnsvc_additive_synth": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp]),

@@ -255,6 +255,72 @@ __global__ void harmonic_amps_kernel(const float* __restrict__ spec, const float
     harm[i] = 0.0108f * v;
 }
 
+// Batched centre padding for the framed-signal STFT GEMM: item b = x[offs[b] .. offs[b+1]) becomes row b of out
+// ([batches, stride]): reflect-padded by `pad` on both sides, zeros from n_b + 2 pad on (the GEMM's K padding and the frames of
+// shorter items).  One launch per pool instead of one per file.
+__global__ __launch_bounds__(256) void reflect_pad_batch_kernel(const float* __restrict__ x, const long* __restrict__ offs, int pad,
+                                                                float* __restrict__ out, long stride) {
+    const int b = blockIdx.y;
+    const long o0 = offs[b], n = offs[b + 1] - o0;
+    float* ob = out + (long)b * stride;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < stride; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < n + 2 * (long)pad) {
+            long j = i - pad;
+            if (j < 0) j = -j;
+            if (j >= n) j = 2 * (n - 1) - j;
+            v = x[o0 + j];
+        }
+        ob[i] = v;
+    }
+}
+
+// complex_mag + harmonic_amps in one pass, one wave per frame: the [2 bins] DFT row is read once, its magnitudes go to the
+// spectrum output AND to LDS, the 49 harmonic taps are gathered from LDS (same arithmetic, operation for operation, as
+// complex_mag_kernel / harmonic_amps_kernel; the unvoiced rule's maximum is a wave reduction instead of one thread's loop
+// over 200 bins — max is exact in any order).
+__global__ __launch_bounds__(256) void spec_harm_kernel(const float* __restrict__ reim, long rows, int bins, int ld,
+                                                        const float* __restrict__ f0, int n_harm, float* __restrict__ spec,
+                                                        float* __restrict__ harm) {
+#pragma clang fp contract(off)
+    extern __shared__ float sh[];                                   // 4 waves x bins
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * 4 + wave;
+    if (t >= rows) return;
+    float* s = sh + wave * bins;
+    const float* r = reim + t * (long)ld;
+    float mx = 0.f;                                                 // magnitudes are >= 0
+    for (int b = lane; b < bins; b += 64) {
+        const float v = hypotf(r[b], r[bins + b]);
+        s[b] = v; spec[t * bins + b] = v;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    // (the LDS row is private to this wave; LDS operations of one wave complete in order)
+    const float f = f0[t];
+    for (int k = lane + 1; k <= n_harm; k += 64) {
+        float v;
+        if (f == 0.f) v = k == 1 ? mx : 0.f;
+        else {
+            const int nb = bins * 8;
+            float pos = ((f * (float)k) * 2.0f) * (float)nb / 16000.0f;
+            pos = fminf(pos, (float)nb);
+            const int gi = (int)rintf(pos);
+            if (gi >= nb) v = 0.f;
+            else {
+                float src = ((float)gi + 0.5f) * 0.125f - 0.5f;
+                if (src < 0.f) src = 0.f;
+                const int i0 = (int)src;
+                const int i1 = i0 + (i0 < bins - 1 ? 1 : 0);
+                const float l1 = src - (float)i0, l0 = 1.0f - l1;
+                v = l0 * s[i0] + l1 * s[i1];
+            }
+        }
+        harm[t * n_harm + (k - 1)] = 0.0108f * v;
+    }
+}
+
 // rows t >= lens[b] of a [batches, T, dim] activation become zero (WavLM's x[padding_mask] = 0, wavlm/WavLM.py:353, 574-575)
 __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, int T, int dim, int ld, const int* __restrict__ lens) {
     const int b = blockIdx.y;
@@ -326,6 +392,25 @@ extern "C" int knnsvc_reflect_pad(const float* x, int64_t n, int32_t pad, float*
     hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, (long)n, pad, out);
     return knnsvc_check_launch("reflect_pad");
+}
+
+extern "C" int knnsvc_reflect_pad_batch(const float* x, const int64_t* offs, int32_t batches, int32_t pad, float* out,
+                                        int64_t stride, void* stream) {
+    KN_REQUIRE(x && offs && out && batches > 0 && batches <= 65535 && pad >= 0 && stride > 2 * (int64_t)pad,
+               "reflect_pad_batch: bad arguments (every item needs n > pad; stride > 2 pad)");
+    const unsigned gx = (unsigned)(cdiv64(stride, 256) < 2048 ? cdiv64(stride, 256) : 2048);
+    hipLaunchKernelGGL(reflect_pad_batch_kernel, dim3(gx, (unsigned)batches), dim3(256), 0, (hipStream_t)stream,
+                       x, (const long*)offs, pad, out, (long)stride);
+    return knnsvc_check_launch("reflect_pad_batch");
+}
+
+extern "C" int knnsvc_spec_harm(const float* reim, int64_t rows, int32_t bins, int32_t ld, const float* f0, int32_t n_harm,
+                                float* spec, float* harm, void* stream) {
+    KN_REQUIRE(reim && f0 && spec && harm && bins > 0 && bins <= 4096 && ld >= 2 * bins && n_harm > 0, "spec_harm: bad arguments");
+    if (rows <= 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(spec_harm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), (size_t)4 * bins * sizeof(float),
+                       (hipStream_t)stream, reim, (long)rows, bins, ld, f0, n_harm, spec, harm);
+    return knnsvc_check_launch("spec_harm");
 }
 
 extern "C" int knnsvc_complex_mag(const float* reim, int64_t rows, int32_t bins, int32_t ld, float* out, void* stream) {

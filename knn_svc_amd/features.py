@@ -53,6 +53,53 @@ def stft_mag(wav_1d: torch.Tensor, n_fft: int = 400, hop: int = 320) -> torch.Te
     return ops.complex_mag(reim, n_fft // 2)
 
 
+def stft_harm_batch(wavs, f0s, Ts, n_fft: int = 400, hop: int = 320, n_harm: int = 49):
+    """STFT magnitudes + harmonic amplitudes of MANY signals in four launches (pad, DFT GEMM, magnitude + harmonics) instead of
+    four per signal: wavs = list of [L_i] device tensors, f0s = list of [>= T_i] device tensors, Ts = frames kept per signal
+    (T_i <= 1 + L_i // hop).  -> list of (spec [T_i, n_fft/2], harm [T_i, n_harm]).  Row for row the same arithmetic as
+    ``stft_mag`` + ``ops.harmonic_amps`` (shorter signals ride along in a batch laid out for the longest one)."""
+    if not wavs:
+        return []
+    dev = wavs[0].device
+    basis = _dft_basis(n_fft, dev)
+    kp = basis.shape[1]
+    bins = n_fft // 2
+    out = [None] * len(wavs)
+    order = sorted(range(len(wavs)), key=lambda i: -wavs[i].numel())          # similar lengths share a batch
+    i0 = 0
+    while i0 < len(order):
+        Lmax = wavs[order[i0]].numel()
+        Tmax = 1 + Lmax // hop
+        stride = ((Tmax - 1) * hop + kp + 3) // 4 * 4
+        # batch: as many as fit ~256 MB of padded signal, and no item shorter than half the longest
+        nb = 1
+        while (i0 + nb < len(order) and (nb + 1) * stride <= (1 << 26) and nb < 4096 and
+               wavs[order[i0 + nb]].numel() * 2 >= Lmax):
+            nb += 1
+        ids = order[i0:i0 + nb]
+        i0 += nb
+        lens = [wavs[i].numel() for i in ids]
+        assert min(lens) > n_fft // 2
+        offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64).to(dev, non_blocking=True)
+        flat = torch.cat([wavs[i].contiguous() for i in ids]) if nb > 1 else wavs[ids[0]].contiguous()
+        xp = ops.reflect_pad_batch(flat, offs, n_fft // 2, stride)
+        reim = torch.empty(nb * Tmax, n_fft, device=dev, dtype=torch.float32)
+        ops.conv_gemm(xp, basis, reim, m=Tmax, n=n_fft, cin=kp, taps=1, stride=1, pad=0, t_in=Tmax, ldx=hop, a_scale=X_SCALE,
+                      batches=nb, x_bstride=stride, o_bstride=Tmax * n_fft)
+        f0b = torch.zeros(nb * Tmax, device=dev, dtype=torch.float32)
+        if all(Ts[i] == Tmax for i in ids):
+            f0b = torch.cat([f0s[i][:Tmax] for i in ids])
+        else:                                         # ragged: one gather-free scatter of the concatenated tracks
+            pos = np.concatenate([r * Tmax + np.arange(Ts[i]) for r, i in enumerate(ids)])
+            f0b[torch.from_numpy(pos).to(dev, non_blocking=True)] = torch.cat([f0s[i][:Ts[i]] for i in ids])
+        spec, harm = ops.spec_harm(reim, bins, f0b.view(-1), n_harm)
+        spec, harm = spec.view(nb, Tmax, bins), harm.view(nb, Tmax, n_harm)
+        for r, i in enumerate(ids):
+            assert Ts[i] <= 1 + lens[r] // hop
+            out[i] = (spec[r, :Ts[i]].contiguous(), harm[r, :Ts[i]].contiguous())
+    return out
+
+
 _RESAMPLE_CACHE = {}
 
 

@@ -90,6 +90,19 @@ def side_features(wav_gpu: torch.Tensor, f0_host: np.ndarray, T: int):
     return f0, harm, spec
 
 
+def side_features_many(wavs_gpu, f0s_host, Ts):
+    """``side_features`` for a list of utterances in four launches (features.stft_harm_batch) instead of four per file.
+    -> list of (f0 [T], harm [T,49], spec [T,200]); identical values."""
+    f0s = []
+    for w, f0, T in zip(wavs_gpu, f0s_host, Ts):
+        assert w.numel() >= C.HOP * T
+        assert abs(len(f0) - T) <= 1 and len(f0) >= T, [len(f0), T]
+        f0s.append(f0[:T].contiguous() if isinstance(f0, torch.Tensor)
+                   else torch.from_numpy(np.ascontiguousarray(f0[:T])).to(w.device, non_blocking=True))
+    res = features.stft_harm_batch(wavs_gpu, f0s, Ts, n_harm=C.N_HARM)
+    return [(f0, harm, spec) for f0, (spec, harm) in zip(f0s, res)]
+
+
 def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_weights=None, device="cuda",
                           duration_limit=None, vad_trigger_level=0, shard_files=False, gather=False):
     """Per-file dicts (matching_pool, synth_pool, audio_synth_pool, spec_synth_pool, f0_pool, harmonics_pool),
@@ -134,9 +147,9 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     loaded = {i: (torch.from_numpy(v[0]).to(dev), v[1]) for i, v in loaded.items() if lo <= i < hi}
     miss = sorted(loaded)
     feats = wavlm.encode_many([loaded[i][0] for i in miss], pow2_batches=True) if miss else []
-    for i, ft in zip(miss, feats):
+    sides = side_features_many([loaded[i][0] for i in miss], [loaded[i][1] for i in miss], [Ts[i] for i in miss])
+    for i, ft, (f0, harm, spec) in zip(miss, feats, sides):
         assert ft.shape[0] == Ts[i]
-        f0, harm, spec = side_features(loaded[i][0], loaded[i][1], Ts[i])
         hits[i] = dict(feats=ft, f0=f0, harm=harm, spec=spec)
         cache.put(keys[i], hits[i], dkeys.get(keys[i]))
     matching, synth, audio, specs, f0p, harmp = {}, {}, {}, {}, {}, {}

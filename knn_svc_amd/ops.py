@@ -683,6 +683,23 @@ def reflect_pad(x1d, pad, extra=0):
     return out
 
 
+def reflect_pad_batch(x_flat, offs, pad, stride):
+    """x_flat: signals back to back, offs: device int64 [B+1] -> [B, stride] (reflect-padded rows, zero tails)."""
+    B = offs.numel() - 1
+    out = torch.empty(B, stride, device=x_flat.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_reflect_pad_batch(_p(x_flat), _p(offs), B, pad, _p(out), stride, _stream()), "reflect_pad_batch")
+    return out
+
+
+def spec_harm(reim, bins, f0, n_harm=49):
+    """DFT product [rows, 2 bins] + f0 [rows] -> (spec [rows, bins], harm [rows, n_harm]) in one pass."""
+    rows = reim.shape[0]
+    spec = torch.empty(rows, bins, device=reim.device, dtype=torch.float32)
+    harm = torch.empty(rows, n_harm, device=reim.device, dtype=torch.float32)
+    check(_lib.load().knnsvc_spec_harm(_p(reim), rows, bins, reim.stride(0), _p(f0), n_harm, _p(spec), _p(harm), _stream()), "spec_harm")
+    return spec, harm
+
+
 def complex_mag(reim, bins):
     rows = reim.shape[0]
     out = torch.empty(rows, bins, device=reim.device, dtype=torch.float32)

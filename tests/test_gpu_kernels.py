@@ -761,3 +761,25 @@ def test_grouped_knn_results_do_not_depend_on_the_grouping(monkeypatch):
             ops.raise_if_nan(f)
     with pytest.raises(RuntimeError):
         matching.wait_for_neighbours(nn[0], None, DEV)
+
+
+def test_side_features_batched_equal_per_file():
+    """matching.side_features_many (one reflect-pad / DFT GEMM / magnitude + harmonics pass per pool, knnsvc_reflect_pad_batch +
+    knnsvc_spec_harm) against matching.side_features file by file (ddsp_prematch_dataset.py:361-404): ragged lengths, unvoiced
+    frames, harmonics beyond Nyquist — the same bits."""
+    from knn_svc_amd import matching
+    lens = [16000 * 3 + 7, 16000 * 3 + 7, 5000, 320 * 40, 16000 * 2 - 1, 48000 + 319, 9000]
+    wavs, f0s, Ts = [], [], []
+    for i, n in enumerate(lens):
+        w, f0 = S.synth_clip(n, 300 + i)
+        T = n // 320
+        f0 = f0[:T + 1].copy()
+        f0[::7] = 0.0                                        # unvoiced frames
+        f0[3::11] *= 9.0                                     # harmonics past the Nyquist bin
+        wavs.append(torch.from_numpy(w).to(DEV)); f0s.append(f0.astype(np.float32)); Ts.append(T)
+    many = matching.side_features_many(wavs, f0s, Ts)
+    for w, f0, T, (f0m, hm, sm) in zip(wavs, f0s, Ts, many):
+        f0o, ho, so = matching.side_features(w, f0, T)
+        assert torch.equal(f0m, f0o) and sm.shape == so.shape == (T, 200) and hm.shape == ho.shape == (T, 49)
+        assert torch.equal(sm, so), float((sm - so).abs().max())
+        assert torch.equal(hm, ho), float((hm - ho).abs().max())
