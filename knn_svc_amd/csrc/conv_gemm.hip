@@ -583,6 +583,7 @@ template <class G, int ACT, bool RES>
 __device__ __forceinline__ void conv_epilogue_wide_fast(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], float* lds_generic,
                                                         int m0, int n0, int b, int g) {
     static_assert(G::NR == 4, "16x16-tile accumulator layout");
+    static_assert(!(RES && ACT != 0), "residual variant has no activation");
     typedef __attribute__((address_space(3))) float lds_f;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
     constexpr int ETN = G::TN / 2, ETM = G::TM / 2;
@@ -608,18 +609,24 @@ __device__ __forceinline__ void conv_epilogue_wide_fast(const ConvArgs& a, typen
     const bool sp = !RES && a.out_split && wcol0 >= a.split_from;          // wave-uniform
     const float oscale = a.out_scale, sscale = a.split_scale;
     const int row_pitch_o = a.ldo * 4 * RSTEP, row_pitch_r = RES ? a.ldr * 4 * RSTEP : 0;
-    f32x4 rnext[RES ? TRIPS : 1];
-    auto load_band = [&](int i) {
+    // residual pieces of up to DEPTH bands in flight (16 x 16 bytes per lane and band): requested DEPTH bands ahead of their
+    // use — with one band ahead every band still waited a full (loaded) memory latency: 34 us of epilogue per tile, 4 x ~7 us
+    constexpr int DEPTH = 3;
+    f32x4 rb[RES ? DEPTH : 1][RES ? TRIPS : 1];
+    auto load_band = [&](int i, f32x4 (&dst)[RES ? TRIPS : 1]) {
         if constexpr (RES) {
             int off = nv ? ((wrow0 + i * 32 + row_in_trip) * a.ldr + n) * 4 : OOB;
 #pragma unroll
             for (int it = 0; it < TRIPS; ++it) {
-                rnext[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
+                dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
                 if (nv) off += row_pitch_r;
             }
         }
     };
-    load_band(0);
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < DEPTH && i < ETM; ++i) load_band(i, rb[i]);
+    }
 #pragma unroll
     for (int i = 0; i < ETM; ++i) {
 #pragma unroll
@@ -629,12 +636,7 @@ __device__ __forceinline__ void conv_epilogue_wide_fast(const ConvArgs& a, typen
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     patch[(t * 16 + 4 * (lane >> 4) + r) * PITCH + j * 16 + (lane & 15)] = acc[2 * i + t][j][r] * oscale;
-        f32x4 rcur[RES ? TRIPS : 1];
-        if constexpr (RES) {
-#pragma unroll
-            for (int it = 0; it < TRIPS; ++it) rcur[it] = rnext[it];
-            if (i + 1 < ETM) load_band(i + 1);
-        }
+        f32x4 (&rcur)[RES ? TRIPS : 1] = rb[RES ? i % DEPTH : 0];
         const lds_f* prow = patch + row_in_trip * PITCH + c;
         const int mrow = wrow0 + i * 32 + row_in_trip;
         if (sp) {       // f16x2 split layout: (row, n) -> hi at (n/32)*128 + (n%32)*2, lo 64 bytes further
@@ -654,16 +656,26 @@ __device__ __forceinline__ void conv_epilogue_wide_fast(const ConvArgs& a, typen
             }
         } else {
             int off = nv ? (mrow * a.ldo + n) * 4 : OOB;
-#pragma unroll 4
-            for (int it = 0; it < TRIPS; ++it) {
-                f32x4 v = *(const lds_f4*)(prow + it * RSTEP * PITCH) + bias4;
-                if constexpr (ACT == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
+            if constexpr (RES) {
+#pragma unroll                      // fully: rcur is a register array
+                for (int it = 0; it < TRIPS; ++it) {
+                    f32x4 v = *(const lds_f4*)(prow + it * RSTEP * PITCH) + bias4;
+                    v += rcur[it];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, off, 0, 0);
+                    if (nv) off += row_pitch_o;
                 }
-                if constexpr (RES) v += rcur[it];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, off, 0, 0);
-                if (nv) off += row_pitch_o;
+                if (i + DEPTH < ETM) load_band(i + DEPTH, rb[i % DEPTH]);
+            } else {
+#pragma unroll 4
+                for (int it = 0; it < TRIPS; ++it) {
+                    f32x4 v = *(const lds_f4*)(prow + it * RSTEP * PITCH) + bias4;
+                    if constexpr (ACT == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, off, 0, 0);
+                    if (nv) off += row_pitch_o;
+                }
             }
         }
     }
