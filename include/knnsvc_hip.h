@@ -105,7 +105,9 @@ typedef struct knnsvc_conv_desc {
      * exact-length launch: the generator's frame-count buckets (hifigan/ddsp_models.py:176-233 is fully convolutional). */
     const int32_t* n_dyn; int32_t dyn_t_in_mul; int32_t dyn_t_in_add; int32_t dyn_m_mul; int32_t dyn_m_add; int32_t dyn_t_out_mul;
     float x_bound_mul; float x_bound_add;
-    /* 1: always the 128x128-tile kernel, whatever the launch size.  The default picks the 256x256-tile kernel for large
+    /* 2: always the 256x256-tile kernel (Gemm2QuadS; needs x_f16x2, n % 4 == 0, 16-byte rows) — what the kNN's dot-matrix
+     * route sets, so that it sums over K exactly as the fused screen kernel does.
+     * 1: always the 128x128-tile kernel, whatever the launch size.  The default picks the 256x256-tile kernel for large
      * launches; the two sum over K in different groupings, so a row's result would depend (in the last bit) on how many other
      * rows and columns the launch has.  The distance GEMM of the kNN sets this: a pool shard of any size gives the distances the
      * whole pool gives (device-count invariance of the sharded search, lib_ongaku_test.py:148-175 is one formula). */
@@ -233,11 +235,13 @@ int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const 
  * more than cap survivors (or one 256x256 tile more than 4096) — the caller must fall back to the dot-matrix route.
  * knnsvc_knn_refine: the reference's distance formula on the candidates, ascending top-k with knnsvc_knn_select's keys,
  * NaN flag, mask and idx_offset semantics: identical results to evaluating every pair.
- * nq * dim and np * dim below 2^28 per call (chunk larger searches). */
+ * nq * dim and np * dim below 2^28 per call (chunk larger searches).
+ * max_blocks: the kernel is persistent (a block walks tiles); 0 = one block per CU, otherwise at most this many blocks
+ * (rounded down to a multiple of 8), so that a search inside a stream pipeline leaves CUs to the other streams' kernels. */
 int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
                       const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
                       int32_t dim, const float* thr, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count, void* cand,
-                      int32_t cap, int32_t* overflow_flag, void* stream);
+                      int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream);
 int knnsvc_knn_refine(const int32_t* cand_count, const void* cand, int32_t cap, const float* q_norm, const float* q_sq,
                       int64_t nq, const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
                       int64_t mask_lo, int64_t mask_hi, int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);

@@ -962,19 +962,10 @@ __global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
     resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
-    // XCD-aware order: ids congruent mod 8 share an L2; an XCD's 32 resident blocks form a (8 row tiles x 4 column tiles)
-    // patch: A panels re-read by 4, weight panels by 8 blocks out of that L2
-    const int gy = (a.n + G::BN - 1) / G::BN;
-    const int gx8 = (int)gridDim.x / gy;
-    constexpr int CW = 4;
-    int L = blockIdx.x;
-    const int full = (gy / CW) * CW * gx8;
-    int c0, cw;
-    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
-    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
-    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
-    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
-    if (m0 >= a.m) return;
+    // XCD-aware order (gemm2_core.h, quad_order_decode)
+    int mt, nt;
+    if (!quad_order_decode((int)blockIdx.x, (a.m + G::BM - 1) / G::BM, (a.n + G::BN - 1) / G::BN, mt, nt)) return;
+    const int m0 = mt * G::BM, n0 = nt * G::BN;
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
 
@@ -1034,8 +1025,7 @@ int launch2quad(const ConvArgs& a, int batches, hipStream_t st) {
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
-    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
-    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
+    dim3 grid((unsigned)quad_order_ids(cdiv64(a.m, G::BM), cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm2quad_kernel<G, EPI>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2quad");
 }
@@ -1300,10 +1290,12 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
                 { g_last_kernel = "F256"; return launch2big<F256>(a, d->batches, st); }
         }
-        if (!d->fixed_tile && a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
+        const bool quad_ok = a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
             (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
             d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
-            d->bias_gstride % 4 == 0) {
+            d->bias_gstride % 4 == 0;
+        KN_REQUIRE(d->fixed_tile != 2 || quad_ok, "conv_gemm: fixed_tile 2 needs the quad kernel's operand layout (split A, 16-byte rows, n % 4 == 0)");
+        if (d->fixed_tile != 1 && quad_ok) {
             // 256x256 block, 128x128 wave tiles, hand-pipelined loop: KNNSVC_QUAD=0 switches it off, =2 forces it for every
             // qualifying launch.  Default kernel: Gemm2QuadS (v_mfma_f32_16x16x32_f16, 32-k slabs); KNNSVC_QUAD16=0 selects its
             // predecessor Gemm2QuadR (32x32x16, 16-k half slabs), KNNSVC_QUAD_DMA=1 the LDS-DMA ring.  Default rule: K >= 1024
@@ -1319,11 +1311,11 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             const int kmin = qk ? atoi(qk) : 1024;
             const char* qg = getenv("KNNSVC_QUAD_GELU");
             const bool transc_ok = !(qg && qg[0] == '0') || (d->act != KNNSVC_ACT_GELU && d->act != KNNSVC_ACT_TANH);
-            if (quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448 && a.K >= kmin && transc_ok)) {
+            if (d->fixed_tile == 2 || quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448 && a.K >= kmin && transc_ok)) {
                 const char* qd = getenv("KNNSVC_QUAD_DMA");
-                if (qd && qd[0] == '1') { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
+                if (qd && qd[0] == '1' && d->fixed_tile != 2) { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
                 const char* q16 = getenv("KNNSVC_QUAD16");
-                if (q16 && q16[0] == '0') { g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st); }
+                if (q16 && q16[0] == '0' && d->fixed_tile != 2) { g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st); }
                 // specialised epilogues (conv_epilogue_wide_fast): bias (+ split), GELU (+ split), residual; KNNSVC_QUAD_EPI=0: generic
                 const char* qf = getenv("KNNSVC_QUAD_EPI");
                 const bool fast_epi = !(qf && qf[0] == '0') && !d->accumulate && a.div == 1.0f && !a.out_absmax &&

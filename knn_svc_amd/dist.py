@@ -109,15 +109,19 @@ def raise_if_any_nan():
     this reads their flags once, takes the maximum over the ranks (so that every rank raises together) and raises."""
     if not _NAN_FLAGS:
         return
-    f = torch.stack([x.reshape(()) for x in _NAN_FLAGS]).max().reshape(1)
+    fl = torch.stack([x.reshape(()) for x in _NAN_FLAGS])
+    f = torch.stack([(fl & 1).max(), ((fl >> 1) & 1).max()])       # [NaN distance, candidate-buffer overflow of the fused route]
     _NAN_FLAGS.clear()
     if dist.is_available() and dist.is_initialized():
         if _host_staged(f):
             f = f.cpu()
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
-    if int(f.item()) != 0:
-        from . import ops
+    nan, over = (int(v) for v in f.tolist())
+    from . import ops
+    if nan:
         raise ops.KnnSvcError("containing nan")
+    if over:            # on every rank together: the caller repeats the searches on the dot-matrix route (ops.retry_on_overflow)
+        raise ops.KnnOverflow("fused kNN route: candidate buffer overflow on some rank")
 
 
 def _hip_merge(part_dist, part_idx):

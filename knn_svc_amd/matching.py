@@ -226,10 +226,16 @@ def _knn_stream(device) -> "torch.cuda.Stream":
     return _KNN_STREAMS[key]
 
 
-def batched_knn(q_all, matching_list, prep):
-    """Top-32 of the stacked frames of many query utterances against one prepared pool -> (idx [sum Nq, 32], NaN flag)."""
+# CUs a grouped search's screening kernel may occupy inside the dataset-mode pipeline (it is persistent: a block walks tiles); the
+# rest stays free for the single-workgroup recurrences and the generator of the items in flight.  0 = all.
+KNN_PIPE_BLOCKS = int(os.environ.get("KNNSVC_KNN_PIPE_BLOCKS", "192"))
+
+
+def batched_knn(q_all, matching_list, prep, max_blocks=0):
+    """Top-32 of the stacked frames of many query utterances against one prepared pool -> (idx [sum Nq, 32], flag: NaN /
+    overflow bits, read by the caller at the end)."""
     idx, _d, fl = ops.knn_topk(q_all, matching_list, C.KNN_K, p_stats=prep["stats"], prepared=prep["split"],
-                               check_nan=False, return_flag=True)
+                               check_nan=False, return_flag=True, max_blocks=max_blocks)
     return idx, fl
 
 
@@ -256,7 +262,7 @@ def grouped_knn(items, query_pool, matching_list, prep, flags):
         ctx = torch.cuda.stream(ks) if ks is not None else contextlib.nullcontext()
         with ctx:
             q_all = torch.cat([query_pool[it] for it in grp], 0).contiguous()
-            idx_all, fl = batched_knn(q_all, matching_list, prep)
+            idx_all, fl = batched_knn(q_all, matching_list, prep, max_blocks=KNN_PIPE_BLOCKS if len(groups) > 1 else 0)
             parts = [t.contiguous() for t in idx_all.split([query_pool[it].shape[0] for it in grp])]
             # ALWAYS an ordering token, also for a single group searched on the caller's own stream: the lists are consumed on
             # lane streams, and a tensor handed out without one is a race waiting for a caller that does not happen to wait
@@ -339,7 +345,12 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
         if nan_flags is not None:
             nan_flags.append(nan_flag)
         else:
-            ops.raise_if_nan(nan_flag)
+            try:
+                ops.raise_if_nan(nan_flag)
+            except ops.KnnOverflow:         # the fused route's candidate buffer overflowed: once more on the dot-matrix route
+                with ops.fused_off():
+                    return match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
+                                          return_debug=return_debug, pool_prep=pool_prep)
     if return_debug:
         return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2,
                                                 iters_wavlm=it1 if it1 is not None else 0,
@@ -419,64 +430,73 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     items = [item for item in query_pool
              if required_subset is None or
              os.path.basename(item).split(".")[0] + "/" + os.path.basename(ref_wav_file) in required_subset]
-    nn = {}
-    nn_ready = {}                 # item -> event of the kNN-stream search that produced nn[item]
-    if shard is not None and share_items:
-        # one search of ALL items' frames in every shard, one all-to-all: each rank gets the lists of its own items
-        rank, ws = kdist.world()
-        owned = [[it for j, it in enumerate(items) if j % ws == r] for r in range(ws)]      # == dist.my_share, per rank
-        order = [it for part in owned for it in part]
-        if order:
-            q_all = torch.cat([query_pool[it] for it in order], 0).contiguous()
-            rows = [sum(query_pool[it].shape[0] for it in part) for part in owned]
-            mine_idx = kdist.sharded_knn_owned(q_all, rows, shard, C.KNN_K, counts=counts)[0]
-            r0 = 0
-            for it in owned[rank]:
-                n = query_pool[it].shape[0]
-                nn[it] = mine_idx[r0:r0 + n].contiguous()
-                r0 += n
-        kdist.raise_if_any_nan()
-        items = owned[rank]
-        if matching_list.is_cuda:
-            tok = ordering_token(matching_list.device)
-            nn_ready.update({it: tok for it in nn})
-    elif shard is not None:          # collectives first, in item order on every rank; the match bodies then need none
-        for item in items:
-            nn[item] = kdist.sharded_knn(query_pool[item].contiguous(), shard, C.KNN_K, replicated=True, counts=counts)[0]
-        kdist.raise_if_any_nan()
-        if matching_list.is_cuda:
-            tok = ordering_token(matching_list.device)
-            nn_ready.update({it: tok for it in nn})
-    # the per-item bodies are independent chains of mostly single-workgroup kernels: three at a time, each on
-    # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
-    flags = []
-    prep = prepare_pool(matching_list, split=shard is None) if len(items) > 1 else None
-    if shard is None and len(items) > 1:
-        # searches over the frames of SEVERAL items at a time (the reference searches 20 rows at a time,
-        # ddsp_prematch_dataset.py:1195-1206; rows are independent): a [~3000, 1024] x [Np, 1024] product runs the matrix cores
-        # 3-4 x as efficiently as one ~300-row search per utterance
-        g_nn, g_ready = grouped_knn(items, query_pool, matching_list, prep, flags)
-        nn.update(g_nn); nn_ready.update(g_ready)
-    def body(item):
-        wait_for_neighbours(nn.get(item), nn_ready.get(item), matching_list.device)      # a group search on the kNN stream
-        return match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
-                              harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
-    # match bodies in flight at once (each is a chain of single-workgroup recurrences: more lanes = more of them side by side)
-    lanes = min(int(os.environ.get("KNNSVC_MATCH_LANES", "3")), len(items)) if matching_list.is_cuda else 1   # (CPU tensors: injected kernels in the gloo tests)
-    if vocode_fn is not None and len(items) > 0:
-        assert waves_out is not None
-        tail = lambda item, r: r + (vocode_fn(r[0], r[2], r[1]),)
-        if matching_list.is_cuda:
-            results = pipeline.LanePipeline(matching_list.device, max(1, lanes)).run(items, body, tail)
+    all_items = items
+
+    def run():
+        items = all_items
+        nn = {}
+        nn_ready = {}                 # item -> event of the kNN-stream search that produced nn[item]
+        if shard is not None and share_items:
+            # one search of ALL items' frames in every shard, one all-to-all: each rank gets the lists of its own items
+            rank, ws = kdist.world()
+            owned = [[it for j, it in enumerate(items) if j % ws == r] for r in range(ws)]      # == dist.my_share, per rank
+            order = [it for part in owned for it in part]
+            if order:
+                q_all = torch.cat([query_pool[it] for it in order], 0).contiguous()
+                rows = [sum(query_pool[it].shape[0] for it in part) for part in owned]
+                mine_idx = kdist.sharded_knn_owned(q_all, rows, shard, C.KNN_K, counts=counts)[0]
+                r0 = 0
+                for it in owned[rank]:
+                    n = query_pool[it].shape[0]
+                    nn[it] = mine_idx[r0:r0 + n].contiguous()
+                    r0 += n
+            kdist.raise_if_any_nan()
+            items = owned[rank]
+            if matching_list.is_cuda:
+                tok = ordering_token(matching_list.device)
+                nn_ready.update({it: tok for it in nn})
+        elif shard is not None:          # collectives first, in item order on every rank; the match bodies then need none
+            for item in items:
+                nn[item] = kdist.sharded_knn(query_pool[item].contiguous(), shard, C.KNN_K, replicated=True, counts=counts)[0]
+            kdist.raise_if_any_nan()
+            if matching_list.is_cuda:
+                tok = ordering_token(matching_list.device)
+                nn_ready.update({it: tok for it in nn})
+        # the per-item bodies are independent chains of mostly single-workgroup kernels: three at a time, each on
+        # its own pair of streams (pipeline.LanePipeline); the NaN flags of their kNN searches are read once at the end
+        flags = []
+        prep = prepare_pool(matching_list, split=shard is None) if len(items) > 1 else None
+        if shard is None and len(items) > 1:
+            # searches over the frames of SEVERAL items at a time (the reference searches 20 rows at a time,
+            # ddsp_prematch_dataset.py:1195-1206; rows are independent): a [~3000, 1024] x [Np, 1024] product runs the matrix cores
+            # 3-4 x as efficiently as one ~300-row search per utterance
+            g_nn, g_ready = grouped_knn(items, query_pool, matching_list, prep, flags)
+            nn.update(g_nn); nn_ready.update(g_ready)
+        def body(item):
+            wait_for_neighbours(nn.get(item), nn_ready.get(item), matching_list.device)      # a group search on the kNN stream
+            return match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
+                                  harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
+        # match bodies in flight at once (each is a chain of single-workgroup recurrences: more lanes = more of them side by side)
+        lanes = min(int(os.environ.get("KNNSVC_MATCH_LANES", "3")), len(items)) if matching_list.is_cuda else 1   # (CPU tensors: injected kernels in the gloo tests)
+        if vocode_fn is not None and len(items) > 0:
+            assert waves_out is not None
+            tail = lambda item, r: r + (vocode_fn(r[0], r[2], r[1]),)
+            if matching_list.is_cuda:
+                results = pipeline.LanePipeline(matching_list.device, max(1, lanes)).run(items, body, tail)
+            else:
+                results = [tail(i, body(i)) for i in items]
+            for item, r in zip(items, results):
+                waves_out[item] = r[3]
+            results = [r[:3] for r in results]
         else:
-            results = [tail(i, body(i)) for i in items]
-        for item, r in zip(items, results):
-            waves_out[item] = r[3]
-        results = [r[:3] for r in results]
-    else:
-        results = pipeline.LanePipeline(matching_list.device, lanes).run(items, body) if lanes > 1 else [body(i) for i in items]
-    for f in flags:
-        ops.raise_if_nan(f)
+            results = pipeline.LanePipeline(matching_list.device, lanes).run(items, body) if lanes > 1 else [body(i) for i in items]
+        for f in flags:
+            ops.raise_if_nan(f)
+        return items, results
+
+    # a candidate-buffer overflow of the fused kNN route (reported by the deferred flags) repeats the searches and the bodies on
+    # the dot-matrix route; under a process group every rank sees it together (dist.raise_if_any_nan)
+    items, results = ops.retry_on_overflow(run)
     for item, (of, hw, sf0) in zip(items, results):
         out_c[item] = of; audio_c[item] = None; f0_c[item] = sf0
         if hw is not None:

@@ -196,7 +196,7 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
     d.w_absmax = w_absmax.data_ptr() if w_absmax is not None else None
     d.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
     d.out_f16x2_scale = out_split_scale
-    d.fixed_tile = 1 if fixed_tile else 0
+    d.fixed_tile = int(fixed_tile)          # False/0: by size, 1/True: the 128x128 kernel, 2: the 256x256 (Gemm2QuadS) kernel
     if x_bound is not None:            # (mul, add): |x| <= mul * max(x_absmax slot) + add — an input that was not measured itself
         d.x_bound_mul, d.x_bound_add = float(x_bound[0]), float(x_bound[1])
     if dyn is not None:
@@ -390,52 +390,59 @@ def prepare_knn_pool(pool, k=32, p_stats=None):
         slot = getattr(p_stats[0], "_slot", None) if p_stats is not None else None      # bound of the whole pool: fine for a chunk
         if slot is None:
             slot = absmax(pc)
-        p2 = torch.empty(npc * (dim // 32) * 64, device=pool.device, dtype=torch.int16)
+        # rows padded to a multiple of 4 (zero images): the dot-matrix GEMM runs on the 256x256 kernel, whose 16-byte epilogue
+        # wants n % 4 == 0 — the padded columns' dots are never looked at (knn_select gets the true row count)
+        npad = -(-npc // 4) * 4
+        p2 = torch.empty(npad * (dim // 32) * 64, device=pool.device, dtype=torch.int16)
+        if npad != npc:
+            p2[npc * (dim // 32) * 64:].zero_()
         check(lib.knnsvc_split_f16x2_dyn(_p(pc), npc, dim, _p(slot), _p(p2), _stream()), "split_pool")
         chunks.append((p0, pc, p2, slot))
     return chunks
 
 
-def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None, allow_fused=True):
-    """Two-kernel route: dot products on the f16x2 GEMM (pool rows = pre-split "weights"), then the reference's distance
-    formula + selection (knnsvc_knn_select).  Both operands are scaled by device-chosen powers of two (range slots, see
-    prepare_knn_pool) — exact, so the dots do not depend on the scale.  Pool and query are chunked so that every buffer
-    resource stays below 1 GiB and the dot matrix below ~1 GiB; pool chunks are folded with knnsvc_knn_merge."""
+def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None, allow_fused=True, max_blocks=0):
+    """q.p^T on the f16x2 matrix-core loop (Gemm2QuadS), then the reference's distance formula + selection.  Two routes over
+    the SAME dot-product bits (both sum over K in the 16x16x32 grouping, whatever the sizes):
+      * fused (default from a few hundred query rows on): knnsvc_knn_screen + knnsvc_knn_refine, no dot matrix (_knn_fused_chunk);
+      * dot matrix: knnsvc_conv_gemm (fixed_tile = 2, pool rows = pre-split "weights") + knnsvc_knn_select.
+    Both operands are scaled by device-chosen powers of two (range slots, see prepare_knn_pool) — exact, so the dots do not
+    depend on the scale.  Pool and query are chunked so that every buffer resource stays below 1 GiB and the dot matrix below
+    ~1 GiB; pool chunks are folded with knnsvc_knn_merge.  ``flag``: bit 0 = NaN distance, bit 1 = the fused route's candidate
+    buffer overflowed (results of that call are then NOT valid: knn_topk / raise_if_nan turn it into a retry on the dot-matrix
+    route) — read by the caller, never here: no host synchronisation inside a search."""
     lib = _lib.load()
     nq, dim = q.shape
     dev = q.device
     q_rows_cap = ((1 << 30) - 1) // (dim * 4) // 128 * 128
     parts_i, parts_d = [], []
-    # the queries are split once into the A2 layout (the weight-split kernel writes exactly that image) and
-    # every column tile of the GEMM stages them with plain copies instead of re-splitting them
-    q2 = None
-    import os
+    # the queries are split once into the A2 layout (the weight-split kernel writes exactly that image)
     q_slot = getattr(qn, "_slot", None)
     if q_slot is None:
         q_slot = absmax(q)
-    if nq >= 128 and os.environ.get("KNNSVC_KNN_A2", "1") != "0":
-        q2 = torch.empty(nq, dim, device=dev, dtype=torch.float32)
-        check(lib.knnsvc_split_f16x2_dyn(_p(q), nq, dim, _p(q_slot), _p(q2), _stream()), "split_queries")
-    fused = allow_fused and knn_fused_on() and q2 is not None and nq >= KNN_FUSED_MIN_Q
+    q2 = torch.empty(nq, dim, device=dev, dtype=torch.float32)
+    check(lib.knnsvc_split_f16x2_dyn(_p(q), nq, dim, _p(q_slot), _p(q2), _stream()), "split_queries")
+    fused = allow_fused and knn_fused_on() and nq >= KNN_FUSED_MIN_Q
     for p0, pc, p2, p_slot in (prepared if prepared is not None else prepare_knn_pool(pool, k, (pn, ps))):
         npc = pc.shape[0]
         idx = torch.empty(nq, k, device=dev, dtype=torch.int64)
         dist = torch.empty(nq, k, device=dev, dtype=torch.float32)
-        done = False
         KNN_ROUTE_COUNTS["chunks"] += 1
         if fused and npc >= KNN_FUSED_MIN_P:
-            done = _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn[p0:], ps[p0:], k, idx_offset + p0,
-                                    (mask[0] - p0, mask[1] - p0), idx, dist, flag)
-        KNN_ROUTE_COUNTS["fused" if done else "dot"] += 1
-        if not done:
-            q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npc, 1) // 128 * 128))
+            KNN_ROUTE_COUNTS["fused"] += 1
+            _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn[p0:], ps[p0:], k, idx_offset + p0,
+                             (mask[0] - p0, mask[1] - p0), idx, dist, flag, max_blocks)
+        else:
+            KNN_ROUTE_COUNTS["dot"] += 1
+            npad = -(-npc // 4) * 4
+            q_rows = max(128, min(nq, q_rows_cap, (1 << 28) // max(npad, 1) // 128 * 128))
             for q0 in range(0, nq, q_rows):
-                qc = (q2 if q2 is not None else q)[q0:q0 + q_rows]
+                qc = q2[q0:q0 + q_rows]
                 m = qc.shape[0]
-                dots = torch.empty(m, npc, device=dev, dtype=torch.float32)
-                conv_gemm(qc, pc, dots, m=m, n=npc, cin=dim, w2=p2, x_split=q2 is not None, x_absmax=q_slot, w_absmax=p_slot,
-                          fixed_tile=True)      # a shard of any size gives the whole pool's distances
-                check(lib.knnsvc_knn_select(_p(dots), npc, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
+                dots = torch.empty(m, npad, device=dev, dtype=torch.float32)
+                conv_gemm(qc, pc, dots, m=m, n=npad, cin=dim, w2=p2, x_split=True, x_absmax=q_slot, w_absmax=p_slot,
+                          fixed_tile=2)         # a shard / a query set of any size gives the whole search's distance bits
+                check(lib.knnsvc_knn_select(_p(dots), npad, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
                                             idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
                                             _stream()), "knn_select")
         parts_i.append(idx); parts_d.append(dist)
@@ -445,26 +452,47 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
 
 
 KNN_ROUTE_COUNTS = {"chunks": 0, "fused": 0, "dot": 0}     # which route each (search, pool chunk) took: tests assert on it
-KNN_FUSED_MIN_Q, KNN_FUSED_MIN_P = 4096, 32768      # below these the dot matrix is small and the two-kernel route is as fast
-KNN_FUSED_SAMPLE, KNN_FUSED_CAP = 8192, 4096
+# Below these the dot matrix is small and its route is faster (tools/knn_bench.py, profiles/r03_knn_bench.txt; ms, fused / dot matrix:
+# 1500 x 30 000: 0.540 / 0.479, 3000 x 30 000: 0.875 / 0.930, 6000 x 30 000: 1.55 / 1.62, 24 000 x 180 000: 21.8 / 36.0): the threshold
+# pass (sample GEMM + selection, ~0.15 ms whatever the size) has to be earned back.  Round 2 had 4096 / 32768.
+KNN_FUSED_MIN_Q = int(_os.environ.get("KNNSVC_KNN_FUSED_MIN_Q", "2048"))
+KNN_FUSED_MIN_P = int(_os.environ.get("KNNSVC_KNN_FUSED_MIN_P", "8192"))
+KNN_FUSED_CAP = 4096
+KNN_OVERFLOW = 2                  # flag bit: the fused route's candidate buffer overflowed
 
 
 def knn_fused_on() -> bool:
     import os
-    return os.environ.get("KNNSVC_KNN_FUSED", "1") != "0"
+    return os.environ.get("KNNSVC_KNN_FUSED", "1") != "0" and not _FUSED_OFF[0]
 
 
-def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offset, mask, idx_out, dist_out, flag) -> bool:
-    """Large query sets against one pool chunk without a [nq, np] dot matrix (knnsvc_knn_screen / knnsvc_knn_refine):
-    thr = each row's exact k-th distance over an evenly strided SAMPLE of the chunk (the existing two-kernel route on
-    ~8 k pool rows), then the whole chunk through the screening GEMM with those thresholds, then the reference formula on
-    the survivors.  Returns False (nothing written) when a row has more survivors than the candidate buffer holds — the
-    caller then takes the dot-matrix route for this chunk.  One host read of the overflow flag per call."""
+_FUSED_OFF = [False]
+
+
+class fused_off:
+    """Context: every search inside takes the dot-matrix route (the retry after a candidate-buffer overflow)."""
+    def __enter__(self):
+        self.prev = _FUSED_OFF[0]; _FUSED_OFF[0] = True
+    def __exit__(self, *a):
+        _FUSED_OFF[0] = self.prev
+
+
+def knn_sample_rows(npc: int) -> int:
+    """Pool rows in the threshold sample of the fused route: ~1/8 of the chunk, 1024 .. 8192.  A row's expected survivors are
+    32 * stride (its k-th best over a 1-in-stride sample sits at the (32 * stride)-th place of the whole chunk)."""
+    return max(1024, min(8192, npc // 8))
+
+
+def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offset, mask, idx_out, dist_out, flag, max_blocks=0):
+    """One pool chunk without a [nq, np] dot matrix (knnsvc_knn_screen / knnsvc_knn_refine): thr = each row's exact k-th
+    distance over an evenly strided SAMPLE of the chunk (the dot-matrix route on a few thousand pool rows), then the whole chunk
+    through the screening GEMM with those thresholds, then the reference formula on the survivors.  A row with more survivors
+    than the candidate buffer holds (many near-identical pool rows, e.g. silence) sets bit 1 of ``flag``; nothing here reads it."""
     lib = _lib.load()
     nq, dim = q.shape
     npc = pc.shape[0]
     dev = q.device
-    stride = max(1, npc // KNN_FUSED_SAMPLE)
+    stride = max(1, npc // knn_sample_rows(npc))
     sample = pc[::stride].contiguous()
     sn, ss = row_norms(sample)
     sflag = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -475,28 +503,28 @@ def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offse
     thr = sd[:, k - 1].contiguous()
     q_rows = max(256, min(nq, ((1 << 28) - 1) // dim // 256 * 256, (1 << 30) // (KNN_FUSED_CAP * 8) // 256 * 256))
     over = torch.zeros(1, device=dev, dtype=torch.int32)
-    idx_tmp = torch.empty_like(idx_out); dist_tmp = torch.empty_like(dist_out)
     nan_tmp = torch.zeros(1, device=dev, dtype=torch.int32)
     for q0 in range(0, nq, q_rows):
         m = min(q_rows, nq - q0)
         cnt = torch.zeros(m, device=dev, dtype=torch.int32)
         cand = torch.empty(m * KNN_FUSED_CAP * 2, device=dev, dtype=torch.int32)
         check(lib.knnsvc_knn_screen(_p(q2[q0:]), _p(q_slot), _p(qn[q0:]), _p(qs[q0:]), m, _p(p2), _p(p_slot), _p(pn), _p(ps), npc, dim,
-                                    _p(thr[q0:]), mask[0], mask[1], _p(cnt), _p(cand), KNN_FUSED_CAP, _p(over), _stream()), "knn_screen")
+                                    _p(thr[q0:]), mask[0], mask[1], _p(cnt), _p(cand), KNN_FUSED_CAP, _p(over), int(max_blocks), _stream()), "knn_screen")
         check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn), _p(ps), npc, k, idx_offset,
-                                    mask[0], mask[1], _p(idx_tmp[q0:]), _p(dist_tmp[q0:]), _p(nan_tmp), _stream()), "knn_refine")
-    if int(over.item()) != 0:
-        return False
-    idx_out.copy_(idx_tmp); dist_out.copy_(dist_tmp)
-    flag.copy_(torch.maximum(flag, torch.maximum(nan_tmp, sflag)))
-    return True
+                                    mask[0], mask[1], _p(idx_out[q0:]), _p(dist_out[q0:]), _p(nan_tmp), _stream()), "knn_refine")
+    # flag |= nan | sample nan | overflow << 1 (flags are 0/1)
+    flag.copy_(flag | nan_tmp | sflag | (over.clamp(max=1) * KNN_OVERFLOW))
 
 
 def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False, mask=None,
-             prepared=None):
+             prepared=None, max_blocks=0):
     """Ascending cosine-distance top-k of each q row among pool rows -> (idx int64 [nq,k], dist f32 [nq,k]).
     ``mask`` = (lo, hi): pool rows [lo, hi) compete at distance exactly 1 (self-matching of per_spk_extract,
-    ddsp_prematch_dataset.py:1606-1607)."""
+    ddsp_prematch_dataset.py:1606-1607).
+    ``check_nan=True``: the flag is read here (one sync); a NaN raises, a candidate-buffer overflow of the fused route repeats the
+    search on the dot-matrix route.  ``check_nan=False, return_flag=True``: nothing is read; the caller hands the flag to
+    ``raise_if_nan`` once everything is enqueued (KnnOverflow -> it repeats the work with ``fused_off()``).
+    ``max_blocks``: grid cap of the persistent screening kernel (0 = the whole chip)."""
     mask = (0, 0) if mask is None else (int(mask[0]), int(mask[1]))
     _need(q, name="knn.q"); _need(pool, name="knn.pool")
     if not (q.is_contiguous() and pool.is_contiguous()):
@@ -508,9 +536,14 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     pn, ps = p_stats if p_stats is not None else row_norms(pool)
     if knn_mode() == "f16x2" and dim % 32 == 0 and npool >= k and nq > 0 and 1 <= k <= 32:
         flag = torch.zeros(1, device=q.device, dtype=torch.int32)
-        idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask, prepared)
+        idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask, prepared, max_blocks=max_blocks)
         if check_nan:
-            raise_if_nan(flag)
+            try:
+                raise_if_nan(flag)
+            except KnnOverflow:
+                flag.zero_()
+                idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask, prepared, allow_fused=False)
+                raise_if_nan(flag)
         return (idx, dist, flag) if return_flag else (idx, dist)
     ws_bytes = lib.knnsvc_knn_workspace_bytes(nq, npool, k)
     ws = torch.empty(max(ws_bytes, 8), device=q.device, dtype=torch.uint8)
@@ -524,12 +557,30 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     return (idx, dist, flag) if return_flag else (idx, dist)
 
 
+def retry_on_overflow(fn):
+    """fn() with deferred flag checks inside; if one of them reports a candidate-buffer overflow of the fused kNN route, the
+    whole of fn is repeated with every search on the dot-matrix route.  (fn must be repeatable: it recomputes its outputs.)"""
+    try:
+        return fn()
+    except KnnOverflow:
+        with fused_off():
+            return fn()
+
+
+class KnnOverflow(KnnSvcError):
+    """The fused kNN route met a query row with more candidates than its buffer holds: the search has to be repeated on the
+    dot-matrix route (``with ops.fused_off(): ...``).  Not an error of the data — many near-identical pool rows do it."""
+
+
 def raise_if_nan(flag):
-    """Host check of the device NaN flag (one sync).  The reference prints 'containing nan' and
-    sys.exit()s inside fast_cosine_dist (lib_ongaku_test.py:166-169); callers may defer this check to the
-    end of a launch sequence so that it does not split the stream."""
-    if int(flag.item()) != 0:
+    """Host check of a search's device flag (one sync).  Bit 0: a NaN distance — the reference prints 'containing nan' and
+    sys.exit()s inside fast_cosine_dist (lib_ongaku_test.py:166-169).  Bit 1: KnnOverflow.  Callers may defer this check to
+    the end of a launch sequence so that it does not split the stream."""
+    v = int(flag.item())
+    if v & 1:
         raise KnnSvcError("containing nan")
+    if v & KNN_OVERFLOW:
+        raise KnnOverflow("fused kNN route: candidate buffer overflow (repeat with ops.fused_off())")
 
 
 def knn_merge(part_dist, part_idx):

@@ -53,28 +53,33 @@ def match_speaker(matching_pool: dict, spec_pool: dict, f0_pool: dict, harm_pool
     harm_l = torch.cat([harm_pool[k] for k in keys], 0).contiguous()
     p_stats = ops.row_norms(pool_h)
     prepared = ops.prepare_knn_pool(pool_h, C.KNN_K)      # split image of the pool: once per speaker
-    flags = []
 
-    def body(i):
-        key = keys[i]
-        q = ops.round_f16(matching_pool[key])                                       # each 20-row block is rounded (:1596)
-        nn, _, flag = ops.knn_topk(q, pool_h, C.KNN_K, p_stats=p_stats, check_nan=False, return_flag=True,
-                                   mask=(starts[i], starts[i + 1]), prepared=prepared)
-        flags.append(flag)
-        nn_f0 = ops.f0_rerank(nn, f0_pool[key], f0_l)                               # the frame's OWN f0, unshifted (:1634)
-        idx4 = nn_f0[:, :C.KNN_USE].contiguous()
-        ar = ops.amp_ratio(spec_pool[key], spec_l, idx4)
-        w, it = ops.smooth_weights(idx4, harm_l, 1000.0, return_iters=True, row_scale=ar)
-        return dict(slice=(starts[i], starts[i + 1]), nearest_nbrs=nn, nearest_nbrs_f0_priority=nn_f0, amp_ratio=ar,
-                    harmonics_best_weight_para=w, iters=it)
+    def run():
+        flags = []
 
-    n_l = max(1, min(lanes, len(keys)))
-    if n_l > 1:
-        items = pipeline.LanePipeline(pool_h.device, n_l).run(range(len(keys)), body)
-    else:
-        items = [body(i) for i in range(len(keys))]
-    for f in flags:
-        ops.raise_if_nan(f)
+        def body(i):
+            key = keys[i]
+            q = ops.round_f16(matching_pool[key])                                       # each 20-row block is rounded (:1596)
+            nn, _, flag = ops.knn_topk(q, pool_h, C.KNN_K, p_stats=p_stats, check_nan=False, return_flag=True,
+                                       mask=(starts[i], starts[i + 1]), prepared=prepared)
+            flags.append(flag)
+            nn_f0 = ops.f0_rerank(nn, f0_pool[key], f0_l)                               # the frame's OWN f0, unshifted (:1634)
+            idx4 = nn_f0[:, :C.KNN_USE].contiguous()
+            ar = ops.amp_ratio(spec_pool[key], spec_l, idx4)
+            w, it = ops.smooth_weights(idx4, harm_l, 1000.0, return_iters=True, row_scale=ar)
+            return dict(slice=(starts[i], starts[i + 1]), nearest_nbrs=nn, nearest_nbrs_f0_priority=nn_f0, amp_ratio=ar,
+                        harmonics_best_weight_para=w, iters=it)
+
+        n_l = max(1, min(lanes, len(keys)))
+        if n_l > 1:
+            items = pipeline.LanePipeline(pool_h.device, n_l).run(range(len(keys)), body)
+        else:
+            items = [body(i) for i in range(len(keys))]
+        for f in flags:
+            ops.raise_if_nan(f)
+        return items
+
+    items = ops.retry_on_overflow(run)
     return dict(pool=pool_h, pool_harmonics=harm_l, pool_f0=f0_l, pool_spec=spec_l, items=items, keys=keys)
 
 

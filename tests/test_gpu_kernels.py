@@ -625,6 +625,21 @@ def test_knn_fused_route_equals_dot_matrix_route(monkeypatch):
     i2, d2 = run(True)
     i0, d0 = run(False)
     assert torch.equal(i0, i2) and torch.equal(d0, d2)
+    # deferred mode (stream pipelines): nothing is read inside the search; the flag carries the overflow bit and raise_if_nan turns it
+    # into KnnOverflow, which ops.retry_on_overflow answers by repeating the work on the dot-matrix route
+    _i, _d, fl = run(True, check_nan=False, return_flag=True)
+    assert int(fl.item()) & ops.KNN_OVERFLOW
+    with pytest.raises(ops.KnnOverflow):
+        ops.raise_if_nan(fl)
+    calls = []
+
+    def work():
+        calls.append(ops.knn_fused_on())
+        i, d, f = ops.knn_topk(qd, pd, 32, check_nan=False, return_flag=True)
+        ops.raise_if_nan(f)
+        return i, d
+    i3, d3 = ops.retry_on_overflow(work)
+    assert calls == [True, False] and torch.equal(i0, i3) and torch.equal(d0, d3)
     # NaN in a query row is reported by either route
     from knn_svc_amd._lib import KnnSvcError
     qn_ = qd.clone(); qn_[100, 7] = float("nan")

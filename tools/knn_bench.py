@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from knn_svc_amd import ops, synthetic as S
-for nq, npool in ((1500, 30000), (300, 30000), (6000, 30000), (24000, 180000)):
+for nq, npool in ((1500, 30000), (300, 30000), (3000, 30000), (6000, 30000), (3000, 180000), (24000, 180000)):
     q = S.clustered_features(nq, 1024, 1).cuda(); p = S.clustered_features(npool, 1024, 2).cuda()
     qs, ps = ops.row_norms(q), ops.row_norms(p)
     for _ in range(2): ops.knn_topk(q, p, 32, q_stats=qs, p_stats=ps, check_nan=False)

@@ -18,7 +18,7 @@ for _ in range(40):
     ops.linear(xin, w, b, out=out, x_split=True, **kw)
 torch.cuda.synchronize()
 assert ops.last_conv_kernel() == "Q256S", ops.last_conv_kernel()
-nb = min(8192, (-(-M // 256) + 7) // 8 * 8 * -(-N // 256))
+nb = min(8192, (-(-M // 256) + 7) // 8 * 8 * -(-N // 256))       # (the row-padded order: encoder shapes)
 buf = (ctypes.c_longlong * (nb * 4))()
 lib = _lib.load()
 assert lib.knnsvc_debug_quad_prof(buf, nb) == 0
