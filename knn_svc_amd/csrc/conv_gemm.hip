@@ -1311,7 +1311,14 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             const int kmin = qk ? atoi(qk) : 1024;
             const char* qg = getenv("KNNSVC_QUAD_GELU");
             const bool transc_ok = !(qg && qg[0] == '0') || (d->act != KNNSVC_ACT_GELU && d->act != KNNSVC_ACT_TANH);
-            if (d->fixed_tile == 2 || quad == 2 || (quad == 1 && d->n >= 256 && tiles >= 448 && a.K >= kmin && transc_ok)) {
+            // The rule looks at the layer's shape (n, K) only, never at m or the batch: the quad kernel sums over K in another
+            // grouping than the 128x128 kernels, so a rule that counted tiles (round 2: >= 448) made an utterance's features depend,
+            // in their last bits, on how many chunks were encoded with it — enough to flip near-tied neighbours and to make a
+            // source converted in a batch differ from the same source converted alone (tests/test_gpu_product.py).
+            // KNNSVC_QUAD_MIN_TILES restores a tile threshold for A/B runs.
+            const char* qt = getenv("KNNSVC_QUAD_MIN_TILES");
+            const long min_tiles = qt ? atol(qt) : 0;
+            if (d->fixed_tile == 2 || quad == 2 || (quad == 1 && d->n >= 256 && tiles >= min_tiles && a.K >= kmin && transc_ok)) {
                 const char* qd = getenv("KNNSVC_QUAD_DMA");
                 if (qd && qd[0] == '1' && d->fixed_tile != 2) { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
                 const char* q16 = getenv("KNNSVC_QUAD16");

@@ -88,6 +88,21 @@ class KNeighborsVC:
         return pred
 
     @torch.inference_mode()
+    def many_to_one(self, src_files, ref_wav_file, converted_audio_dir=None, ckpt_type="mix", post_opt="post_opt_0.2",
+                    duration_limit=None, target=None):
+        """BASELINE cfg 5 (no counterpart upstream: the reference would call ``special_match`` once per source and rebuild the
+        target pool each time, ddsp_matcher.py:937-1023): MANY sources against ONE target pool that is built once and stays
+        resident, all sources through the stream pipeline as one batch (knn_svc_amd/serving.py).  Under a process group the
+        sources are dealt over the ranks (no collective).  ``target``: a serving.TargetVoice to reuse.  -> written paths (all
+        ranks' on every rank), named like ``special_match``'s outputs."""
+        from . import serving
+        if target is None:
+            target = serving.TargetVoice(self, ref_wav_file, duration_limit)
+        mine = kdist.my_share([str(p) for p in src_files])
+        written = serving.BatchConverter(self, target, ckpt_type, post_opt).convert_files(mine, converted_audio_dir)
+        return kdist.gather_paths(written)
+
+    @torch.inference_mode()
     def bulk_match(self, src_dataset_path, tgt_dataset_path, converted_audio_dir, topk: int = 4, device=None,
                    prioritize_f0=True, ckpt_type="mix", tgt_loudness_db=-16, required_subset_file=None,
                    post_opt="no_post_opt", duration_limit=None):

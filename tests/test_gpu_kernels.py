@@ -69,6 +69,10 @@ def test_linear_split_layout_in_and_out(monkeypatch):
     if not hasattr(wd, "_w2"):
         pytest.skip("KNNSVC_GEMM is not f16x2")
     ref = ops.linear(x, wd, b, act=ops.ACT_GELU)
+    # (by default a pre-split operand with K >= 1024 takes the 256x256 kernel, whatever M: another K grouping — fp32 noise apart)
+    got_q = ops.linear(ops.split_pack(x), wd, b, act=ops.ACT_GELU, x_split=True)
+    assert ops.last_conv_kernel() == "Q256S" and float((got_q - ref).abs().max()) < 2e-5
+    monkeypatch.setenv("KNNSVC_QUAD", "0")          # the same 128x128 kernel for both: staging is the only difference
     got = ops.linear(ops.split_pack(x), wd, b, act=ops.ACT_GELU, x_split=True)
     assert torch.equal(ref, got)
     packed = ops.linear(x, wd, b, act=ops.ACT_GELU, out_split=True)
