@@ -226,22 +226,23 @@ int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const 
                       int64_t mask_lo, int64_t mask_hi,
                       int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
 
-/* Fused route for large query sets (no [nq, np] dot matrix in HBM; lib_ongaku_test.py:148-175 + ddsp_prematch_dataset.py:1195-1210
- * at BASELINE cfg 5 sizes).  knnsvc_knn_screen: q.p^T on the f16x2 matrix-core path (both operands pre-split by
- * knnsvc_split_f16x2_dyn with the range slots q_absmax / p_absmax) with every product screened in registers against
- * thr[row] — a distance the row's k-th best is known not to exceed, e.g. its exact k-th distance over a sample of the pool —
- * using a conservative margin; surviving (pool index, dot) pairs are appended to cand[row][0 .. cap) (8 bytes each),
- * cand_count[row] counts them (caller zeroes cand_count and overflow_flag).  overflow_flag != 0 afterwards: some row had
- * more than cap survivors (or one 256x256 tile more than 4096) — the caller must fall back to the dot-matrix route.
- * knnsvc_knn_refine: the reference's distance formula on the candidates, ascending top-k with knnsvc_knn_select's keys,
- * NaN flag, mask and idx_offset semantics: identical results to evaluating every pair.
+/* Fused route (no [nq, np] dot matrix in HBM; lib_ongaku_test.py:148-175 + ddsp_prematch_dataset.py:1195-1210 at BASELINE cfg 5
+ * sizes).  knnsvc_knn_screen: q.p^T on the f16x2 matrix-core path (both operands pre-split by knnsvc_split_f16x2_dyn with the
+ * range slots q_absmax / p_absmax), every product screened in registers: first conservatively against thr[row], then — the few
+ * survivors — exactly: the reference's distance of the pair as a (distance, pool index) key against (thr[row], thr_idx[row]),
+ * the row's k-th best key over ANY subset of this pool (e.g. a strided sample searched with knnsvc_conv_gemm + knnsvc_knn_select:
+ * thr = its k-th distance, thr_idx = that row's index IN THIS POOL).  Exactly the pairs with key <= that key are appended to
+ * cand[row][0 .. cap) as (pool index, dot) (8 bytes each); cand_count[row] counts them (caller zeroes cand_count and
+ * overflow_flag).  overflow_flag != 0 afterwards: some row had more than cap such pairs — the caller must fall back to the
+ * dot-matrix route.  knnsvc_knn_refine: the reference's distance formula on the candidates, ascending top-k with
+ * knnsvc_knn_select's keys, NaN flag, mask and idx_offset semantics: identical results to evaluating every pair.
  * nq * dim and np * dim below 2^28 per call (chunk larger searches).
  * max_blocks: the kernel is persistent (a block walks tiles); 0 = one block per CU, otherwise at most this many blocks
  * (rounded down to a multiple of 8), so that a search inside a stream pipeline leaves CUs to the other streams' kernels. */
 int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
                       const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
-                      int32_t dim, const float* thr, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count, void* cand,
-                      int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream);
+                      int32_t dim, const float* thr, const int64_t* thr_idx, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count,
+                      void* cand, int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream);
 int knnsvc_knn_refine(const int32_t* cand_count, const void* cand, int32_t cap, const float* q_norm, const float* q_sq,
                       int64_t nq, const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
                       int64_t mask_lo, int64_t mask_hi, int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);

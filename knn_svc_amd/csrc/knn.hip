@@ -405,8 +405,8 @@ __device__ __forceinline__ float knn_pick_scale(const float* slot) {      // == 
 // (tests: fused == dot-matrix, sharded == unsharded, bit for bit).  Round 2 kept both on the 32x32x16 grouping (Gemm2QuadR here,
 // the 128x128 kernel there) and paid ~15 % of the matrix rate for it.
 using QG = Gemm2QuadS;
-constexpr int SCR_LIST = 4096;                       // survivors one 256x256 tile can stage in LDS
-constexpr int SCR_QD = 24;                           // survivors one LANE (256 accumulator elements) can queue
+constexpr int SCR_LIST = 3072;                       // entries of the tile list in LDS (flushed to the rows' global slots when full)
+constexpr int SCR_QD = 40;                           // entries of a lane's queue (drained before a column's 32 elements could overflow it)
 
 // Persistent: block b walks tiles b, b + gridDim.x, ... (gridDim.x a multiple of 8: a tile keeps its XCD).  The host caps the
 // grid (`max_blocks`): inside a stream pipeline the search then leaves CUs to the single-workgroup recurrences and the generator
@@ -414,7 +414,7 @@ constexpr int SCR_QD = 24;                           // survivors one LANE (256 
 __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     const float* __restrict__ q2, const float* __restrict__ q_absmax, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
     const unsigned short* __restrict__ p2, const float* __restrict__ p_absmax, const float* __restrict__ pn, const float* __restrict__ psq,
-    long np, int dim, const float* __restrict__ thr, long mask_lo, long mask_hi,
+    long np, int dim, const float* __restrict__ thr, const long* __restrict__ thr_idx, long mask_lo, long mask_hi,
     int* __restrict__ cand_count, unsigned* __restrict__ cand, int cap, int* __restrict__ overflow, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int gx = (int)((nq + 255) / 256), gy = (int)((np + 255) / 256);
@@ -440,17 +440,28 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
 
     // ---- screening epilogue.  Round 2's form tested every accumulator element under a branch that held two LDS atomics: with
     // ~1 survivor per (row, tile) some lane of a wave took the slow path at ~40 % of its 256 elements — 40-80 us per tile next to a
-    // 64 us main loop.  Now: (1) a branch-light pass over the registers, 3 VALU per element — the test
-    //        1 - dot/(|q||p|) < thr + eps (1 + (|q|^2 + |p|^2)/(|q||p|))     (knn_select_kernel's conservative screen)
-    //     is rearranged to  acc > A1[row] * |p| - (A2[row] + B2[col])  with per-row / per-column constants (eps' = 4.5e-6 instead
-    //     of 3.8e-6 absorbs the rounding of this form: the candidate set only grows, the result stays identical); a survivor goes
-    //     into the lane's private LDS queue (lane-interleaved: conflict-free), no atomics, nothing to wait for;
-    // (2) the queues are drained (a handful of entries per lane) into the tile list with the per-row counts; (3) as before: one
-    //     global atomic per (tile, row) reserves the row's slots, the list is scattered.
+    // 64 us main loop — and its only test was the conservative one, which lets every near-tie through: on audio with silence
+    // (thousands of near-identical pool frames) rows overflowed their candidate buffers and the whole search fell back.  Now:
+    // (1) a branch-light COARSE pass over the registers, 3 VALU per element: knn_select_kernel's conservative screen
+    //        1 - dot/(|q||p|) < thr + eps (1 + (|q|^2 + |p|^2)/(|q||p|))
+    //     rearranged to  acc > A1[row] * |p| - (A2[row] + B2[col])  (eps' = 4.5e-6 instead of 3.8e-6 absorbs this form's rounding);
+    // (2) on its few survivors the EXACT test: the reference's distance from this very dot product (ref_distance, the value the
+    //     refine pass would compute) as a (distance bits, index) key against key32[row], the row's k-th best key over the sample.
+    //     A pool row can only be among the true k best if its key is <= that — ties included, they are ordered by index — so what
+    //     passes is exactly the set {key <= key32}: its size is the RANK of the sample's k-th best in the whole chunk (about
+    //     k * stride), however many near-identical rows the pool holds;
+    // (3) survivors go to the lane's private LDS queue (lane-interleaved: conflict-free), no atomics; the queues are drained
+    //     into the tile list, and the list is flushed to the rows' global candidate slots (one global atomic per (flush, row))
+    //     as often as needed — a tile of silence against silence legitimately yields tens of thousands of candidates.
     float* s_a1 = lds;                                 // [256] |q| (1 - thr - eps') / out_scale   (+huge for rows past nq)
     float* s_a2 = s_a1 + 256;                          // [256] eps' |q|^2 / out_scale
-    int* s_m1 = (int*)(s_a2 + 256);                    // [256] masked pool rows pass this row (thr >= 1)
-    int* s_cnt = s_m1 + 256;                           // [256] survivors per row of this tile
+    float* s_qn = s_a2 + 256;                          // [256] |q|, |q|^2: the exact formula's row operands
+    float* s_qsq = s_qn + 256;
+    unsigned* s_khi = (unsigned*)(s_qsq + 256);        // [256] key32: distance bits, pool index
+    unsigned* s_klo = s_khi + 256;
+    float* s_pn = (float*)(s_klo + 256);               // [256] |p|, |p|^2 of the tile's pool rows: the exact formula's column operands
+    float* s_psq = s_pn + 256;
+    int* s_cnt = (int*)(s_psq + 256);                  // [256] entries per row in the current list
     int* s_base = s_cnt + 256;                         // [256] their first slot in the row's global candidate list
     int* s_n = s_base + 256;                           // [1] entries in the tile list
     unsigned* s_list = (unsigned*)(s_n + 4);           // [SCR_LIST][3]: row << 16 | position in row, pool index, dot bits
@@ -468,9 +479,16 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         const float t = v ? thr[r] : 0.f, n_ = v ? qn[r] : 0.f, sq_ = v ? qsq[r] : 0.f;
         s_a1[tid] = v ? n_ * ((1.0f - t) - EPS) * inv_os : 3.0e38f;        // rows past nq: nothing survives
         s_a2[tid] = v ? EPS * sq_ * inv_os : 0.f;
-        s_m1[tid] = v && !(1.0f > t) ? 1 : 0;
+        s_qn[tid] = n_; s_qsq[tid] = sq_;
+        // a NaN / +inf threshold (a NaN query row) keeps every pair: the refine pass then reports it
+        const bool open = !(t < __builtin_inff());
+        s_khi[tid] = open ? 0xFFFFFFFFu : sortable(t);
+        s_klo[tid] = open ? 0xFFFFFFFFu : (unsigned)(v ? thr_idx[r] : 0);
         s_cnt[tid] = 0;
         if (tid == 0) s_n[0] = 0;
+        const long pc = (long)n0 + tid;
+        s_pn[tid] = pc < np ? pn[pc] : 0.f;
+        s_psq[tid] = pc < np ? psq[pc] : 0.f;
     }
     __syncthreads();
     const bool masked = mask_lo < mask_hi;
@@ -483,12 +501,53 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
             ra1[i][r] = s_a1[row]; ra2[i][r] = s_a2[row];
         }
     int qcnt = 0;
-    bool spill = false;
-    auto push = [&](int row, int col, float accv) {
-        if (qcnt < SCR_QD) {
-            unsigned* e = s_queue + ((qcnt * 256 + tid) << 1);
-            e[0] = ((unsigned)row << 8) | (unsigned)col; e[1] = __float_as_uint(accv * out_scale);      // the dot product
-        } else spill = true;
+    bool capped = false;
+    // all lanes: queues -> tile list -> global slots, repeated until every queue is empty (block-uniform control flow)
+    auto drain_and_flush = [&]() __attribute__((always_inline)) {
+        int e = 0;
+        for (;;) {
+            for (; e < qcnt; ++e) {
+                const unsigned* qe = s_queue + ((e * 256 + tid) << 1);
+                const unsigned code = qe[0];
+                const int row = (int)(code >> 8), col = (int)(code & 255u);
+                // the EXACT test (2): the distance the refine pass would compute for this pair, as a key against key32[row]
+                const float dot = __uint_as_float(qe[1]);
+                const long p = (long)n0 + col;
+                float d = ref_distance(dot, s_qsq[row], s_psq[col], s_qn[row], s_pn[col]);
+                const bool isnan = d != d;
+                if (masked && p >= mask_lo && p < mask_hi) d = 1.f;      // a masked pool row competes at exactly 1
+                const unsigned hi = sortable(d), khi = s_khi[row];
+                if (!(isnan || hi < khi || (hi == khi && (unsigned)p <= s_klo[row]))) continue;
+                const int pos = atomicAdd(&s_n[0], 1);
+                if (pos >= SCR_LIST) break;                          // list full: this entry and the rest after the flush
+                const int lp = atomicAdd(&s_cnt[row], 1);
+                s_list[pos * 3] = ((unsigned)row << 16) | (unsigned)lp;
+                s_list[pos * 3 + 1] = (unsigned)p;
+                s_list[pos * 3 + 2] = qe[1];
+            }
+            __syncthreads();
+            { const int c = s_cnt[tid]; s_base[tid] = c ? atomicAdd(&cand_count[m0 + tid], c) : 0; }
+            __syncthreads();
+            const int n = s_n[0] < SCR_LIST ? s_n[0] : SCR_LIST;
+            for (int x = tid; x < n; x += 256) {
+                const unsigned rl = s_list[x * 3];
+                const int row = (int)(rl >> 16), slot = s_base[row] + (int)(rl & 0xFFFFu);
+                if (slot < cap) {
+                    unsigned* dst = cand + ((long)(m0 + row) * cap + slot) * 2;
+                    dst[0] = s_list[x * 3 + 1]; dst[1] = s_list[x * 3 + 2];
+                } else capped = true;
+            }
+            __syncthreads();
+            s_cnt[tid] = 0;
+            if (tid == 0) s_n[0] = 0;
+            if (!__syncthreads_or(e < qcnt)) break;
+        }
+        qcnt = 0;
+    };
+    auto push = [&](int row, int col, float accv) __attribute__((always_inline)) {
+        unsigned* e = s_queue + ((qcnt * 256 + tid) << 1);           // qcnt < SCR_QD: the queues are drained whenever a lane
+        e[0] = ((unsigned)row << 8) | (unsigned)col;                 // comes within one column's 32 elements of the depth
+        e[1] = __float_as_uint(accv * out_scale);                    // the dot product (out_scale is a power of two: exact)
         ++qcnt;
     };
 #pragma unroll
@@ -498,57 +557,23 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         const bool pv = p < np;
         const float v_pn = pv ? pn[p] : 0.f;
         const float v_b2 = pv ? EPS * psq[p] * inv_os : -__builtin_inff();       // columns past np: the bound becomes +inf
-        if (!masked) {
+        const bool in_mask = masked && pv && p >= mask_lo && p < mask_hi;
 #pragma unroll
-            for (int i = 0; i < QG::TM; ++i)
+        for (int i = 0; i < QG::TM; ++i)
 #pragma unroll
-                for (int r = 0; r < QG::NR; ++r) {
-                    const float bound = fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2));
-                    if (!(acc[i][j][r] <= bound)) push(QG::acc_row(wave, lane, i, r), col, acc[i][j][r]);   // NaN anywhere: a candidate
-                }
-        } else {
-            const bool in_mask = p >= mask_lo && p < mask_hi;
-#pragma unroll
-            for (int i = 0; i < QG::TM; ++i)
-#pragma unroll
-                for (int r = 0; r < QG::NR; ++r) {
+            for (int r = 0; r < QG::NR; ++r) {
+                const float bound = fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2));
+                // (NaN anywhere: the comparison fails and the pair goes to the exact test, which keeps NaN distances;
+                //  a masked pool row competes at exactly 1, whatever its dot product)
+                if ((!(acc[i][j][r] <= bound) || in_mask) && pv) {
                     const int row = QG::acc_row(wave, lane, i, r);
-                    const float bound = fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2));
-                    if (!(acc[i][j][r] <= bound) || (in_mask && pv && s_m1[row])) push(row, col, acc[i][j][r]);   // a masked row competes at exactly 1
+                    if ((long)m0 + row < nq) push(row, col, acc[i][j][r]);
                 }
-        }
-    }
-    // drain: LDS operations of one wave complete in order, the queue entries are this lane's own
-    const int qn_ = qcnt < SCR_QD ? qcnt : SCR_QD;
-    for (int e = 0; __any(e < qn_); ++e) {
-        if (e < qn_) {
-            const unsigned* qe = s_queue + ((e * 256 + tid) << 1);
-            const unsigned code = qe[0], dbits = qe[1];
-            const int row = (int)(code >> 8), col = (int)(code & 255u);
-            if ((long)m0 + row < nq && (long)n0 + col < np) {
-                const int lp = atomicAdd(&s_cnt[row], 1);
-                const int pos = atomicAdd(&s_n[0], 1);
-                if (pos < SCR_LIST && lp < 65536) {
-                    s_list[pos * 3] = ((unsigned)row << 16) | (unsigned)lp;
-                    s_list[pos * 3 + 1] = (unsigned)(n0 + col);
-                    s_list[pos * 3 + 2] = dbits;
-                } else spill = true;
             }
-        }
+        if (__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR)) drain_and_flush();
     }
-    if (spill) atomicOr(overflow, 1);
-    __syncthreads();
-    { const int c = s_cnt[tid]; s_base[tid] = c ? atomicAdd(&cand_count[m0 + tid], c) : 0; }      // one global atomic per (tile, row)
-    __syncthreads();
-    const int n = s_n[0] < SCR_LIST ? s_n[0] : SCR_LIST;
-    for (int e = tid; e < n; e += 256) {
-        const unsigned rl = s_list[e * 3];
-        const int row = (int)(rl >> 16), slot = s_base[row] + (int)(rl & 0xFFFFu);
-        if (slot < cap) {
-            unsigned* dst = cand + ((long)(m0 + row) * cap + slot) * 2;
-            dst[0] = s_list[e * 3 + 1]; dst[1] = s_list[e * 3 + 2];
-        } else atomicOr(overflow, 1);
-    }
+    drain_and_flush();
+    if (capped) atomicOr(overflow, 1);
     __syncthreads();                                   // the list is consumed: the stages take the next tile's operands
   }
 }
@@ -686,15 +711,16 @@ extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_n
 
 extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
                                  const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
-                                 int32_t dim, const float* thr, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count, void* cand,
-                                 int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream) {
-    KN_REQUIRE(q_f16x2 && q_absmax && q_norm && q_sq && p_f16x2 && p_absmax && p_norm && p_sq && thr && cand_count && cand && overflow_flag,
+                                 int32_t dim, const float* thr, const int64_t* thr_idx, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count,
+                                 void* cand, int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream) {
+    KN_REQUIRE(q_f16x2 && q_absmax && q_norm && q_sq && p_f16x2 && p_absmax && p_norm && p_sq && thr && thr_idx && cand_count && cand && overflow_flag,
                "knn_screen: null pointer");
     KN_REQUIRE(nq > 0 && np > 0 && dim >= 32 && dim % 32 == 0 && cap > 0, "knn_screen: bad sizes (dim must be a multiple of 32)");
     KN_REQUIRE(nq * (long)dim * 4 < (1L << 30) && np * (long)dim * 4 < (1L << 30), "knn_screen: operands must stay below 1 GiB (chunk the call)");
     KN_REQUIRE(((uintptr_t)q_f16x2 & 15) == 0 && ((uintptr_t)p_f16x2 & 15) == 0, "knn_screen: 16-byte alignment");
     KN_REQUIRE(max_blocks >= 0, "knn_screen: max_blocks must be >= 0 (0 = one block per CU)");
-    static_assert(QG::LDS_BYTES >= (256 * 5 + 4) * 4 + SCR_LIST * 12 + SCR_QD * 256 * 8, "epilogue state fits the operand stages");
+    static_assert(QG::LDS_BYTES >= (256 * 10 + 4) * 4 + SCR_LIST * 12 + SCR_QD * 256 * 8, "epilogue state fits the operand stages");
+    static_assert(SCR_QD > QG::TM * QG::NR, "a lane queue holds more than one column's elements");
     static bool attr = false;
     static int cus = 0;
     if (!attr) {
@@ -711,7 +737,7 @@ extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, con
     if (blocks > ntiles) blocks = ntiles;              // (ntiles is a multiple of 8)
     hipLaunchKernelGGL(knn_screen_kernel, dim3((unsigned)blocks), dim3(256), QG::LDS_BYTES, (hipStream_t)stream,
                        (const float*)q_f16x2, q_absmax, q_norm, q_sq, (long)nq, (const unsigned short*)p_f16x2, p_absmax, p_norm, p_sq,
-                       (long)np, dim, thr, (long)mask_lo, (long)mask_hi, cand_count, (unsigned*)cand, cap, overflow_flag, (int)ntiles);
+                       (long)np, dim, thr, (const long*)thr_idx, (long)mask_lo, (long)mask_hi, cand_count, (unsigned*)cand, cap, overflow_flag, (int)ntiles);
     return knnsvc_check_launch("knn_screen");
 }
 

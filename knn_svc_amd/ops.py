@@ -499,8 +499,9 @@ def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offse
     # sampled rows inside the masked range must compete at 1 here as they do globally (unmasked, a query's own frames would
     # pull thr below its true k-th distance): sample row j is pool row j * stride
     smask = (-(-max(mask[0], 0) // stride), -(-max(mask[1], 0) // stride)) if mask[0] < mask[1] else (0, 0)
-    _si, sd = _knn_topk_gemm(q, sample, k, 0, qn, qs, sn, ss, sflag, smask, None, allow_fused=False)
+    si, sd = _knn_topk_gemm(q, sample, k, 0, qn, qs, sn, ss, sflag, smask, None, allow_fused=False)
     thr = sd[:, k - 1].contiguous()
+    thr_idx = (si[:, k - 1] * stride).contiguous()                 # sample row j is pool row j * stride
     q_rows = max(256, min(nq, ((1 << 28) - 1) // dim // 256 * 256, (1 << 30) // (KNN_FUSED_CAP * 8) // 256 * 256))
     over = torch.zeros(1, device=dev, dtype=torch.int32)
     nan_tmp = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -509,7 +510,7 @@ def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offse
         cnt = torch.zeros(m, device=dev, dtype=torch.int32)
         cand = torch.empty(m * KNN_FUSED_CAP * 2, device=dev, dtype=torch.int32)
         check(lib.knnsvc_knn_screen(_p(q2[q0:]), _p(q_slot), _p(qn[q0:]), _p(qs[q0:]), m, _p(p2), _p(p_slot), _p(pn), _p(ps), npc, dim,
-                                    _p(thr[q0:]), mask[0], mask[1], _p(cnt), _p(cand), KNN_FUSED_CAP, _p(over), int(max_blocks), _stream()), "knn_screen")
+                                    _p(thr[q0:]), _p(thr_idx[q0:]), mask[0], mask[1], _p(cnt), _p(cand), KNN_FUSED_CAP, _p(over), int(max_blocks), _stream()), "knn_screen")
         check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn), _p(ps), npc, k, idx_offset,
                                     mask[0], mask[1], _p(idx_out[q0:]), _p(dist_out[q0:]), _p(nan_tmp), _stream()), "knn_refine")
     # flag |= nan | sample nan | overflow << 1 (flags are 0/1)

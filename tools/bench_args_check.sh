@@ -1,6 +1,6 @@
 # GPU box: bench.py under unusual but legal argument combinations; prints value / ms per step for each
 for args in "--steps 1 --warmup 0" "--steps 2 --warmup 0 --pipeline-depth 1" "--steps 20 --warmup 5" "--steps 3 --warmup 1 --max-batch 8"; do
-  out=$(timeout -k 10 300 python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1)
+  out=$(timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-configs $args 2>/dev/null | tail -1)
   python - "$args" "$out" <<'PY'
 import json, sys
 try:
