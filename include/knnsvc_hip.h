@@ -116,6 +116,12 @@ typedef struct knnsvc_conv_desc {
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
 
+/* out = (c + (b + a)) / div, elementwise over n floats (n % 4 == 0), max |out| folded into the range slot out_absmax (may be
+ * NULL): the mean of the parallel ResBlock branches of a generator stage (hifigan/ddsp_models.py:218-227).  n_dyn (optional,
+ * device int32): only the first n_dyn * dyn_mul floats are touched (bucketed sequence lengths, see "Dynamic length"). */
+int knnsvc_mean3(const float* a, const float* b, const float* c, int64_t n, float div, float* out, float* out_absmax,
+                 const int32_t* n_dyn, int64_t dyn_mul, void* stream);
+
 /* Split fp32 weights [rows, K] (K % 32 == 0) into three truncated bf16 planes, layout [rows][K/32][3][32]
  * (6 bytes per weight).  With w_bf16x3 set and cin % 32 == 0, knnsvc_conv_gemm evaluates every fp32
  * product as six bf16 MFMAs (a0b0+a0b1+a1b0+a0b2+a2b0+a1b1, fp32 accumulate): fp32-level accuracy at

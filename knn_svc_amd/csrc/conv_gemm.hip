@@ -1462,6 +1462,39 @@ extern "C" int knnsvc_absmax(const float* x, int64_t rows, int32_t cols, int32_t
     return knnsvc_check_launch("absmax");
 }
 
+namespace {
+// out = (c + (b + a)) / div over the first rows * cols floats of contiguous tensors, with max |out| folded into a range slot:
+// the sum of the three parallel ResBlock branches of a generator stage (hifigan/ddsp_models.py:218-227: xs = rb0 + rb1 + rb2,
+// x = xs / num_kernels), in the association the serial accumulate epilogue used — the branches now run on streams of their own.
+__global__ __launch_bounds__(256) void mean3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                    long n4, float div, float* __restrict__ out, float* __restrict__ slot,
+                                                    const int* __restrict__ n_dyn, long dyn_mul4) {
+#pragma clang fp contract(off)
+    if (n_dyn) { const long v = (long)n_dyn[0] * dyn_mul4; n4 = v < n4 ? v : n4; }
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 va = ((const f32x4*)a)[i], vb = ((const f32x4*)b)[i], vc = ((const f32x4*)c)[i];
+        f32x4 v = (vc + (vb + va)) / div;
+        ((f32x4*)out)[i] = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned ab = abs_bits(v[e]); m = ab > m ? ab : m; }
+    }
+    if (slot) publish_absmax(kn_stripe(slot), m);
+}
+}  // namespace
+
+extern "C" int knnsvc_mean3(const float* a, const float* b, const float* c, int64_t n, float div, float* out, float* out_absmax,
+                            const int32_t* n_dyn, int64_t dyn_mul, void* stream) {
+    KN_REQUIRE(a && b && c && out && n >= 0 && n % 4 == 0 && dyn_mul % 4 == 0 && div != 0.f, "mean3: bad arguments (n and dyn_mul are multiples of 4)");
+    KN_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0, "mean3: 16-byte alignment");
+    if (n == 0) return KNNSVC_OK;
+    long blocks = cdiv64(n / 4, 256 * 4);
+    blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, (long)(n / 4), div, out,
+                       out_absmax, n_dyn, (long)(dyn_mul / 4));
+    return knnsvc_check_launch("mean3");
+}
+
 #ifdef KN_QUAD_PROF
 extern "C" int knnsvc_debug_quad_prof(long long* host, int n_blocks) {
     if (n_blocks > 8192) n_blocks = 8192;

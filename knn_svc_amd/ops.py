@@ -230,6 +230,19 @@ def absmax(x2d, slot=None):
     return slot
 
 
+def mean3(a, b, c, div, out, out_absmax=None, dyn=None, row_floats=0):
+    """out = (c + (b + a)) / div over contiguous tensors; ``dyn`` = (device frame count, bucket frames): only the first
+    count * (numel / bucket frames) floats are touched."""
+    n = a.numel()
+    nd, mul = (None, 0)
+    if dyn is not None:
+        nd, mul = dyn[0], n // dyn[1]
+    if not range_slots_on():
+        out_absmax = None
+    check(_lib.load().knnsvc_mean3(_p(a), _p(b), _p(c), n, float(div), _p(out), _p(out_absmax), _p(nd), mul, _stream()), "mean3")
+    return out
+
+
 SLOT_W = 64 * 32     # a range slot is 64 stripes of one 128-byte cache line each (float 32 i = stripe i): include/knnsvc_hip.h
 
 

@@ -13,6 +13,8 @@ one GEMM over K = (k/u)*Cin, N = u*Cout with a row-scatter epilogue.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -85,6 +87,17 @@ class Vocoder:
         self._graph_pool = None if not torch.cuda.is_available() else torch.cuda.graph_pool_handle()
         self.max_graphs = 32
         self.use_graphs = True
+        self.parallel_resblocks = os.environ.get("KNNSVC_PAR_RESBLOCKS", "1") != "0"
+        self._branch = {}
+
+    def _branch_streams(self, dev):
+        """Two side streams per (device, current stream) for the ResBlock branches (the generator may run on several streams)."""
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+        if key not in self._branch:
+            pr = torch.cuda.current_stream(idx).priority
+            self._branch[key] = [torch.cuda.Stream(device=idx, priority=pr) for _ in range(2)]
+        return self._branch[key]
 
     # -------------------------------------------------------------------------------------------
     def _conv(self, x, w, out, *, T_in, cin, cout, k, **kw):
@@ -219,10 +232,12 @@ class Vocoder:
             self._conv(cat[i], self.ccv[i], xc, T_in=t_out, cin=ld_c, cout=cout, k=3, m=t_out, pad=1,
                        x_absmax=cat_slot[i], out_absmax=s_xc)
             xs, s_xs = new(t_out, cout), slot()
-            t1, ra, rb_ = new(t_out, cout), new(t_out, cout), new(t_out, cout)
             nblk = len(self.res[i])
-            for j, blk in enumerate(self.res[i]):
+
+            def branch(j, blk, out_buf, s_out, accumulate, div):
+                """One ResBlock1 (hifigan/ddsp_models.py:13-44): three (dilated conv -> conv + residual) pairs on xc."""
                 kr = blk["k"]
+                t1, ra, rb_ = new(t_out, cout), new(t_out, cout), new(t_out, cout)
                 cur, s_cur = xc, s_xc
                 for m, cv in enumerate(blk["convs"]):
                     d = cv["d"]
@@ -232,13 +247,34 @@ class Vocoder:
                                pad=(kr * d - d) // 2, bias=cv["b1"], a_slope=LRELU, act=ops.ACT_LRELU, act_slope=LRELU,
                                x_absmax=s_cur)
                     last = m == len(blk["convs"]) - 1
-                    dst = xs if last else (ra if cur is not ra else rb_)
-                    s_dst = s_xs if last else slot()
+                    dst = out_buf if last else (ra if cur is not ra else rb_)
+                    s_dst = s_out if last else slot()
                     self._conv(t1, cv["w2"], dst, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, pad=(kr - 1) // 2,
                                bias=cv["b2"], resid=cur, ldr=cout,
-                               accumulate=(last and j > 0), div=(float(nblk) if (last and j == nblk - 1) else 1.0),
+                               accumulate=(last and accumulate), div=(div if last else 1.0),
                                x_absmax=s_cur, x_bound=cv["t1_bound"], out_absmax=s_dst)
                     cur, s_cur = dst, s_dst
+
+            if self.parallel_resblocks and nblk == 3:
+                # the three ResBlocks of a stage (kernel sizes 3 / 7 / 11) only share their input: each runs on a stream of its own
+                # (forked from / joined into the current stream, also inside a graph capture), which fills the chip where one
+                # branch's launches do not — the first stage's convolutions are 470 blocks for 1024 slots — and overlaps the tails
+                # of the others.  Their mean is taken by knnsvc_mean3 in the association the serial epilogues used.
+                main = torch.cuda.current_stream(dev)
+                side = self._branch_streams(dev)
+                outs = [new(t_out, cout) for _ in range(3)]
+                fork = main.record_event()
+                for j in (1, 2):                     # the side branches first: branch 0 follows on the caller's stream
+                    side[j - 1].wait_event(fork)
+                    with torch.cuda.stream(side[j - 1]):
+                        branch(j, self.res[i][j], outs[j], None, False, 1.0)
+                branch(0, self.res[i][0], outs[0], None, False, 1.0)
+                for st in side:
+                    main.wait_stream(st)
+                ops.mean3(outs[0], outs[1], outs[2], float(nblk), xs, out_absmax=s_xs, dyn=dyn)
+            else:
+                for j, blk in enumerate(self.res[i]):
+                    branch(j, blk, xs, s_xs, j > 0, float(nblk) if j == nblk - 1 else 1.0)
             x, s_x, t_cur = xs, s_xs, t_out
         y = new(t_cur, 1)
         self._conv(x, self.post_w, y, T_in=t_cur, cin=x.shape[1], cout=1, k=7, m=t_cur, pad=3, a_slope=0.01,
