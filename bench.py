@@ -456,14 +456,17 @@ def main():
         # Roofline pass: the timed region replays hipGraphs (encoder, vocoder), and HIP events cannot be
         # recorded around individual launches inside a replayed graph.  The same K steps are therefore run
         # once more eagerly with an event pair around every launch of the dominant kernel, on its own stream.
-        enc.use_graphs = voc.use_graphs = False
+        # (only the encoder goes eager: its launches are the ones timed.  The generator keeps replaying its graph — run eagerly,
+        #  its ~110 launches on three streams left the HOST behind the GPU, and every timing of the following conversion then
+        #  included launch gaps: dominant-kernel fraction 0.47 instead of 0.51, kNN stage 0.86 instead of 0.46 ms)
+        enc.use_graphs = False
         timer.enabled = True
         stage.on = True                     # five event pairs per step; the table is printed only with --stages
         for _ in range(a.steps):
             step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
         barrier()
         timer.enabled = False
-        enc.use_graphs = voc.use_graphs = True
+        enc.use_graphs = True
     kdist.raise_if_any_nan()                                            # the deferred NaN flags of every sharded search of this run
     assert y.numel() == SRC_SECONDS * C.SAMPLE_RATE, y.numel()          # 1500 frames x 320
     assert bool(torch.isfinite(y).all()), "non-finite waveform"

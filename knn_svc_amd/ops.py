@@ -577,6 +577,7 @@ def retry_on_overflow(fn):
     try:
         return fn()
     except KnnOverflow:
+        KNN_ROUTE_COUNTS["overflow_retries"] = KNN_ROUTE_COUNTS.get("overflow_retries", 0) + 1
         with fused_off():
             return fn()
 

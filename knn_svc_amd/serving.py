@@ -138,7 +138,11 @@ class BatchConverter:
                 return M.match_features(qpool[i], f0s[i], tg.feats, tg.f0, tg.harm, self.ckpt_type, post_opt,
                                         nan_flags=flags, pool_prep=tg.prep, nn32=nn.get(i))
             tail = lambda i, r: voc(r[0], r[2], r[1])
-            ys = pipeline.LanePipeline(dev, max(1, min(self.lanes, len(items)))).run(items, body, tail)
+            n_lanes = max(1, min(self.lanes, len(items)))
+            from .vocoder import serial_resblocks
+            import contextlib
+            with serial_resblocks() if n_lanes > 1 else contextlib.nullcontext():           # (many streams already)
+                ys = pipeline.LanePipeline(dev, n_lanes).run(items, body, tail)
             peak = torch.stack([y.abs().max() for y in ys])
             for f in flags:
                 ops.raise_if_nan(f)                          # one host read per search, after everything is enqueued

@@ -28,6 +28,21 @@ def _fold(sd, name):
     return torch._weight_norm(sd[name + ".weight_v"].float(), sd[name + ".weight_g"].float(), 0)
 
 
+_SERIAL = [False]
+
+
+class serial_resblocks:
+    """Context: generators run their ResBlock branches one after the other on the caller's stream.  For callers that already
+    keep many streams busy (the dataset-mode / serving pipelines: match lanes + their partner streams + the kNN stream + the
+    tail): HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues and streams that share a queue serialise — two more streams
+    per generator made the cfg 5 share 25-35 % SLOWER (12.0 -> 15.7-18.4 ms per source), while the north-star pipeline (one
+    lane) gains 7 % from them."""
+    def __enter__(self):
+        self.prev = _SERIAL[0]; _SERIAL[0] = True
+    def __exit__(self, *a):
+        _SERIAL[0] = self.prev
+
+
 class Vocoder:
     def __init__(self, state: dict, h: dict, kind: str = "mix", device="cuda"):
         assert kind in ("mix", "f0")
@@ -90,6 +105,9 @@ class Vocoder:
         self.parallel_resblocks = os.environ.get("KNNSVC_PAR_RESBLOCKS", "1") != "0"
         self._branch = {}
 
+    def _par(self) -> bool:
+        return self.parallel_resblocks and not _SERIAL[0]
+
     def _branch_streams(self, dev):
         """Two side streams per (device, current stream) for the ResBlock branches (the generator may run on several streams)."""
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -123,7 +141,7 @@ class Vocoder:
             return self._forward(c, f0, harm)
         q = self.BUCKET_FRAMES
         Nb = -(-N // q) * q
-        key = Nb
+        key = Nb if self._par() else (Nb, "serial")
         ent = self._graphs.get(key)
         if ent is None:
             if key not in self._seen:                      # first sight: eager, exact length
@@ -255,7 +273,7 @@ class Vocoder:
                                x_absmax=s_cur, x_bound=cv["t1_bound"], out_absmax=s_dst)
                     cur, s_cur = dst, s_dst
 
-            if self.parallel_resblocks and nblk == 3:
+            if self._par() and nblk == 3:
                 # the three ResBlocks of a stage (kernel sizes 3 / 7 / 11) only share their input: each runs on a stream of its own
                 # (forked from / joined into the current stream, also inside a graph capture), which fills the chip where one
                 # branch's launches do not — the first stage's convolutions are 470 blocks for 1024 slots — and overlaps the tails

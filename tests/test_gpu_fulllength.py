@@ -93,21 +93,24 @@ def test_attention_full_length_vs_oracle():
         assert float((out[rows].cpu().double() - ref64[rows]).abs().max()) <= 1.5 * cmx + 1e-7
 
 
-def test_vocoder_full_size_300_frames_vs_oracle():
-    """Full-size 'mix' generator (22.9 M parameters), 300 frames = 6 s = 96 000 samples, vs the CPU oracle."""
+@pytest.mark.parametrize("kind", ["mix", "f0"])
+def test_vocoder_full_size_300_frames_vs_oracle(kind):
+    """Full-size generator, both variants — 'mix' (hifigan/ddsp_models.py:405-493: harmonic excitation, 22.9 M parameters) and the
+    f0-only one the wavlm_only checkpoints use (hifigan/ddsp_models_f0.py:106-216, 320-381: sine excitation, BASELINE cfg 1) —,
+    300 frames = 6 s = 96 000 samples, vs the CPU oracle."""
     from knn_svc_amd.vocoder import Vocoder
     from oracle import vocoder_ref
     h = C.HIFIGAN_V1
-    sd = S.seeded_state(S.generator_param_spec(h, "mix"), 2)
+    sd = S.seeded_state(S.generator_param_spec(h, kind), 2)
     g = torch.Generator().manual_seed(3)
     N = 300
     c = torch.randn(N, 1024, generator=g)
     _, f0 = S.synth_clip(N * 320, 5); f0 = torch.from_numpy(f0[:N].copy())
-    harm = torch.rand(N, 49, generator=g) * 0.02
-    ref = vocoder_ref.synthesizer(sd, h, "mix", c[None], f0[None, :, None], harm[None])[0, 0]
-    y = Vocoder(sd, h, "mix", DEV).forward(c.to(DEV), f0.to(DEV), harm.to(DEV))
+    harm = torch.rand(N, 49, generator=g) * 0.02 if kind == "mix" else None
+    ref = vocoder_ref.synthesizer(sd, h, kind, c[None], f0[None, :, None], None if harm is None else harm[None])[0, 0]
+    y = Vocoder(sd, h, kind, DEV).forward(c.to(DEV), f0.to(DEV), None if harm is None else harm.to(DEV))
     mx, rms, rmax, rrms = _stats(y, ref)
-    print(f"full generator, 300 frames: rms {rms:.2e} max|d| {mx:.2e} (ref rms {rrms:.3f})")
+    print(f"full generator ({kind}), 300 frames: rms {rms:.2e} max|d| {mx:.2e} (ref rms {rrms:.3f})")
     assert y.numel() == N * 320 and rms < 2e-6 and mx < 5e-5      # north_star bar: 1e-4 RMS
 
 

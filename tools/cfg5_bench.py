@@ -76,7 +76,9 @@ def main():
             if a.sequential:
                 ys = [tail(i, head(i)) for i in range(a.sources)]
             else:
-                ys = pipe.run(range(a.sources), head, tail)
+                from knn_svc_amd.vocoder import serial_resblocks
+                with serial_resblocks():
+                    ys = pipe.run(range(a.sources), head, tail)
             peak = torch.stack([y.abs().max() for y in ys])
             for f in flags:
                 ops.raise_if_nan(f)
