@@ -6,6 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/profiles_$tag; mkdir -p $O
 cd $R
 timeout 900 python3 bench.py --steps 10 --warmup 2 --stages > $O/bench.out 2> $O/bench.err
+timeout 900 python3 bench.py > $O/${tag}_bench_default_line.json 2> /dev/null
 tail -1 $O/bench.out > $O/${tag}_bench_n1.json
 grep '^\[stage\]' $O/bench.err > $O/${tag}_bench_n1_stages.txt
 grep '^\[gemm\]' $O/bench.err > $O/${tag}_bench_n1_gemm_shapes.txt
@@ -26,10 +27,13 @@ A2=1 KNNSVC_QUAD=2 tools/pmc_cycles.sh quad_$tag 31500 1024 4096 5 > $O/${tag}_p
 python3 tools/knn_bench.py > $O/${tag}_knn_bench.txt 2>&1
 KNNSVC_KNN_FUSED=0 python3 tools/knn_bench.py 2>&1 | tail -1 >> $O/${tag}_knn_bench.txt
 bash tools/quad16_ab.sh > $O/${tag}_quad_vs_f128_real_epilogues.txt 2>&1
+bash tools/quad_fastepi_ab.sh 2>&1 | grep -v amdgpu > $O/${tag}_quad_specialised_vs_generic_epilogue.txt
+bash tools/quad_prof.sh 2>&1 | grep -v amdgpu > $O/${tag}_quad_phase_trace.txt
 python3 tools/gemm_zero.py 31500 1024 4096 > $O/${tag}_gemm_zero_vs_random.txt 2>&1
 python3 tools/layer_error.py 6 6 > $O/${tag}_layer_error.txt 2>&1
 ( python3 tools/vocoder_replay.py; KNNSVC_RANGE_SLOTS=0 python3 tools/vocoder_replay.py ) > $O/${tag}_vocoder_range_slots.txt 2>&1
 python3 tools/cfg5_bench.py --sources 32 --pool-minutes 60 --reps 3 2>/dev/null | tail -1 > $O/${tag}_cfg5_share_1gpu.json
+python3 tools/cfg5_product_bench.py 2>/dev/null | tail -1 > $O/${tag}_cfg5_share_product_entry_1gpu.json
 timeout 600 python3 tools/cfg3_bench.py --speakers 4 --utts 80 2>/dev/null | tail -1 > $O/${tag}_cfg3_1gpu.json
 rm -rf $O/kt $O/kts $O/pmcf $O/pmcw
 ls -la $O
