@@ -116,6 +116,26 @@ typedef struct knnsvc_conv_desc {
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
 
+/* One ResBlock1 iteration of the generator in one launch (hifigan/ddsp_models.py:13-44):
+ *     t1 = lrelu(conv1d(lrelu(x), w1, dilation = dil) + b1);   out = conv1d(t1, w2) + b2 + x
+ * x, out: channel-last [t, channels] fp32 (row pitches ldx / ldo), both convolutions `taps` wide with "same" zero padding; the
+ * inner activation t1 lives only in LDS.  Weights as for knnsvc_conv_gemm: packed [channels, taps * channels] and pre-split
+ * (knnsvc_split_weight_f16x2) with their power-of-two scales.  Activation scales as in "Range": x_absmax is x's range slot
+ * (t1 is bounded by t1_bound_mul * max|x| + t1_bound_add, as knnsvc_conv_desc.x_bound_*), or fixed a1_scale / a2_scale.
+ * out_absmax (optional): max |out| is folded into that slot.  n_dyn (optional): the valid length is n_dyn[0] * dyn_mul <= t.
+ * Results are bit-identical to the two knnsvc_conv_gemm launches.  channels = 32 or 64. */
+typedef struct knnsvc_pair_desc {
+    const float* x; int32_t ldx; int32_t t; int32_t channels; int32_t taps; int32_t dil;
+    const void* w1_f16x2; float w1_scale; const float* b1;
+    const void* w2_f16x2; float w2_scale; const float* b2;
+    float* out; int32_t ldo;
+    float slope;
+    const float* x_absmax; float t1_bound_mul; float t1_bound_add; float a1_scale; float a2_scale;
+    float* out_absmax;
+    const int32_t* n_dyn; int32_t dyn_mul;
+} knnsvc_pair_desc;
+int knnsvc_resblock_pair(const knnsvc_pair_desc* d, void* stream);
+
 /* out = (c + (b + a)) / div, elementwise over n floats (n % 4 == 0), max |out| folded into the range slot out_absmax (may be
  * NULL): the mean of the parallel ResBlock branches of a generator stage (hifigan/ddsp_models.py:218-227).  n_dyn (optional,
  * device int32): only the first n_dyn * dyn_mul floats are touched (bucketed sequence lengths, see "Dynamic length"). */

@@ -40,6 +40,20 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PairDesc(C.Structure):
+    """struct knnsvc_pair_desc (field order and types must match the header)."""
+    _fields_ = [
+        ("x", vp), ("ldx", i32), ("t", i32), ("channels", i32), ("taps", i32), ("dil", i32),
+        ("w1_f16x2", vp), ("w1_scale", f32), ("b1", vp),
+        ("w2_f16x2", vp), ("w2_scale", f32), ("b2", vp),
+        ("out", vp), ("ldo", i32),
+        ("slope", f32),
+        ("x_absmax", vp), ("t1_bound_mul", f32), ("t1_bound_add", f32), ("a1_scale", f32), ("a2_scale", f32),
+        ("out_absmax", vp),
+        ("n_dyn", vp), ("dyn_mul", i32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "knnsvc_abi_version": (i32, []),
@@ -47,6 +61,7 @@ SIGNATURES = {
     "knnsvc_conv_gemm_last_kernel": (C.c_char_p, []),
     "knnsvc_conv_gemm": (i32, [C.POINTER(ConvDesc), vp]),
     "knnsvc_mean3": (i32, [vp, vp, vp, i64, f32, vp, vp, vp, i64, vp]),
+    "knnsvc_resblock_pair": (i32, [C.POINTER(PairDesc), vp]),
     "knnsvc_split_weight_bf16x3": (i32, [vp, i64, i32, vp, vp]),
     "knnsvc_split_weight_f16x2": (i32, [vp, i64, i32, f32, vp, vp]),
     "knnsvc_split_f16x2_dyn": (i32, [vp, i64, i32, vp, vp, vp]),

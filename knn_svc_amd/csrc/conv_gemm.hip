@@ -1463,6 +1463,173 @@ extern "C" int knnsvc_absmax(const float* x, int64_t rows, int32_t cols, int32_t
 }
 
 namespace {
+// -------------------------------------------------------------------------------------------------
+// Fused ResBlock pair of the generator (hifigan/ddsp_models.py:13-44, one iteration of ResBlock1.forward):
+//     t1  = lrelu(conv1_{k, dil}(lrelu(x)) + b1)          out = conv2_{k, 1}(t1) + b2 + x
+// in ONE launch: a block computes BM - (k - 1) output rows for all C channels.  Phase 1 is the windowed main loop of
+// conv_gemm2win_kernel on the BM rows [t0 - (k-1)/2, ...) the second convolution needs; its epilogue applies bias + leaky ReLU,
+// zeroes rows outside [0, T) (conv2 pads t1 with zeros, not x) and writes the f16x2 split image of t1 — [slab][row][144 B], the
+// layout the window has — into LDS over the dead window; phase 2 is the same tap loop with its A fragments read from that image
+// (Gemm2Win::mainloop_resident), only the weights stream; its epilogue adds bias and the residual x and stores.  t1 never
+// reaches HBM: per pair the unfused form moves 5 activation tensors (read x, write t1 | read t1, read x, write out) and exposes
+// four un-overlapped bursts in two single-round launches; this moves 3 (x is read twice) and exposes two.
+// Same products, same order, same roundings as the two launches (same main loop, same epilogue arithmetic, same split): the
+// result is bit-identical (tests/test_gpu_kernels.py::test_resblock_pair_equals_two_launches).
+struct PairArgs {
+    const float* x; int ldx; int T; int C; int taps; int dil;
+    const unsigned short* w1; const unsigned short* w2; const float* b1; const float* b2;
+    float* out; int ldo;
+    float slope; float w1_scale, w2_scale;
+    const float* x_absmax; float bound_mul, bound_add; float a1_scale, a2_scale;
+    float* out_absmax;
+    const int* n_dyn; int dyn_mul;
+};
+
+template <class G, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_pair_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) char lds_c;
+    typedef __attribute__((address_space(3))) unsigned short lds_h;
+    static_assert(G::NR == 16, "32x32 accumulator tiles");
+    constexpr int IR = G::BM + 16;                              // image rows: the last taps of the discarded tail rows read past BM
+    int T = a.T;
+    if (a.n_dyn) T = *a.n_dyn * a.dyn_mul;
+    float s1 = a.a1_scale, s2 = a.a2_scale;
+    if (a.x_absmax) {
+        const float xmax = kn_slot_max(a.x_absmax);
+        s1 = kn_pick_scale(xmax);
+        s2 = kn_pick_scale(fmaf(xmax, a.bound_mul, a.bound_add));
+    }
+    const float os1 = 1.0f / (s1 * a.w1_scale), os2 = 1.0f / (s2 * a.w2_scale);
+    const int taps = a.taps, h2 = (taps - 1) / 2, pad1 = a.dil * (taps - 1) / 2, BMo = G::BM - (taps - 1);
+    const int t0 = (int)blockIdx.x * BMo;
+    if (t0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, K = C * taps, ncs = C / 32;
+    float* out_slot = a.out_absmax ? kn_stripe(a.out_absmax) : nullptr;
+
+    // ---- phase 1: t1 rows [t0 - h2, t0 - h2 + BM)
+    typename G::acc_t acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t x_rsrc = uniform_rsrc(a.x, ((T - 1) * a.ldx + C) * 4);
+    {
+        Split2BLoader<G::B_P, G::B_PIECES> bl(C, K, 0, tid);
+        const int w_off0 = ((t0 - h2 - pad1 + (tid >> 3)) * a.ldx + (tid & 7) * 4) * 4;
+        G::mainloop(lds, ncs, taps, a.dil, w_off0, a.ldx * 4, bl, acc, x_rsrc, Split2BLoader<G::B_P, G::B_PIECES>::desc(a.w1, C, K), s1, a.slope);
+    }
+    // (the main loop ends behind a barrier: every wave is done with the window and the weight stage)
+    lds_c* img = (lds_c*)lds;
+    const int img_slab = IR * G::PITCH;
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j) {
+        const int col = G::acc_col(wave, lane, j);
+        const float bv = a.b1 ? a.b1[col] : 0.f;
+        lds_c* base = img + (col >> 5) * img_slab + (col & 31) * 2;
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = G::acc_row(wave, lane, i, r);
+                const int g = t0 - h2 + row;
+                float v = fmaf(acc[i][j][r], os1, bv);                  // as conv_epilogue_lin: out_scale is a power of two
+                v = lrelu(v, a.slope);
+                if (g < 0 || g >= T) v = 0.f;                           // conv2's own zero padding
+                const float xs = v * s2;                                // as f16x2_split4
+                const _Float16 h = (_Float16)xs;
+                const _Float16 l = (_Float16)(xs - (float)h);
+                *(lds_h*)(base + row * G::PITCH) = __builtin_bit_cast(unsigned short, h);
+                *(lds_h*)(base + row * G::PITCH + 64) = __builtin_bit_cast(unsigned short, l);
+            }
+    }
+    __syncthreads();
+
+    // ---- phase 2: out rows [t0, t0 + BMo)
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    {
+        Split2BLoader<G::B_P, G::B_PIECES> bl(C, K, 0, tid);
+        G::mainloop_resident(lds, ncs, taps, img_slab, ncs * img_slab, bl, acc, Split2BLoader<G::B_P, G::B_PIECES>::desc(a.w2, C, K));
+    }
+    const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(a.out, ((T - 1) * a.ldo + C) * 4);
+    const int ldo4 = a.ldo * 4, ldx4 = a.ldx * 4;
+    unsigned amax = 0;
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j) {
+        const int col = G::acc_col(wave, lane, j);
+        const float bv = a.b2 ? a.b2[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = G::acc_row(wave, lane, i, r);
+                rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, row < BMo ? (t0 + row) * ldx4 + col * 4 : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = G::acc_row(wave, lane, i, r);
+                float v = fmaf(acc[i][j][r], os2, bv);
+                v += rv[r];
+                if (row < BMo && t0 + row < T) { const unsigned ab = abs_bits(v); amax = ab > amax ? ab : amax; }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, row < BMo ? (t0 + row) * ldo4 + col * 4 : OOB, 0, 0);
+            }
+        }
+    }
+    if (out_slot) publish_absmax(out_slot, amax);
+}
+
+template <class G, int MINB>
+int launch_pair(const PairArgs& a, hipStream_t st) {
+    constexpr int IR = G::BM + 16;
+    const int ncs = a.C / 32;
+    const int lds_bytes = G::LDS_BYTES > (ncs * IR + G::BN) * G::PITCH ? G::LDS_BYTES : (ncs * IR + G::BN) * G::PITCH;
+    static int attr = 0;
+    if (attr < lds_bytes) {
+        if (hipFuncSetAttribute((const void*)conv_pair_kernel<G, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "resblock_pair: hipFuncSetAttribute failed");
+        attr = lds_bytes;
+    }
+    const int BMo = G::BM - (a.taps - 1);
+    hipLaunchKernelGGL((conv_pair_kernel<G, MINB>), dim3((unsigned)cdiv64(a.T, BMo)), dim3(256), lds_bytes, st, a);
+    return knnsvc_check_launch("resblock_pair");
+}
+
+using P64 = Gemm2Win<128, 64, 4, 1, 1, 2, 64>;        // C = 64: window 27.6 KB / image 41.5 KB + weights 9.2 KB: 3 blocks / CU
+using P32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // C = 32: window 46 KB + 4.6 KB / image 39 KB: 3 blocks / CU
+using P128 = Gemm2Win<64, 128, 2, 2, 1, 2, 64>;       // C = 128: 64-row tiles (image 4 x 80 rows = 46 KB + weights 18.4 KB): 2 blocks / CU
+}  // namespace
+
+extern "C" int knnsvc_resblock_pair(const knnsvc_pair_desc* d, void* stream) {
+    KN_REQUIRE(d && d->x && d->w1_f16x2 && d->w2_f16x2 && d->out, "resblock_pair: null operand");
+    KN_REQUIRE(d->channels == 32 || d->channels == 64 || d->channels == 128, "resblock_pair: 32, 64 or 128 channels (other widths take the two-launch form)");
+    KN_REQUIRE(d->taps >= 1 && d->taps <= 11 && (d->taps & 1) && d->dil >= 1 && d->dil * (d->taps - 1) <= 64, "resblock_pair: odd taps <= 11, dil * (taps - 1) <= 64");
+    KN_REQUIRE(d->t >= 0 && d->ldx >= d->channels && d->ldo >= d->channels && d->ldx % 4 == 0 && ((uintptr_t)d->x & 15) == 0, "resblock_pair: bad layout");
+    KN_REQUIRE((long)d->t * d->ldx * 4 < (1L << 30) && (long)d->t * d->ldo * 4 < (1L << 30), "resblock_pair: tensors must stay below 1 GiB");
+    KN_REQUIRE(d->w1_scale > 0.f && d->w2_scale > 0.f, "resblock_pair: weight scales");
+    KN_REQUIRE(d->x_absmax || (d->a1_scale > 0.f && d->a2_scale > 0.f), "resblock_pair: a range slot or both activation scales");
+    if (d->n_dyn) KN_REQUIRE(d->dyn_mul > 0, "resblock_pair: dyn_mul");
+    if (d->t == 0) return KNNSVC_OK;
+    PairArgs a;
+    a.x = d->x; a.ldx = d->ldx; a.T = d->t; a.C = d->channels; a.taps = d->taps; a.dil = d->dil;
+    a.w1 = (const unsigned short*)d->w1_f16x2; a.w2 = (const unsigned short*)d->w2_f16x2; a.b1 = d->b1; a.b2 = d->b2;
+    a.out = d->out; a.ldo = d->ldo; a.slope = d->slope; a.w1_scale = d->w1_scale; a.w2_scale = d->w2_scale;
+    a.x_absmax = d->x_absmax; a.bound_mul = d->t1_bound_mul > 0.f ? d->t1_bound_mul : 1.0f; a.bound_add = d->t1_bound_add;
+    a.a1_scale = d->a1_scale; a.a2_scale = d->a2_scale; a.out_absmax = d->out_absmax; a.n_dyn = d->n_dyn; a.dyn_mul = d->dyn_mul;
+    if (d->channels == 128) return launch_pair<P128, 2>(a, (hipStream_t)stream);
+    if (d->channels == 64) return launch_pair<P64, 3>(a, (hipStream_t)stream);
+    return launch_pair<P32, 3>(a, (hipStream_t)stream);
+}
+
+namespace {
 // out = (c + (b + a)) / div over the first rows * cols floats of contiguous tensors, with max |out| folded into a range slot:
 // the sum of the three parallel ResBlock branches of a generator stage (hifigan/ddsp_models.py:218-227: xs = rb0 + rb1 + rb2,
 // x = xs / num_kernels), in the association the serial accumulate epilogue used — the branches now run on streams of their own.

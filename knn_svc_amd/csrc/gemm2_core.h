@@ -1256,6 +1256,73 @@ struct Gemm2Win {
 #undef KN_STAGE_B
     }
 
+    // Phase 2 of the fused ResBlock pair (conv_pair_kernel): the same tap loop with the A operand ALREADY resident in LDS for
+    // every channel slab — the split image of the pair's inner activation, [slab][IR rows][PITCH] from byte 0, written by the
+    // first convolution's epilogue — so only the weights stream (staged at byte `boff`).  Stride-1, dilation-1 taps: the
+    // fragments of tap t sit t rows further.  Same products in the same order as `mainloop` (slab-major, taps inside).
+    template <class BLoad, class RB>
+    __device__ __forceinline__ static void mainloop_resident(float* lds_generic, int ncs, int taps, int img_slab_bytes, int boff,
+                                                             BLoad& bload, f32x16 (&acc)[TM][TN], RB rb_desc) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 31, lh = lane >> 5;
+        const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
+        const int b_frag = boff + (wn * TN * 32 + li) * PITCH + lh * 16;
+        g2_u32x4 rb[B_P];
+#define KN_LOAD_B(SLAB)                                                                                        \
+    { bload.begin(SLAB); _Pragma("unroll") for (int j = 0; j < B_P; ++j) rb[j] = bload(SLAB, j, rb_desc); }
+#define KN_STAGE_B()                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < B_P; ++j) {                                                         \
+        const int q = tid + 256 * j;                                                                          \
+        if (B_PIECES % 256 == 0 || q < B_PIECES) *(lds_u4*)(lds + boff + (q >> 3) * PITCH + (q & 7) * 16) = rb[j]; \
+    }
+        KN_LOAD_B(0)
+        KN_STAGE_B()
+        __syncthreads();
+        for (int cs = 0; cs < ncs; ++cs) {
+            const bool more_cs = cs + 1 < ncs;
+            const int a_cs = a_frag + cs * img_slab_bytes;
+            for (int tap = 0; tap < taps; ++tap) {
+                const bool last_tap = tap + 1 == taps;
+                const bool more = !last_tap || more_cs;
+                if (more) {
+                    const int slab = last_tap ? (cs + 1) : ((tap + 1) * ncs + cs);
+                    KN_LOAD_B(slab)
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    f16x8 fa[TM][2], fb[TN][2];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            fa[i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + a_cs + tap * PITCH + i * 32 * PITCH + p * 64 + ks * 32));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            fb[j][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + b_frag + j * 32 * PITCH + p * 64 + ks * 32));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            f32x16 c = acc[i][j];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], c, 0, 0, 0);   // small terms first
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                            acc[i][j] = c;
+                        }
+                }
+                __syncthreads();                 // every wave is done with this weight slab
+                if (more) { KN_STAGE_B() }
+                __syncthreads();
+            }
+        }
+#undef KN_LOAD_B
+#undef KN_STAGE_B
+    }
+
     __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
         return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     }

@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, KnnSvcError, check
+from ._lib import ConvDesc, KnnSvcError, PairDesc, check
 
 ACT_NONE, ACT_GELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 
@@ -228,6 +228,35 @@ def absmax(x2d, slot=None):
     check(_lib.load().knnsvc_absmax(_p(x2d), x2d.shape[0], x2d.shape[1], x2d.stride(0) if x2d.shape[0] > 1 else x2d.shape[1],
                                     _p(slot), _stream()), "absmax")
     return slot
+
+
+def resblock_pair_ok(channels: int, taps: int, dil: int) -> bool:
+    """The fused ResBlock pair covers the generator's narrow stages (knnsvc_resblock_pair); KNNSVC_FUSED_PAIR=0 switches it off."""
+    import os
+    widths = (32, 64, 128) if os.environ.get("KNNSVC_FUSED_PAIR_128", "0") == "1" else (32, 64)
+    return (os.environ.get("KNNSVC_FUSED_PAIR", "1") != "0" and gemm_mode() == "f16x2" and channels in widths and
+            taps % 2 == 1 and taps <= 11 and dil * (taps - 1) <= 64)
+
+
+def resblock_pair(x, w1, b1, w2, b2, out, *, t, channels, taps, dil, slope, x_absmax, t1_bound, out_absmax=None, dyn=None,
+                  ldx=None, ldo=None):
+    """out = conv1d(lrelu(conv1d(lrelu(x), w1, dilation=dil) + b1), w2) + b2 + x in one launch (see the header); w1 / w2 are packed
+    conv weights carrying their f16x2 split (attach_split).  Bit-identical to the two conv_gemm launches."""
+    d = PairDesc()
+    d.x = x.data_ptr(); d.ldx = ldx if ldx is not None else channels; d.t = t; d.channels = channels; d.taps = taps; d.dil = dil
+    d.w1_f16x2 = w1._w2.data_ptr(); d.w1_scale = w1._w2_scale; d.b1 = b1.data_ptr() if b1 is not None else None
+    d.w2_f16x2 = w2._w2.data_ptr(); d.w2_scale = w2._w2_scale; d.b2 = b2.data_ptr() if b2 is not None else None
+    d.out = out.data_ptr(); d.ldo = ldo if ldo is not None else channels
+    d.slope = slope
+    if range_slots_on() and x_absmax is not None:
+        d.x_absmax = x_absmax.data_ptr(); d.t1_bound_mul, d.t1_bound_add = float(t1_bound[0]), float(t1_bound[1])
+        d.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
+    else:                                   # A/B aid (KNNSVC_RANGE_SLOTS=0): the fixed activation scale 16
+        d.x_absmax = None; d.a1_scale = d.a2_scale = 16.0; d.out_absmax = None
+    if dyn is not None:
+        d.n_dyn = dyn[0].data_ptr(); d.dyn_mul = t // dyn[1]
+    check(_lib.load().knnsvc_resblock_pair(C.byref(d), _stream()), "resblock_pair")
+    return out
 
 
 def mean3(a, b, c, div, out, out_absmax=None, dyn=None, row_floats=0):

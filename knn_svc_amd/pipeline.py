@@ -43,7 +43,8 @@ class LanePipeline:
         # matching._side_stream) on hardware queues of their own — normal-priority streams can collide with each
         # other on a queue (more so once RCCL has created its streams) but never with these — and lets a lone
         # workgroup take the first CU that frees up.
-        self.tail_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        import os
+        self.tail_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("KNNSVC_TAIL_PRIORITY", "-1")))
 
     def run(self, items, head, tail=None):
         """results[i] = tail(item_i, head(item_i)) (or head(item_i) without a tail), in item order.

@@ -259,12 +259,20 @@ class Vocoder:
                 cur, s_cur = xc, s_xc
                 for m, cv in enumerate(blk["convs"]):
                     d = cv["d"]
+                    last = m == len(blk["convs"]) - 1
+                    if not (last and (accumulate or div != 1.0)) and ops.resblock_pair_ok(cout, kr, d):
+                        # both convolutions of the pair in one launch, t1 in LDS only (knnsvc_resblock_pair): the narrow stages
+                        dst = out_buf if last else (ra if cur is not ra else rb_)
+                        s_dst = s_out if last else slot()
+                        ops.resblock_pair(cur, cv["w1"], cv["b1"], cv["w2"], cv["b2"], dst, t=t_out, channels=cout, taps=kr, dil=d,
+                                          slope=LRELU, x_absmax=s_cur, t1_bound=cv["t1_bound"], out_absmax=s_dst, dyn=self._dyn)
+                        cur, s_cur = dst, s_dst
+                        continue
                     # t1 = lrelu(convs1(lrelu(cur)) + b1) is not measured: its consumer bounds it by t1_bound applied to cur's slot
                     # (leaky ReLUs do not grow their argument) — one publishing launch per ResBlock pair instead of two
                     self._conv(cur, cv["w1"], t1, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, dil=d,
                                pad=(kr * d - d) // 2, bias=cv["b1"], a_slope=LRELU, act=ops.ACT_LRELU, act_slope=LRELU,
                                x_absmax=s_cur)
-                    last = m == len(blk["convs"]) - 1
                     dst = out_buf if last else (ra if cur is not ra else rb_)
                     s_dst = s_out if last else slot()
                     self._conv(t1, cv["w2"], dst, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, pad=(kr - 1) // 2,
@@ -273,14 +281,22 @@ class Vocoder:
                                x_absmax=s_cur, x_bound=cv["t1_bound"], out_absmax=s_dst)
                     cur, s_cur = dst, s_dst
 
-            if self._par() and nblk == 3:
-                # the three ResBlocks of a stage (kernel sizes 3 / 7 / 11) only share their input: each runs on a stream of its own
-                # (forked from / joined into the current stream, also inside a graph capture), which fills the chip where one
-                # branch's launches do not — the first stage's convolutions are 470 blocks for 1024 slots — and overlaps the tails
-                # of the others.  Their mean is taken by knnsvc_mean3 in the association the serial epilogues used.
+            # Each branch writes its own output; knnsvc_mean3 takes (rb2 + (rb1 + rb0)) / 3 — the association of the reference's
+            # running sum (xs += resblock(x); x = xs / num_kernels, ddsp_models.py:218-227) — and publishes the stage's range slot.
+            # The three ResBlocks (kernel sizes 3 / 7 / 11) only share their input: where few other streams are busy each runs on
+            # a stream of its own (forked from / joined into the current stream, also inside a graph capture), which fills the
+            # chip where one branch's launches do not — the first stage's convolutions are 470 blocks for 1024 slots — and overlaps
+            # the others' tails; inside the dataset-mode / serving pipelines they run one after the other (serial_resblocks).
+            # Same kernels, same buffers, same slots either way: the waveform does not depend on the mode.
+            if nblk != 3:                            # other configurations: the running sum in the last epilogues, as round 2
+                for j, blk in enumerate(self.res[i]):
+                    branch(j, blk, xs, s_xs, j > 0, float(nblk) if j == nblk - 1 else 1.0)
+                x, s_x, t_cur = xs, s_xs, t_out
+                continue
+            outs = [new(t_out, cout) for _ in range(3)]
+            if self._par():
                 main = torch.cuda.current_stream(dev)
                 side = self._branch_streams(dev)
-                outs = [new(t_out, cout) for _ in range(3)]
                 fork = main.record_event()
                 for j in (1, 2):                     # the side branches first: branch 0 follows on the caller's stream
                     side[j - 1].wait_event(fork)
@@ -289,10 +305,10 @@ class Vocoder:
                 branch(0, self.res[i][0], outs[0], None, False, 1.0)
                 for st in side:
                     main.wait_stream(st)
-                ops.mean3(outs[0], outs[1], outs[2], float(nblk), xs, out_absmax=s_xs, dyn=dyn)
             else:
                 for j, blk in enumerate(self.res[i]):
-                    branch(j, blk, xs, s_xs, j > 0, float(nblk) if j == nblk - 1 else 1.0)
+                    branch(j, blk, outs[j], None, False, 1.0)
+            ops.mean3(outs[0], outs[1], outs[2], float(nblk), xs, out_absmax=s_xs, dyn=dyn)
             x, s_x, t_cur = xs, s_xs, t_out
         y = new(t_cur, 1)
         self._conv(x, self.post_w, y, T_in=t_cur, cin=x.shape[1], cout=1, k=7, m=t_cur, pad=3, a_slope=0.01,

@@ -148,6 +148,11 @@ class WavLMEncoder:
         cdim = C.conv_layers(self.cfg)[-1][0]
         b = ln_elem(f("layer_norm.weight"), f("layer_norm.bias"), cdim)
         plan["feats"] = b < lim; plan["bounds"]["feats"] = b
+        # the projection's output feeds the positional conv as fp32: its operand scale comes from THIS bound, fixed at load, not
+        # from a range slot over the batch — a slot made a chunk's features depend (in their last bits, through the split of its
+        # small elements) on which other chunks were encoded with it, and files are cached / searched across batches
+        plan["bounds"]["proj"] = lin(ln_l2(f("layer_norm.weight"), f("layer_norm.bias"), cdim), f("post_extract_proj.weight"),
+                                     f("post_extract_proj.bias"))
         E = self.E
         for l in range(self.n_layers):
             p = f"encoder.layers.{l}."
@@ -250,7 +255,9 @@ class WavLMEncoder:
             tap["conv"] = x.clone()
         f_sp = sp(cin, plan["feats"])
         feats = ops.layernorm(x, self.ln_g, self.ln_b, out_split=f_sp)
-        x_slot = ops.new_slot(dev) if dyn else None
+        pb = plan["bounds"]["proj"]
+        fixed_pos = ops.gemm_mode() == "f16x2" and math.isfinite(pb) and 0.0 < pb < 1e30 and os.environ.get("KNNSVC_POS_SLOT") != "1"
+        x_slot = ops.new_slot(dev) if (dyn and not fixed_pos) else None
         x = ops.linear(feats, self.proj_w, self.proj_b, x_split=f_sp, x_absmax=None if f_sp else slot_of(feats),
                        out_absmax=x_slot)             # [B*T, E]
         E, H, G, K = self.E, self.H, self.G, self.Kpos
@@ -263,7 +270,8 @@ class WavLMEncoder:
         ops.conv_gemm(x, self.pos_w, x2, m=T, n=cg, cin=cg, taps=K, pad=K // 2, t_in=T, ldx=E, ldo=E,
                       bias=self.pos_b, act=ops.ACT_GELU, resid=x, ldr=E, batches=B, groups=G,
                       x_bstride=T * E, x_gstride=cg, w_gstride=cg * cg * K, bias_gstride=cg,
-                      o_bstride=T * E, o_gstride=cg, r_bstride=T * E, r_gstride=cg, x_absmax=x_slot)
+                      o_bstride=T * E, o_gstride=cg, r_bstride=T * E, r_gstride=cg, x_absmax=x_slot,
+                      a_scale=ops.pick_scale(pb) if fixed_pos else 0.0)
         x = x2
         table = self._table(T)
         hdim = self.layers[0]["w1"].shape[0] if self.layers else 0

@@ -802,3 +802,55 @@ def test_side_features_batched_equal_per_file():
         assert torch.equal(f0m, f0o) and sm.shape == so.shape == (T, 200) and hm.shape == ho.shape == (T, 49)
         assert torch.equal(sm, so), float((sm - so).abs().max())
         assert torch.equal(hm, ho), float((hm - ho).abs().max())
+
+
+@pytest.mark.parametrize("C_,k,d", [(32, 3, 1), (32, 11, 5), (64, 7, 3), (64, 11, 5), (64, 3, 5), (32, 7, 1), (128, 3, 1), (128, 11, 5)])
+def test_resblock_pair_equals_two_launches(C_, k, d):
+    """knnsvc_resblock_pair (one ResBlock1 iteration, hifigan/ddsp_models.py:13-44, in one launch with the inner activation in LDS)
+    against the two knnsvc_conv_gemm launches the generator otherwise issues: same main loop, same epilogue arithmetic, same
+    f16x2 split of the inner activation -> the same bits, output and range slot; ragged length (tiles end mid-sequence, the
+    second convolution's zero padding of t1 at both ends), and the bucketed form with a device-side length."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(100 + C_ + k + d)
+    T = 3 * 246 + 57
+    x = (torch.randn(T, C_, generator=g) * 1.7).to(DEV)
+    w1 = ops.attach_split(ops.pack_conv_weight(torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5).to(DEV))
+    w2 = ops.attach_split(ops.pack_conv_weight(torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5).to(DEV))
+    b1 = torch.randn(C_, generator=g).to(DEV); b2 = torch.randn(C_, generator=g).to(DEV)
+    w1_ = w1.cpu().view(C_, k, C_).permute(0, 2, 1)
+    bound = (float(w1_.abs().sum(dim=(1, 2)).max()), float(b1.abs().max()))
+    slope = 0.1
+
+    def two(xin, t, dyn=None):
+        sx = ops.absmax(xin[:t] if dyn is None else xin); so = ops.new_slot(DEV)
+        t1 = torch.full((xin.shape[0], C_), float("nan"), device=DEV); out = torch.zeros(xin.shape[0], C_, device=DEV)
+        ops.conv_gemm(xin, w1, t1, m=xin.shape[0], n=C_, cin=C_, taps=k, dil=d, pad=(k * d - d) // 2, t_in=xin.shape[0], bias=b1,
+                      a_slope=slope, act=ops.ACT_LRELU, act_slope=slope, x_absmax=sx, dyn=dyn)
+        ops.conv_gemm(t1, w2, out, m=xin.shape[0], n=C_, cin=C_, taps=k, pad=(k - 1) // 2, t_in=xin.shape[0], bias=b2, resid=xin, ldr=C_,
+                      x_absmax=sx, x_bound=bound, out_absmax=so, dyn=dyn)
+        return out, so, sx
+
+    def one(xin, t, sx, dyn=None):
+        so = ops.new_slot(DEV)
+        out = torch.zeros(xin.shape[0], C_, device=DEV)
+        ops.resblock_pair(xin, w1, b1, w2, b2, out, t=xin.shape[0], channels=C_, taps=k, dil=d, slope=slope, x_absmax=sx,
+                          t1_bound=bound, out_absmax=so, dyn=dyn)
+        return out, so
+    o2, s2, sx = two(x, T)
+    o1, s1 = one(x, T, sx)
+    assert torch.equal(o1, o2), float((o1 - o2).abs().max())
+    assert float(s1.max()) == float(s2.max()) == float(o2.abs().max())
+    # against fp64 (the pair is a real convolution pair, not merely self-consistent)
+    xd = x.cpu().double().t()[None]
+    lr = torch.nn.functional.leaky_relu
+    t1r = lr(F.conv1d(lr(xd, slope), w1_.double(), b1.cpu().double(), dilation=d, padding=(k * d - d) // 2), slope)
+    ref = F.conv1d(t1r, w2.cpu().view(C_, k, C_).permute(0, 2, 1).double(), b2.cpu().double(), padding=(k - 1) // 2) + xd
+    assert float((o1.cpu().double().t()[None] - ref).abs().max()) < 2e-5
+    # bucketed: laid out for Tb rows, valid length in a device int (frames x 8 rows per frame)
+    Tb, n_valid = 8 * 110, 99
+    xb = torch.zeros(Tb, C_, device=DEV); xb[:8 * n_valid] = x[:8 * n_valid]
+    nd = torch.tensor([n_valid], device=DEV, dtype=torch.int32)
+    ob2, sb2, sxb = two(xb, 8 * n_valid, dyn=(nd, 110))
+    ob1, sb1 = one(xb, 8 * n_valid, sxb, dyn=(nd, 110))
+    assert torch.equal(ob1[:8 * n_valid], ob2[:8 * n_valid]) and float(ob1[8 * n_valid:].abs().max()) == 0.0
+    assert float(sb1.max()) == float(sb2.max())
