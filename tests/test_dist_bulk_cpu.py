@@ -98,7 +98,7 @@ def _inject():
     matching.side_features = _cpu_side_features
     matching.match_features = _cpu_match_features
     matching.prepare_pool = lambda P, split=True: None
-    matching.batched_knn = lambda q_all, P, prep: (_cpu_local_topk(q_all, P, 32, 0)[0], None)
+    matching.batched_knn = lambda q_all, P, prep, max_blocks=0: (_cpu_local_topk(q_all, P, 32, 0)[0], None)
     kd._hip_local_topk = _cpu_local_topk
     kd._hip_merge = _cpu_merge
     matching._POOL_CACHE = None
