@@ -553,17 +553,12 @@ extern "C" int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, con
     KN_REQUIRE(!use_f0 || (shifted_f0 && pool_f0), "concat_reselect: f0 variant needs both f0 arrays");
     KN_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)pool & 15) == 0, "concat_reselect: 16-byte alignment");
     if (dim <= 1024 && (unsigned long long)np * dim * 4 < 0xFFFFFFFFull && (unsigned long long)nq * dim * 4 < 0xFFFFFFFFull) {
-        // The kernel asks for (nearly) the WHOLE LDS of its CU, far more than the 30 rows it uses.  Measured (tools/determinism_*.py,
-        // round 3): when a workgroup of another kernel shares the CU — the generator's C = 256 convolutions fit next to 121 KB, and
-        // inside the stream pipeline they run at the same time — a few frames per utterance come out with slightly different costs
-        // (1e-3 relative on one candidate, enough to swap two near-tied selections and, through the recurrence, the rows behind
-        // them); the rows it reads from LDS are intact (re-read behind the barrier: same sums), its inputs are intact, a canary
-        // behind its rows stays intact, extra barriers change nothing, and alone on its CU the kernel is bit-stable under any load
-        // on the rest of the chip.  The cause inside the CU is not identified; isolation removes the symptom (32 sources x 4
-        // pipelined runs bit-identical, equal to the unpipelined path) at the price of one CU's LDS per running re-selection.
-        // KNNSVC_CONCAT_SHARE_CU=1 restores the minimal request.
+        // KNNSVC_CONCAT_OWN_CU=1: ask for (nearly) the whole LDS of the CU so that no other kernel's workgroup is placed next to this
+        // one.  Debugging aid from round 3's determinism hunt (see the Makefile's note on -fno-slp-vectorize: with compiler-made
+        // packed-fp32 math this kernel's sums were perturbed by MFMA-issuing neighbours on its CU; isolation removed the symptom
+        // before the cause was found).
         size_t pl = (size_t)30 * dim * 4;
-        { const char* e = getenv("KNNSVC_CONCAT_SHARE_CU"); if (!(e && e[0] == '1') && pl < (size_t)158 * 1024) pl = (size_t)158 * 1024; }
+        { const char* e = getenv("KNNSVC_CONCAT_OWN_CU"); if (e && e[0] == '1' && pl < (size_t)158 * 1024) pl = (size_t)158 * 1024; }
         static size_t pattr = 0;
         if (pl > pattr) {
             if (hipFuncSetAttribute((const void*)concat_reselect_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
