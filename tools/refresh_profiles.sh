@@ -28,7 +28,7 @@ python3 tools/knn_bench.py > $O/${tag}_knn_bench.txt 2>&1
 KNNSVC_KNN_FUSED=0 python3 tools/knn_bench.py 2>&1 | tail -1 >> $O/${tag}_knn_bench.txt
 bash tools/quad16_ab.sh > $O/${tag}_quad_vs_f128_real_epilogues.txt 2>&1
 bash tools/quad_fastepi_ab.sh 2>&1 | grep -v amdgpu > $O/${tag}_quad_specialised_vs_generic_epilogue.txt
-bash tools/quad_prof.sh 2>&1 | grep -v amdgpu > $O/${tag}_quad_phase_trace.txt
+( make -C knn_svc_amd/csrc BUILD=build_prof OUT=../libknnsvc_prof.so EXTRA=-DKN_QUAD_PROF -j16 > /dev/null 2>&1; bash tools/quad_prof.sh 2>&1 | grep -v amdgpu > $O/${tag}_quad_phase_trace.txt )
 python3 tools/gemm_zero.py 31500 1024 4096 > $O/${tag}_gemm_zero_vs_random.txt 2>&1
 python3 tools/layer_error.py 6 6 > $O/${tag}_layer_error.txt 2>&1
 ( python3 tools/vocoder_replay.py; KNNSVC_RANGE_SLOTS=0 python3 tools/vocoder_replay.py ) > $O/${tag}_vocoder_range_slots.txt 2>&1
