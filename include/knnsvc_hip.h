@@ -136,6 +136,11 @@ typedef struct knnsvc_pair_desc {
 } knnsvc_pair_desc;
 int knnsvc_resblock_pair(const knnsvc_pair_desc* d, void* stream);
 
+/* out = alpha * x (accumulate = 0) or out + alpha * x (accumulate = 1) over n floats (n % 4 == 0): one term of the layer
+ * weighting `(feats * w[:, None]).sum(0)` over WavLM's layer outputs (ddsp_prematch_dataset.py:349-350) when w is not one-hot
+ * (terms are added in ascending layer order, each product rounded on its own, as torch evaluates it). */
+int knnsvc_axpy(const float* x, int64_t n, float alpha, int32_t accumulate, float* out, void* stream);
+
 /* out = (c + (b + a)) / div, elementwise over n floats (n % 4 == 0), max |out| folded into the range slot out_absmax (may be
  * NULL): the mean of the parallel ResBlock branches of a generator stage (hifigan/ddsp_models.py:218-227).  n_dyn (optional,
  * device int32): only the first n_dyn * dyn_mul floats are touched (bucketed sequence lengths, see "Dynamic length"). */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "knnsvc_conv_gemm_last_kernel": (C.c_char_p, []),
     "knnsvc_conv_gemm": (i32, [C.POINTER(ConvDesc), vp]),
     "knnsvc_mean3": (i32, [vp, vp, vp, i64, f32, vp, vp, vp, i64, vp]),
+    "knnsvc_axpy": (i32, [vp, i64, f32, i32, vp, vp]),
     "knnsvc_resblock_pair": (i32, [C.POINTER(PairDesc), vp]),
     "knnsvc_split_weight_bf16x3": (i32, [vp, i64, i32, vp, vp]),
     "knnsvc_split_weight_f16x2": (i32, [vp, i64, i32, f32, vp, vp]),

@@ -1650,6 +1650,27 @@ __global__ __launch_bounds__(256) void mean3_kernel(const float* __restrict__ a,
 }
 }  // namespace
 
+namespace {
+// out = alpha * x (+ out): the weighted sum over WavLM layer outputs of a general layer weighting
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, long n4, float alpha, int accumulate, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = ((const f32x4*)x)[i] * alpha;
+        if (accumulate) v = ((const f32x4*)out)[i] + v;
+        ((f32x4*)out)[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int knnsvc_axpy(const float* x, int64_t n, float alpha, int32_t accumulate, float* out, void* stream) {
+    KN_REQUIRE(x && out && n >= 0 && n % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0, "axpy: n % 4 == 0, 16-byte aligned");
+    if (n == 0) return KNNSVC_OK;
+    long blocks = cdiv64(n / 4, 256 * 4);
+    blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 4), alpha, accumulate, out);
+    return knnsvc_check_launch("axpy");
+}
+
 extern "C" int knnsvc_mean3(const float* a, const float* b, const float* c, int64_t n, float div, float* out, float* out_absmax,
                             const int32_t* n_dyn, int64_t dyn_mul, void* stream) {
     KN_REQUIRE(a && b && c && out && n >= 0 && n % 4 == 0 && dyn_mul % 4 == 0 && div != 0.f, "mean3: bad arguments (n and dyn_mul are multiples of 4)");

@@ -360,14 +360,18 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
     return out_feats, harm_w, shifted
 
 
-def _layer_of(weights) -> int:
+def _mix_of(weights, wavlm):
+    """A layer weighting as the encoder takes it: None for the one-hot on its exit layer (the live path), else the tuple."""
     if weights is None:
-        return C.MATCH_LAYER
-    w = torch.as_tensor(weights).reshape(-1).float().cpu()
-    nz = torch.nonzero(w).reshape(-1)
-    if len(nz) != 1 or float(w[nz[0]]) != 1.0:
-        raise NotImplementedError("only one-hot layer weightings are supported (the reference uses layer 6)")
-    return int(nz[0])
+        return None
+    w = [float(v) for v in torch.as_tensor(weights).reshape(-1).float().cpu().tolist()]
+    if any(v != 0.0 for v in w[wavlm.n_layers + 1:]):
+        raise NotImplementedError(f"layer weighting uses layers beyond the {wavlm.n_layers} the encoder was loaded with "
+                                  "(load it with n_layers = the last weighted layer)")
+    w = (w + [0.0] * (wavlm.n_layers + 1))[:wavlm.n_layers + 1]
+    if sum(1 for v in w if v != 0.0) == 1 and w[wavlm.n_layers] == 1.0:
+        return None
+    return tuple(w)
 
 
 def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, match_weights=None, synth_weights=None,
@@ -402,9 +406,12 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     assert prioritize_f0, "prioritize_f0=False is unsupported by the reference (ddsp_prematch_dataset.py:1375)"
     if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type and "mix" not in ckpt_type:
         raise NotImplementedError(ckpt_type)
-    for wts in (match_weights, synth_weights):
-        if _layer_of(wts) != wavlm.n_layers:
-            raise NotImplementedError("layer weighting does not match the encoder's exit layer")
+    # the layer weighting (ddsp_prematch_dataset.py:349-350).  matching == synth features on the live path (ddsp_matcher.py:88-89,
+    # 319: both the one-hot on layer 6); two DIFFERENT weightings would need two feature sets per file and are not supported
+    mix_m, mix_s = _mix_of(match_weights, wavlm), _mix_of(synth_weights, wavlm)
+    if mix_m != mix_s:
+        raise NotImplementedError("different matching and synthesis layer weightings")
+    wavlm.set_layer_mix(mix_m)
     if src_dataset_path is None:
         assert os.path.isfile(src_wav_file)
     query_pool, _, _, _, query_f0_pool, _ = get_complete_spk_pool(src_wav_file, wavlm, device=device,

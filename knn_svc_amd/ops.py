@@ -259,6 +259,12 @@ def resblock_pair(x, w1, b1, w2, b2, out, *, t, channels, taps, dil, slope, x_ab
     return out
 
 
+def axpy(x, alpha, out, accumulate):
+    """out = alpha * x (+ out): one term of a general WavLM layer weighting."""
+    check(_lib.load().knnsvc_axpy(_p(x), x.numel(), float(alpha), 1 if accumulate else 0, _p(out), _stream()), "axpy")
+    return out
+
+
 def mean3(a, b, c, div, out, out_absmax=None, dyn=None, row_floats=0):
     """out = (c + (b + a)) / div over contiguous tensors; ``dyn`` = (device frame count, bucket frames): only the first
     count * (numel / bucket frames) floats are touched."""

@@ -118,6 +118,7 @@ class WavLMEncoder:
         self.rel_emb = state["encoder.layers.0.self_attn.relative_attention_bias.weight"].detach().float().cpu()
         self.plan = self._range_plan(state)
         self._tables = {}
+        self.layer_mix = None      # general layer weighting (set_layer_mix): None = the output of layer n_layers
         self._graphs = {}          # (B, L, masked) -> (hipGraph, static output, static input, static lengths); insertion order = LRU order
         self._seen = set()
         self._graph_pool = None if not torch.cuda.is_available() else torch.cuda.graph_pool_handle()
@@ -170,6 +171,25 @@ class WavLMEncoder:
             plan["layers"].append(dict(xn=xn_e < lim, xn2=x2_e < lim, h=hb < lim, attn_f16=narrow))
             plan["bounds"][f"layer{l}"] = dict(xn=xn_e, q=qb, k=kb, v=vb, xn2=x2_e, h=hb)
         return plan
+
+    def set_layer_mix(self, weights) -> None:
+        """General layer weighting (ddsp_prematch_dataset.py:349-350: ``(feats * w[:, None]).sum(0)`` over the 25 stacked layer
+        results — index 0 is the encoder's input after the positional conv, index l the output of layer l).  ``weights``: a
+        sequence whose entries beyond ``n_layers`` are zero, or None / a one-hot on ``n_layers`` for the plain layer output (the
+        live path: layer 6).  The encoder then returns sum_l w[l] * layer_result[l], terms added in ascending l."""
+        if weights is not None:
+            w = [float(v) for v in torch.as_tensor(weights).reshape(-1).tolist()]
+            if any(v != 0.0 for v in w[self.n_layers + 1:]):
+                raise ValueError(f"layer weighting uses layers beyond the {self.n_layers} this encoder was loaded with")
+            w = (w + [0.0] * (self.n_layers + 1))[:self.n_layers + 1]
+            if sum(1 for v in w if v != 0.0) == 1 and w[self.n_layers] == 1.0:
+                w = None
+            weights = None if w is None else tuple(w)
+        if weights != self.layer_mix:
+            self.layer_mix = weights
+            self._graphs.clear(); self._seen.clear()          # captured schedules end in the old weighting
+            WavLMEncoder._uids += 1
+            self.uid = WavLMEncoder._uids                     # cached pool features belong to the old weighting
 
     def n_frames(self, n_samples: int) -> int:
         n = n_samples
@@ -275,7 +295,12 @@ class WavLMEncoder:
         x = x2
         table = self._table(T)
         hdim = self.layers[0]["w1"].shape[0] if self.layers else 0
-        for ly, pl in zip(self.layers, plan["layers"]):
+        mix = self.layer_mix
+        acc = None
+        if mix is not None:
+            acc = torch.empty_like(x)
+            ops.axpy(x, mix[0], acc, False)                  # layer_results[0]: the encoder's input (WavLM.py:583-585)
+        for li_, (ly, pl) in enumerate(zip(self.layers, plan["layers"])):
             e_sp = sp(E, pl["xn"])
             xn = ops.layernorm(x, ly["ln1_g"], ly["ln1_b"], out_split=e_sp)
             gate = ops.wavlm_gate(xn, H, ly["gate_w"], ly["gate_b"], ly["grep_a"], x_split=e_sp)
@@ -294,6 +319,10 @@ class WavLMEncoder:
             hmid = ops.linear(xn, ly["w1"], ly["b1"], act=ops.ACT_GELU, x_split=e2_sp, out_split=h_sp,
                               x_absmax=None if e2_sp else slot_of(xn), out_absmax=h_slot)
             x = ops.linear(hmid, ly["w2"], ly["b2"], resid=x, x_split=h_sp, x_absmax=h_slot)
+            if acc is not None and mix[li_ + 1] != 0.0:
+                ops.axpy(x, mix[li_ + 1], acc, True)
+        if acc is not None:
+            return acc.view(B, T, E)
         return x.view(B, T, E)
 
     def full_features(self, wav_1d: torch.Tensor, max_batch: int = 8) -> torch.Tensor:

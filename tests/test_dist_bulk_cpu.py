@@ -35,6 +35,9 @@ class FakeEncoder:
     def n_frames(self, n):
         return (n - 400) // 320 + 1
 
+    def set_layer_mix(self, weights):
+        assert weights is None          # the live path's one-hot on layer 6
+
     def weights_fingerprint(self):
         return "fake"
 

@@ -40,6 +40,33 @@ def test_wavlm_tiny_golden(golden):
         assert d < 1e-4, (nl, d)
 
 
+def test_wavlm_general_layer_weighting_golden(golden):
+    """A layer weighting that is not one-hot (ddsp_prematch_dataset.py:349-350: ``(feats * w[:, None]).sum(0)`` over the stacked
+    layer results): the encoder's weighted sum against the same combination of the reference's own layer outputs (fixture g1:
+    layers 0, 1 and 3 of the tiny model), and the one-hot special case back to the plain layer output."""
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g1_wavlm_tiny")
+    cfg = C.WAVLM_TINY
+    sd = S.seeded_state(S.wavlm_param_spec(cfg), int(g["seed"]))
+    wav, _ = S.synth_clip(int(g["n_samples"]), int(g["clip_seed"]))
+    x = torch.from_numpy(np.pad(wav, (0, 320)))[None].to(DEV)
+    enc = WavLMEncoder(sd, cfg, DEV, n_layers=3)
+    plain = enc.encode_batch(x)[0].clone()
+    w = [0.25, 0.5, 0.0, 0.25]
+    enc.set_layer_mix(w)
+    uid = enc.uid
+    for _ in range(3):                                   # eager, capture, replay
+        out = enc.encode_batch(x)[0]
+        ref = (torch.from_numpy(g["layer0"]) * w[0] + torch.from_numpy(g["layer1"]) * w[1]) + torch.from_numpy(g["layer3"]) * w[3]
+        d = _maxdiff(out, ref.numpy())
+        assert d < 1e-4, d
+    with pytest.raises(ValueError):
+        enc.set_layer_mix([0.0, 0.0, 0.0, 0.5, 0.5])     # layer 4 of a 3-layer encoder
+    enc.set_layer_mix([0.0, 0.0, 0.0, 1.0])              # one-hot on the exit layer: the plain path again
+    assert enc.layer_mix is None and enc.uid != uid
+    assert torch.equal(enc.encode_batch(x)[0], plain)
+
+
 def test_wavlm_chunked_golden(golden):
     from knn_svc_amd.wavlm import WavLMEncoder
     g = golden("g1b_wavlm_chunked")
