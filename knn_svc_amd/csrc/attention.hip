@@ -473,6 +473,9 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
     gload(0);
     const int ntiles = (Tk + KT - 1) / KT;
     for (int t = 0; t < ntiles; ++t) {
+#ifdef KN_ATT_NOSTAGE      // timing aid: the first tile's K / V serve every tile, no barriers after it
+        if (t == 0) {
+#endif
         __syncthreads();
         if (kv_split) {
             // K and V columns of `qkv` already hold the f16x2 split layout (written by the QKV GEMM's epilogue, scale 16):
@@ -502,7 +505,11 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
         }
         }
         __syncthreads();
+#ifdef KN_ATT_NOSTAGE
+        }
+#else
         if (t + 1 < ntiles) gload((t + 1) * KT);
+#endif
 
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -518,29 +525,44 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
                 const f16x8 k0 = __builtin_bit_cast(f16x8, *(const l_u4*)(kp + st * 32));
                 const f16x8 k1 = __builtin_bit_cast(f16x8, *(const l_u4*)(kp + 128 + st * 32));
                 const f16x8 q0 = __builtin_bit_cast(f16x8, qf[st][0]), q1 = __builtin_bit_cast(f16x8, qf[st][1]);
+#ifdef KN_ATT_NOS          // timing aid: one product instead of twelve
+                if (st == 0) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q0, s, 0, 0, 0);
+                else { s[st] += __builtin_bit_cast(float, __builtin_bit_cast(au32x4, k0)[0] ^ __builtin_bit_cast(au32x4, k1)[1] ^ __builtin_bit_cast(au32x4, q1)[0]); }
+#else
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q0, s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q1, s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q0, s, 0, 0, 0);
+#endif
             }
             // rows past T hold zero Q (and zero gate): their scores are finite, nothing is written for them
             const l_f* tp = tbq + kbase;
+#ifndef KN_ATT_NOBIAS
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = fmaf(g_i, tp[(r & 3) + 8 * (r >> 2)], s[r]);
+#endif
             if (kbase + 32 > Tk) {                                    // wave-uniform: only the last key tile masks
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) s[r] = -__builtin_inff();
             }
+#ifdef KN_ATT_NOEXP       // timing aid: no max / exp / sums
+            float mx = s[0];
+#else
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 #pragma unroll
             for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
+#endif
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);                    // key 0 is always valid: finite from the first tile on
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * (1.0f / 256.0f));
             const float mneg = fmaf(m_new, -1.0f / 256.0f, 14.0f);       // P carries 2^14 (cancels in O / l)
             float ps = 0.f;
 #pragma unroll
+#ifdef KN_ATT_NOEXP
+            for (int r = 0; r < 16; ++r) { s[r] = s[r] * 1e-9f; } ps = s[3] + mneg;
+#else
             for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], 1.0f / 256.0f, mneg)); ps += s[r]; }
+#endif
             ps += __shfl_xor(ps, 32, 64);
             l_run = l_run * alpha + ps;
             m_run = m_new;
@@ -576,9 +598,14 @@ __global__ __launch_bounds__(256, 3) void attention2_kernel(const float* __restr
                     const f16x8 v0 = __builtin_bit_cast(f16x8, (au32x4){x0[0], x0[1], x1[0], x1[1]});
                     const f16x8 v1 = __builtin_bit_cast(f16x8, (au32x4){y0[0], y0[1], y1[0], y1[1]});
                     f32x16 c = o[dt];
+#ifdef KN_ATT_NOPV         // timing aid: one product per step instead of six
+                    if (dt == 0) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, b0, c, 0, 0, 0);
+                    else c[st] += __builtin_bit_cast(float, __builtin_bit_cast(au32x4, v0)[0] ^ __builtin_bit_cast(au32x4, v1)[1] ^ __builtin_bit_cast(au32x4, b1)[0]);
+#else
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, b0, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b1, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b0, c, 0, 0, 0);
+#endif
                     o[dt] = c;
                 }
             }

@@ -62,6 +62,37 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Wave-wide sum on the VALU: four DPP adds fold each row of 16 lanes (xor 1, xor 2, half-mirror, mirror), four readlanes pick
+// the row sums.  ds_bpermute-based __shfl_xor trees cost six dependent LDS round trips per value — in a frame-sequential
+// kernel that is latency on the critical path of every frame.  Every lane gets the total.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+// the same fold for a double (two 32-bit DPP moves per step)
+__device__ __forceinline__ double wave_sum_d_dpp(double v) {
+#define KN_DPP_D(CTRL)                                                                                          \
+    {                                                                                                          \
+        const long b = __builtin_bit_cast(long, v);                                                            \
+        const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true); \
+        v += __builtin_bit_cast(double, ((long)hi << 32) | (unsigned)lo);                                      \
+    }
+    KN_DPP_D(0xB1) KN_DPP_D(0x4E) KN_DPP_D(0x141) KN_DPP_D(0x140)
+#undef KN_DPP_D
+    const long b = __builtin_bit_cast(long, v);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __builtin_bit_cast(double, ((long)__builtin_amdgcn_readlane(hi, 16 * k) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, 16 * k));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1,6 +1,7 @@
 // Small HBM-bound kernels: layer norm (+GELU), gated rel-pos multiplier, weighted neighbour
 // gather, reflect padding, complex magnitude, harmonic-amplitude extraction.
 #include "common.h"
+#include <cstdlib>
 #include "gemm2_core.h"      // f16x2_split4: the split ("A2") activation layout of the emulated-fp32 GEMMs
 
 namespace {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // A lane owns CPL = C/64 consecutive channels and keeps their k taps in registers; a block stages the
 // input span of its 64 output rows in LDS; each wave walks 16 rows (LN statistics by wave reduction).
 // The unfused route wrote, re-read and re-wrote the [T, C] tensor (4.1 GB per 10 min of audio at C = 512).
-template <int CPL, int KMAXT>
+template <int CPL, int KMAXT, int RP>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ x, long L, long T, int k, int stride,
                                                            const float* __restrict__ w, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ out, int split) {
@@ -124,41 +125,57 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
         for (int t = 0; t < KMAXT; ++t) wr[c][t] = t < k ? w[ch * k + t] : 0.f;
     }
     __syncthreads();
-    for (int r = 0; r < 16; ++r) {
-        const int lm = wave * 16 + r;
-        const long m = m0 + lm;
-        if (m >= T) break;
-        float xv[KMAXT];
+    // RP rows per pass: independent chains (LDS reads, the two reductions, the GELU's rcp / exp2, the stores) interleave, and the
+    // LayerNorm sums are DPP folds + readlanes (common.h) instead of twelve dependent ds_bpermute round trips per row — the kernel
+    // is VALU work (80 FMAs, 8 GELUs per lane and row) that sat half idle behind those latencies (RP = 1 with shuffles: 2.04 ms
+    // for 21 x 96 015 rows, the VALU floor is ~1.1).
+    for (int r = 0; r < 16; r += RP) {
+        float y[RP][CPL], s[RP], mean[RP], q[RP], rstd[RP];
 #pragma unroll
-        for (int t = 0; t < KMAXT; ++t) xv[t] = t < k ? xs[lm * stride + t] : 0.f;
-        float y[CPL], s = 0.f;
+        for (int u = 0; u < RP; ++u) {
+            const int lm = wave * 16 + r + u;          // rows past T read zeros / stale LDS: finite, never stored
+            float xv[KMAXT];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            float a = 0.f;
+            for (int t = 0; t < KMAXT; ++t) xv[t] = t < k ? xs[lm * stride + t] : 0.f;
+            s[u] = 0.f;
 #pragma unroll
-            for (int t = 0; t < KMAXT; ++t) a += wr[c][t] * xv[t];
-            y[c] = a; s += a;
+            for (int c = 0; c < CPL; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < KMAXT; ++t) a += wr[c][t] * xv[t];
+                y[u][c] = a; s[u] += a;
+            }
         }
-        const float mean = wave_sum(s) / (float)C;
-        float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) { const float d = y[c] - mean; q += d * d; }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
-        float* o = out + (b * T + m) * C + lane * CPL;
+        for (int u = 0; u < RP; ++u) mean[u] = (RP > 1 ? wave_sum_dpp(s[u]) : wave_sum(s[u])) / (float)C;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) y[c] = gelu_erf((y[c] - mean) * rstd * g[c] + be[c]);
-        if (CPL % 4 == 0) {
-            if (split) {
-                float* orow = out + (b * T + m) * C;
+        for (int u = 0; u < RP; ++u) {
+            q[u] = 0.f;
 #pragma unroll
-                for (int c = 0; c < CPL; c += 4) store_split4(orow, lane * CPL + c, (f32x4){y[c], y[c + 1], y[c + 2], y[c + 3]});
+            for (int c = 0; c < CPL; ++c) { const float d = y[u][c] - mean[u]; q[u] += d * d; }
+        }
+#pragma unroll
+        for (int u = 0; u < RP; ++u) rstd[u] = 1.0f / sqrtf((RP > 1 ? wave_sum_dpp(q[u]) : wave_sum(q[u])) / (float)C + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < RP; ++u) {
+            const long m = m0 + wave * 16 + r + u;
+            if (m >= T) break;
+            float* o = out + (b * T + m) * C + lane * CPL;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) y[u][c] = gelu_erf((y[u][c] - mean[u]) * rstd[u] * g[c] + be[c]);
+            if (CPL % 4 == 0) {
+                if (split) {
+                    float* orow = out + (b * T + m) * C;
+#pragma unroll
+                    for (int c = 0; c < CPL; c += 4) store_split4(orow, lane * CPL + c, (f32x4){y[u][c], y[u][c + 1], y[u][c + 2], y[u][c + 3]});
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CPL; c += 4) *(f32x4*)(o + c) = (f32x4){y[u][c], y[u][c + 1], y[u][c + 2], y[u][c + 3]};
+                }
             } else {
 #pragma unroll
-                for (int c = 0; c < CPL; c += 4) *(f32x4*)(o + c) = (f32x4){y[c], y[c + 1], y[c + 2], y[c + 3]};
+                for (int c = 0; c < CPL; ++c) o[c] = y[u][c];
             }
-        } else {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) o[c] = y[c];
         }
     }
 }
@@ -440,12 +457,16 @@ extern "C" int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, co
     const long T = (L - k) / stride + 1;
     dim3 grid((unsigned)cdiv64(T, 64), (unsigned)batches);
     hipStream_t st = (hipStream_t)stream;
-#define KN_C0(CPL, KM) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, KM>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out, out_f16x2)
+    static int rp = -1;        // rows per pass and reduction flavour: 2 (default), 4, or 1 = round 2's kernel (shuffle sums), for A/B
+    if (rp < 0) { const char* e = getenv("KNNSVC_CONV0_RP"); rp = e ? atoi(e) : 2; if (rp != 1 && rp != 4) rp = 2; }
+#define KN_C0R(CPL, KM, RP) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, KM, RP>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out, out_f16x2)
+#define KN_C0(CPL, KM) { if (rp == 2) KN_C0R(CPL, KM, 2); else if (rp == 4) KN_C0R(CPL, KM, 4); else KN_C0R(CPL, KM, 1); }
     if (k <= 10) {        // WavLM's k = 10: no padded taps in the unrolled FIR
-        if (channels == 512) KN_C0(8, 10); else if (channels == 256) KN_C0(4, 10); else if (channels == 128) KN_C0(2, 10); else KN_C0(1, 10);
+        if (channels == 512) KN_C0(8, 10) else if (channels == 256) KN_C0(4, 10) else if (channels == 128) KN_C0(2, 10) else KN_C0(1, 10)
     } else {
-        if (channels == 512) KN_C0(8, 16); else if (channels == 256) KN_C0(4, 16); else if (channels == 128) KN_C0(2, 16); else KN_C0(1, 16);
+        if (channels == 512) KN_C0(8, 16) else if (channels == 256) KN_C0(4, 16) else if (channels == 128) KN_C0(2, 16) else KN_C0(1, 16)
     }
+#undef KN_C0R
 #undef KN_C0
     return knnsvc_check_launch("wavlm_conv0");
 }

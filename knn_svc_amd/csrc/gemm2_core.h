@@ -1211,10 +1211,12 @@ struct Gemm2Win {
             for (int tap = 0; tap < taps; ++tap, tap_off += tap_step) {
                 const bool last_tap = tap + 1 == taps;
                 const bool more = !last_tap || more_cs;
+#ifndef KN_WIN_NOBLOAD          // timing aid: the first weight slab serves every step
                 if (more) {
                     const int slab = last_tap ? KN_CS(ci + 1) : ((tap + 1) * ncs + cs);
                     KN_LOAD_B(slab)
                 }
+#endif
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     f16x8 fa[TM][2], fb[TN][2];
@@ -1243,10 +1245,16 @@ struct Gemm2Win {
                             acc[i][j] = c;
                         }
                 }
+#ifndef KN_WIN_NOBAR            // timing aid: no barriers inside the loop
                 __syncthreads();                 // every wave is done with this weight slab (and, on the last tap, the window)
+#endif
+#ifndef KN_WIN_NOBLOAD
                 if (more) { KN_STAGE_B() }
+#endif
                 if (last_tap && more_cs) { KN_STAGE_W() }
+#ifndef KN_WIN_NOBAR
                 __syncthreads();
+#endif
             }
         }
 #undef KN_CS

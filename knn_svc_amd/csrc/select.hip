@@ -220,19 +220,6 @@ __global__ __launch_bounds__(256) void concat_reselect_kernel(
 }
 
 
-// Wave-wide sum on the VALU: four DPP adds fold each row of 16 lanes (xor 1, xor 2, half-mirror, mirror), four readlanes pick
-// the row sums.  ds_bpermute-based __shfl_xor trees cost six dependent LDS round trips per value — in a frame-sequential
-// kernel that is latency on the critical path of every frame.  Every lane gets the total.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-    const int b = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-    return (r0 + r1) + (r2 + r3);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Pipelined variant (feature dim <= 1024): 8 waves, one per candidate.  Everything frame i needs is

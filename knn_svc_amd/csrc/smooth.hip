@@ -83,8 +83,7 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
                                                    float* __restrict__ xch_global, int use_lds,
                                                    float* __restrict__ out_w, int* __restrict__ out_iters) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ double red[16];
-    __shared__ float s_loss;
+    __shared__ double red[2][16];
     float* xw = use_lds ? sm : xch_global;                 // [nq][4] softmax weights
     float* xg = xw + nq * KW;                              // [nq][4] gradient w.r.t. w from the pair (t-1, t)
     f32x4* theta = (f32x4*)state;
@@ -140,16 +139,13 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
             f32x4 gs = {-twoS * y[4], -twoS * y[5], -twoS * y[6], -twoS * y[7]};
             best[nq + t] = gs;                                     // scratch row after `best`
         }
-        lsum = wave_sum_d(lsum);
-        if (lane == 0) red[wave] = lsum;
+        lsum = wave_sum_d_dpp(lsum);                  // two barriers per iteration: see adam_reg_kernel
+        if (lane == 0) red[it & 1][wave] = lsum;
         __syncthreads();
-        if (tid == 0) {
-            double tot = 0.0;
-            for (int i = 0; i < 16; ++i) tot += red[i];
-            s_loss = (float)(S * tot);
-        }
-        __syncthreads();
-        const float loss = s_loss;
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[it & 1][i];
+        const float loss = (float)(S * tot);
         // ---- phase 3: the reference's loop control (uniform across the block) -------------------
         if (it % 100 == 1) {
             if (!forced && fabs(min_loss - conv_min) < 1e-5) break;
@@ -182,7 +178,6 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
             }
             theta[t] = th; m1[t] = mm; v2[t] = vv; vmax[t] = vm;
         }
-        __syncthreads();
     }
     // softmax(best)
     __syncthreads();
@@ -205,8 +200,7 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
                                                       const float* __restrict__ gram, float* __restrict__ out_w,
                                                       int* __restrict__ out_iters) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ double red[8];
-    __shared__ float s_loss;
+    __shared__ double red[2][8];      // by iteration parity: a fast wave may write its next sum while a slow one still reads
     float* xw = sm;                       // [nq][4]
     float* xg = sm + nq * KW;             // [nq][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -264,16 +258,17 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
             }
             __builtin_amdgcn_sched_barrier(0);      // one frame at a time: keeps the matvec temporaries of different frames from coexisting
         }
-        lsum = wave_sum_d(lsum);
-        if (lane == 0) red[wave] = lsum;
+        // Two barriers per iteration (round 3; four before): the wave sums are DPP folds instead of twelve ds_bpermute round
+        // trips, every thread adds the eight wave sums itself (same order everywhere: the loss is uniform) instead of waiting
+        // for thread 0, and the barrier that closed the iteration is gone — xw[t] / xg[t + 1] are only rewritten behind the
+        // NEXT iteration's first barrier, which their last readers (this iteration's update phase) have to pass first.
+        lsum = wave_sum_d_dpp(lsum);
+        if (lane == 0) red[it & 1][wave] = lsum;
         __syncthreads();
-        if (tid == 0) {
-            double tot = 0.0;
-            for (int i = 0; i < 8; ++i) tot += red[i];
-            s_loss = (float)(S * tot);
-        }
-        __syncthreads();
-        const float loss = s_loss;
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tot += red[it & 1][i];
+        const float loss = (float)(S * tot);
         if (it % 100 == 1) {
             if (!forced && fabs(min_loss - conv_min) < 1e-5) break;
             conv_min = min_loss;
@@ -306,7 +301,6 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();            // xw / xg are rewritten by the next iteration
     }
 #pragma unroll
     for (int f = 0; f < FPT; ++f) {

@@ -41,7 +41,8 @@ def test_knn_full_size_properties(north_star_features):
     ref_i, ref_d = knn_ref.knn_topk(q[rows], p, 32)
     st = knn_ref.topk_agreement(ref_i, idx_c[rows], knn_ref.cosine_dist_f64(q[rows], p), tau=5e-7)
     print("full-size kNN, 32 sampled rows:", st)
-    assert st["unexplained"] == 0 and st["top4"] == 1.0 and st["sets"] == 1.0 and st["allk"] >= 0.96 and st["max_gap"] <= 5e-7
+    # ratcheted to the measured values (r03: every sampled row equals the oracle's ordered top-32, largest inversion 0)
+    assert st["unexplained"] == 0 and st["top4"] == 1.0 and st["sets"] == 1.0 and st["allk"] >= 0.99 and st["max_gap"] <= 5e-7
     assert float((dist_c[rows] - ref_d).abs().max()) < 5e-6
     # determinism: the same launch twice is bit-identical
     idx2, dist2 = ops.knn_topk(qd, pd, 32)
@@ -236,6 +237,6 @@ def test_prematch_speaker_full_size_properties():
         first4 = float((ref[:, :4] == nn[rows][:, :4]).all(1).float().mean())
         sets = float(np.mean([set(a.tolist()) == set(b.tolist()) for a, b in zip(ref, nn[rows])]))
         print(f"prematch speaker, utterance {i}: first-4 rows equal {first4:.3f}, top-32 sets equal {sets:.3f}")
-        assert first4 >= 0.99 and sets >= 0.95
+        assert first4 == 1.0 and sets >= 0.99              # measured (r03): 1.000 / 1.000 on all three utterances
         ra = prematch_ref.amp_ratio(spec[s:e][rows], spec, nnf[rows][:, :4])
         assert float(((ra - ar[rows]).abs() / ra).max()) < 2e-6

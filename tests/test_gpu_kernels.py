@@ -572,7 +572,7 @@ def test_smooth_weights_with_amp_ratio():
     w, it = ops.smooth_weights(idx.to(DEV), pool.to(DEV), 1000.0, return_iters=True, row_scale=ar.to(DEV))
     e = _err(w, ref)[0]
     print("amp-scaled weights max|d|", e, "iters", int(it), "ref", it_ref)
-    assert e < 5e-3 and abs(int(it) - it_ref) <= 100
+    assert e < 2e-5 and abs(int(it) - it_ref) <= 2        # measured (r03): 1.1e-6, 401 iterations on both sides
     plain = ops.smooth_weights(idx.to(DEV), pool.to(DEV), 1000.0)
     assert float((plain - w).abs().max()) > 1e-3                                  # the scale is not ignored
 
