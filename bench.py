@@ -137,6 +137,7 @@ class stage:
 
 
 _FRONT_SIDE = {}
+_CONV = [0]                            # conversions started so far (the same count on every rank): who owns the next back half
 
 
 def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
@@ -169,10 +170,17 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
         counts = [1500 * (base + (1 if r < rem else 0)) for r in range(ws)]
         with stage("knn"):
             nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K, replicated=True, counts=counts)
+        # ONE rank owns the back half (match + generator) of a conversion, and the owner rotates: conversion i belongs to
+        # rank i mod ws, which alone receives the pool rows (point-to-point, no replication) — the other ranks go straight on
+        # to the front half of conversion i + 1.  Per rank and conversion: 1/ws of the encoder + 1/ws of a back half.
+        owner = _CONV[0] % ws
+        _CONV[0] += 1
         with stage("gather"):
-            P = kdist.all_gather_rows_var(P_loc, counts)
-            Pf0 = kdist.all_gather_rows_var(Pf0_loc, counts)
-            Ph = kdist.all_gather_rows_var(Ph_loc, counts)
+            P = kdist.gather_rows_var(P_loc, counts, owner)
+            Pf0 = kdist.gather_rows_var(Pf0_loc, counts, owner)
+            Ph = kdist.gather_rows_var(Ph_loc, counts, owner)
+        if rank != owner:
+            return None
         return dict(qf=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, nn32=nn32)
     # the pool all-gather (123 MB per rank) starts now and travels under the local kNN search; waited for below
     P, wait_P = kdist.all_gather_rows_async(P_loc)
@@ -188,6 +196,8 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
 
 def step_back(voc, f):
     """f0 shift / re-rank / concat re-selection / Adam weights / gathers -> additive synth + generator."""
+    if f is None:                      # --scaling strong: another rank owns this conversion's back half
+        return None
     with stage("match"):
         of, hw, s0, dbg = match_features(f["qf"], f["qf0"], f["P"], f["Pf0"], f["Ph"], "mix", "post_opt_0.2", nn32=f["nn32"],
                                          return_debug=True)
@@ -210,10 +220,11 @@ def run_steps(n, depth, enc, voc, src, sf0, pool_w, pool_f0, max_batch, pipe):
     if depth <= 1:
         y = None
         for _ in range(n):
-            y = step(enc, voc, src, sf0, pool_w, pool_f0, max_batch)
+            yi = step(enc, voc, src, sf0, pool_w, pool_f0, max_batch)
+            y = yi if yi is not None else y
         return y
-    return pipe.run(range(n), lambda _i: step_front(enc, src, sf0, pool_w, pool_f0, max_batch),
-                    lambda _i, f: step_back(voc, f))[-1]
+    ys = pipe.run(range(n), lambda _i: step_front(enc, src, sf0, pool_w, pool_f0, max_batch), lambda _i, f: step_back(voc, f))
+    return next((y for y in reversed(ys) if y is not None), None)       # strong scaling: this rank's last own conversion
 
 
 def effective_cores() -> int:
@@ -468,8 +479,11 @@ def main():
         timer.enabled = False
         enc.use_graphs = True
     kdist.raise_if_any_nan()                                            # the deferred NaN flags of every sharded search of this run
-    assert y.numel() == SRC_SECONDS * C.SAMPLE_RATE, y.numel()          # 1500 frames x 320
-    assert bool(torch.isfinite(y).all()), "non-finite waveform"
+    if y is not None:                                                   # strong scaling with fewer steps than ranks: not every rank owned one
+        assert y.numel() == SRC_SECONDS * C.SAMPLE_RATE, y.numel()      # 1500 frames x 320
+        assert bool(torch.isfinite(y).all()), "non-finite waveform"
+    else:
+        assert STRONG and rank != 0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         if dist.get_backend() == "gloo":
@@ -513,7 +527,8 @@ def main():
                                    "ckpt_type=mix, post_opt_0.2, cold (pool encoded inside the step); seeded random "
                                    "weights of WavLM-Large (6 layers executed) and the 22.9 M-param generator",
                        "nq": 1500, "np_per_rank": (30000 // ws if STRONG else 30000),
-                       "pool_sharding": (f"one pool, rows over {ws} rank(s) in file order, replicated queries, RCCL all-gather merge"
+                       "pool_sharding": (f"one pool, rows over {ws} rank(s) in file order, replicated queries, RCCL all-gather merge of the top-32 lists; "
+                                         f"match + generator of conversion i on rank i mod {ws} only, pool rows to that rank point-to-point"
                                          if STRONG else f"rows over {ws} rank(s), RCCL all-to-all merge"),
                        "wavlm_batch_chunks": a.max_batch,
                        "pipeline_depth": a.pipeline_depth,

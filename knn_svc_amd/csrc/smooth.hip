@@ -241,12 +241,17 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
             if (t < nq - 1) {
                 const f32x4 w1 = *(const f32x4*)&xw[(t + 1) * KW], w0 = *(const f32x4*)&xw[t * KW];
                 const float c[8] = {w1[0], w1[1], w1[2], w1[3], -w0[0], -w0[1], -w0[2], -w0[3]};
-                float y[8];
+                // c[j] - c[i] once per pair: (c[i] - c[j]) is its exact negation (a free source modifier), the sums keep their order
+                float dd[GE], y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = i + 1; j < 8; ++j) dd[tri(i, j)] = c[j] - c[i];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float s = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j != i) s += g[f][tri(i, j)] * (c[j] - c[i]);
+                    for (int j = 0; j < 8; ++j) if (j != i) s = fmaf(g[f][tri(i, j)], j > i ? dd[tri(i, j)] : -dd[tri(i, j)], s);
                     y[i] = s;
                 }
                 float qf = 0.f;

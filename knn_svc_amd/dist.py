@@ -100,6 +100,33 @@ def all_gather_rows_var(t: torch.Tensor, counts=None) -> torch.Tensor:
     return torch.cat([g[r, :c] for r, c in enumerate(counts)], 0)
 
 
+def gather_rows_var(t: torch.Tensor, counts, dst: int):
+    """The rows of every rank's shard (``counts[r]`` rows on rank r), in rank order, on rank ``dst`` ONLY -> the whole tensor
+    there, None elsewhere.  Point-to-point (one grouped isend / irecv batch): a pool that only its owner matches against is not
+    replicated (bench.py --scaling strong: the owner of a conversion rotates over the ranks).  gloo with device tensors
+    (one-card rehearsal) stages through host memory like the collectives above."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    counts = [int(c) for c in counts]
+    assert t.shape[0] == counts[rank], (t.shape, counts, rank)
+    staged = _host_staged(t)
+    src = t.contiguous().cpu() if staged else t.contiguous()
+    if rank != dst:
+        if counts[rank]:
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, dst)]):
+                r.wait()
+        return None
+    out = torch.empty((sum(counts),) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
+    views = out.split(counts, 0)
+    views[rank].copy_(src)
+    ops_ = [dist.P2POp(dist.irecv, views[r], r) for r in range(ws) if r != rank and counts[r]]
+    if ops_:
+        for r in dist.batch_isend_irecv(ops_):
+            r.wait()
+    return out.to(t.device) if staged else out
+
+
 _NAN_FLAGS = []      # device flags of the per-shard searches since the last raise_if_any_nan()
 
 

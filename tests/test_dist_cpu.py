@@ -102,6 +102,8 @@ def test_work_sharing_single_process():
     sys.path.insert(0, ROOT)
     from knn_svc_amd import dist as kd
     assert kd.my_share([1, 2, 3]) == [1, 2, 3] and kd.gather_paths(["a"]) == ["a"]
+    t = torch.arange(6.).reshape(3, 2)
+    assert kd.gather_rows_var(t, [3], 0) is t
 
 
 def _uneven_worker(rank, ws, port, out):
@@ -123,6 +125,10 @@ def _uneven_worker(rank, ws, port, out):
     ri, rd = kd.sharded_knn(qr, mine.contiguous(), 8, _cpu_local_topk, _cpu_merge, replicated=True)
     fi, fd = _cpu_local_topk(qr, pool, 8, 0)
     ok = ok and bool(torch.equal(rd, fd)) and bool((ri == fi).float().mean() > 0.99)
+    # rows to ONE rank only (the owner of a conversion's back half, bench.py --scaling strong), both ways round
+    for dst in (0, 1):
+        g = kd.gather_rows_var(mine.contiguous(), [437, 263], dst)
+        ok = ok and ((g is None) if rank != dst else bool(torch.equal(g, pool)))
     # contiguous file shares reproduce the single-process order
     lo, hi = kd.contiguous_share(11)
     ok = ok and (lo, hi) == ((0, 6) if rank == 0 else (6, 11))

@@ -132,6 +132,9 @@ def _knn_worker(rank, ws, port, res):
     # (c) variable-size row gather and the deferred NaN check (every rank raises together)
     g = kd.all_gather_rows_var(mine[:, :8].contiguous())
     ok = ok and bool(torch.equal(g, pool[:, :8]))
+    for dst in (0, 1):              # rows to one rank only (strong scaling: the owner of a conversion's back half)
+        g1 = kd.gather_rows_var(mine[:, :8].contiguous(), [cut, 9000 - cut], dst)
+        ok = ok and ((g1 is None) if rank != dst else (g1.is_cuda and bool(torch.equal(g1, pool[:, :8]))))
     kd.raise_if_any_nan()
     qn = q.clone(); qn[3, 5] = float("nan")
     raised = False
