@@ -358,6 +358,28 @@ def test_attention_and_gate():
     assert _err(out, ref)[0] < 2e-5
 
 
+@pytest.mark.parametrize("B,T,split", [(2, 333, False), (3, 700, True), (1, 1500, True)])
+def test_attention_64_queries_per_wave_equals_32(B, T, split, monkeypatch):
+    """attention2q_kernel<2> (64 queries per wave: the large-batch dispatch) against attention2_kernel (32 per wave): the
+    same operations per query in the same order — bit-identical, with ragged last blocks, key-padding lengths, pre-split K / V
+    and split output."""
+    ops = _ops()
+    H, E = 16, 1024
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B * T, 3 * E, generator=g) * 0.5).to(DEV)
+    gate = torch.rand(B * T, H, generator=g).to(DEV)
+    table = (torch.randn(H, 2 * T - 1, generator=g) * 0.1).to(DEV)
+    lens = torch.tensor([T - 37 * b for b in range(B)], dtype=torch.int32, device=DEV)
+    if split:
+        qkv = qkv.clone(); qkv[:, E:] = ops.split_pack(qkv[:, E:].contiguous())
+    res = {}
+    for qb in ("1", "2"):
+        monkeypatch.setenv("KNNSVC_ATT_QB", qb)
+        res[qb] = [ops.wavlm_attention(qkv, gate, table, B, T, H, kv_split=split, out_split=split, kv_len=kl).clone() for kl in (None, lens)]
+    for a, b in zip(res["1"], res["2"]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 # ------------------------------------------------------------------ kNN
 def test_knn_golden(golden):
     from oracle import knn_ref
