@@ -719,6 +719,13 @@ __global__ __launch_bounds__(256, 2) void attention2q_kernel(const float* __rest
     };
     gload(0);
     const int ntiles = (Tk + KT - 1) / KT;
+#ifdef KN_ATT_PROF          // timing aid (tools/attn_whatif.sh): where one wave's cycles go, printed by a few workgroups
+    unsigned long long pf[4] = {0, 0, 0, 0}, tq = __builtin_readcyclecounter();
+    const unsigned long long t_begin = tq;
+#define KN_ATICK(K) { const unsigned long long now = __builtin_readcyclecounter(); pf[K] += now - tq; tq = now; }
+#else
+#define KN_ATICK(K)
+#endif
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
         if (kv_split) {
@@ -746,11 +753,13 @@ __global__ __launch_bounds__(256, 2) void attention2q_kernel(const float* __rest
         }
         __syncthreads();
         if (t + 1 < ntiles) gload((t + 1) * KT);
+        KN_ATICK(0)
 
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kbase = t * KT + sub * 32;
             if (kbase >= Tk) break;
+
             // ---- S^T = K . Q^T for the QB query blocks: every K fragment pair is read once --------------
             f32x16 s[QB];
 #pragma unroll
@@ -770,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void attention2q_kernel(const float* __rest
                     s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q0, s[u], 0, 0, 0);
                 }
             }
+            KN_ATICK(1)
             // ---- online softmax per query block (lane-local + one exchange with lane ^ 32) ----------------
 #pragma unroll
             for (int u = 0; u < QB; ++u) {
@@ -801,6 +811,7 @@ __global__ __launch_bounds__(256, 2) void attention2q_kernel(const float* __rest
                         for (int r = 0; r < 16; ++r) o[u][d][r] *= alpha;
                 }
             }
+            KN_ATICK(2)
             // ---- O^T += V^T . P^T: every transposed V fragment is read once -------------------------------
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -834,8 +845,15 @@ __global__ __launch_bounds__(256, 2) void attention2q_kernel(const float* __rest
                     }
                 }
             }
+            KN_ATICK(3)
         }
     }
+#ifdef KN_ATT_PROF
+    if (tid == 0 && blockIdx.x == 2 && blockIdx.y == 3 && (blockIdx.z % 5) == 0)
+        printf("att prof (cycles per 64-key tile, wave 0 of batch %d): stage+barriers %.0f  S (K reads + issue) %.0f  softmax (incl. wait for S) %.0f  PV (split, V reads, issue) %.0f  | whole block %.0f\n",
+               (int)blockIdx.z, (double)pf[0] / ntiles, (double)pf[1] / ntiles, (double)pf[2] / ntiles, (double)pf[3] / ntiles, (double)(__builtin_readcyclecounter() - t_begin));
+#endif
+#undef KN_ATICK
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
         if (!qvalid[u]) continue;

@@ -208,6 +208,22 @@ class Vocoder:
             ch = uic // 2 ** (n_up - level)
             return buf[:, ch:], buf.shape[1], self.side[level], cat_slot[n_up - 1 - level]
 
+        # ---- head of the main path: input projection + conv_pre -> cat_pre[:, :uic] ------------------------
+        # It shares nothing with the side path below but the concat buffer's slot (both fold a maximum into it), and the side
+        # path — the synthesiser and eight short convolutions down to the frame rate, each a single wave of workgroups — is the
+        # critical path to the first stage: with free streams the head runs next to it (the ResBlock branches' fork / join).
+        s_x0, s_c = slot(), slot()
+
+        def head():
+            x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b, x_absmax=ops.absmax(c.contiguous(), s_c), out_absmax=s_x0, dyn=dyn)
+            self._conv(x0, self.pre_w, cat_pre, T_in=N, cin=x0.shape[1], cout=uic, k=7, m=N, pad=3, bias=self.pre_b,
+                       ldo=cat_pre.shape[1], x_absmax=s_x0, out_absmax=cat_pre_slot)
+        head_on = None
+        if self._par() and os.environ.get("KNNSVC_HEAD_FORK", "1") != "0":
+            head_on = self._branch_streams(dev)[0]
+            head_on.wait_event(torch.cuda.current_stream(dev).record_event())
+            with torch.cuda.stream(head_on):
+                head()
         # ---- excitation + sin_prenet -> res[0] -------------------------------------------------
         cond, ld0, c0, s0 = res_view(0)
         ops.additive_synth(f0.contiguous(), harm.contiguous() if self.kind == "mix" else None, self.prenet_w, self.prenet_b,
@@ -227,11 +243,10 @@ class Vocoder:
             self._conv(mid, rb["w"], dst, T_in=t_mid, cin=c_d, cout=c_d, k=3, m=lens[i + 1], pad=1, bias=rb["b"],
                        a_slope=LRELU, resid=mid, ldr=c_d, ldo=ld_d, x_absmax=s_mid, out_absmax=s_dst)
         # ---- main path ------------------------------------------------------------------------------
-        s_x0 = slot()
-        x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b, x_absmax=ops.absmax(c.contiguous(), slot()), out_absmax=s_x0, dyn=dyn)
-        hd = x0.shape[1]
-        self._conv(x0, self.pre_w, cat_pre, T_in=N, cin=hd, cout=uic, k=7, m=N, pad=3, bias=self.pre_b,
-                   ldo=cat_pre.shape[1], x_absmax=s_x0, out_absmax=cat_pre_slot)
+        if head_on is None:
+            head()
+        else:
+            torch.cuda.current_stream(dev).wait_stream(head_on)
         x, s_x = new(N, uic), slot()
         self._conv(cat_pre, self.cpre_w, x, T_in=N, cin=cat_pre.shape[1], cout=uic, k=3, m=N, pad=1, bias=self.cpre_b,
                    x_absmax=cat_pre_slot, out_absmax=s_x)
