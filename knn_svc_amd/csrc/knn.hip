@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
     bool saw_nan = false, has_thr = false;      // has_thr: the list holds k real entries, thr_d is its largest distance
     float thr_d = 0.f;
     const float v_rq = __builtin_amdgcn_rcpf(v_qn);
-    constexpr int U = 4;               // sub-chunks of 128 columns per wave and iteration, all loads issued up front
+#ifndef KN_SELECT_U
+#define KN_SELECT_U 2          // 2: 156 us at 1500 x 30000; 4: 164; 8: 200; 16: 220 (kernel time under rocprofv3) — the warm-up merges bound it, not load latency
+#endif
+    constexpr int U = KN_SELECT_U;     // sub-chunks of 128 columns per wave and iteration, all loads issued up front
     for (long base0 = (long)wave * (128 * U); base0 < np; base0 += 512 * U) {
         float dv[2 * U], sv[2 * U], nv[2 * U];
 #pragma unroll
