@@ -1,7 +1,8 @@
 """Idle analysis of a rocprofv3 kernel trace of the pipelined bench: over the last WINDOW ms, the time during which no
-chip-wide kernel (>= 256 workgroups) is executing, and the largest such gaps with the kernels around them.
+chip-wide kernel (>= MINWG workgroups, default 256; env MINWG) is executing, and the largest such gaps with the kernels around them.
     python tools/timeline_gaps.py <kernel_trace.csv> [window_ms]"""
-import csv, sys
+import csv, os, sys
+MINWG = int(os.environ.get("MINWG", "256"))
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     wg = (int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) * max(1, int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"]))) * \
@@ -11,7 +12,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 win = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 150e6
 t1 = rows[-1][1]; t0 = t1 - win
-wide = [(max(s, t0), e, n) for s, e, n, wg in rows if wg >= 256 and e > t0]
+wide = [(max(s, t0), e, n) for s, e, n, wg in rows if wg >= MINWG and e > t0]
 busy = 0; cur_s = cur_e = None; gaps = []; last_name = None
 for s, e, n in wide:
     if cur_e is None: cur_s, cur_e, last_name = s, e, n; continue
