@@ -10,16 +10,28 @@ work of its neighbours.  Every item still does all of its work; only the order o
 results are bit-identical to the sequential order (same kernels, same inputs).
 
 Constraint: a captured hipGraph owns its input / output / scratch buffers, so the SAME graph must not be replayed from
-two lanes at once (`WavLMEncoder.encode_batch`, `Vocoder.forward`): heads that encode use one lane (bench.py), heads that
-only match may use several (dataset mode), the generator runs on the single tail stream.  Replaying one encoder graph
-from two lanes aborts the process (observed), it does not merely race.
+two streams at once (`WavLMEncoder.encode_batch`, `Vocoder.forward`): heads that encode use one lane (bench.py), heads that
+only match may use several (dataset mode).  Replaying one encoder graph from two lanes aborts the process (observed), it
+does not merely race.  The tail runs on THREE tail streams when there are several lanes (item i on tail i mod 3): the
+generator keeps one graph instance and one memory pool per tail (`current_tail()`), so up to three generators of different
+items are in flight — each is a chain of short launches that leave most of the chip idle on their own.
 
 HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that share a queue
 serialise.  knn_svc_amd/__init__.py raises the default to 8 before the runtime starts.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
+
+
+_TAIL = threading.local()
+
+
+def current_tail() -> int:
+    """Index of the tail stream the calling code runs on (0 outside LanePipeline.run or with one tail)."""
+    return getattr(_TAIL, "k", 0)
 
 
 def _tensors(obj):
@@ -44,7 +56,18 @@ class LanePipeline:
         # other on a queue (more so once RCCL has created its streams) but never with these — and lets a lone
         # workgroup take the first CU that frees up.
         import os
-        self.tail_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("KNNSVC_TAIL_PRIORITY", "-1")))
+        pr = int(os.environ.get("KNNSVC_TAIL_PRIORITY", "-1"))
+        # THREE tail streams, item i's tail on stream i mod 3 (KNNSVC_TAILS=n): the generator is ~110 launches most of which are a
+        # single round of workgroups waiting on latencies, so one generator leaves most of the chip's issue slots idle and two or
+        # three in flight (different items) fill them — cfg 5 share 2620 -> 3140 xRT with two tails, 3070-3140 with three / four;
+        # dataset mode on 5-10 s utterances (cfg 3) 1405 -> 1840 -> 2080 -> 2080 (tools/cfg5_product_bench.py, tools/cfg3_bench.py).
+        # A consumer that replays hipGraphs keeps one graph instance and one memory pool per tail (Vocoder.forward, current_tail()).
+        # Only with several lanes (dataset mode, serving: the generator runs with its ResBlock branches in series there): next to
+        # the generator's own branch streams the extra tails oversubscribe the hardware queues — the depth-2 pipeline of bench.py
+        # (one lane) went from 35 to 470-750 ms per step with three tails.
+        n_tails = int(os.environ.get("KNNSVC_TAILS", "0")) or (3 if lanes > 1 else 1)
+        self.tail_streams = [torch.cuda.Stream(device=self.device, priority=pr) for _ in range(max(1, n_tails))]
+        self.tail_stream = self.tail_streams[0]
 
     def run(self, items, head, tail=None):
         """results[i] = tail(item_i, head(item_i)) (or head(item_i) without a tail), in item order.
@@ -52,7 +75,7 @@ class LanePipeline:
         ``head`` and ``tail`` must only enqueue GPU work (no host synchronisation — a ``.item()`` inside them
         would serialise the pipeline); they see their lane / the tail stream as the current stream."""
         cur = torch.cuda.current_stream(self.device)
-        for s in self.lanes + [self.tail_stream]:
+        for s in self.lanes + self.tail_streams:
             s.wait_stream(cur)
         out = []
         for i, item in enumerate(items):
@@ -63,12 +86,17 @@ class LanePipeline:
             if tail is None:
                 out.append(h)
                 continue
-            with torch.cuda.stream(self.tail_stream):
-                self.tail_stream.wait_event(done)
+            ts = self.tail_streams[i % len(self.tail_streams)]
+            with torch.cuda.stream(ts):
+                ts.wait_event(done)
                 for t in _tensors(h):
-                    t.record_stream(self.tail_stream)
-                out.append(tail(item, h))
-        for s in self.lanes + [self.tail_stream]:
+                    t.record_stream(ts)
+                _TAIL.k = i % len(self.tail_streams)
+                try:
+                    out.append(tail(item, h))
+                finally:
+                    _TAIL.k = 0
+        for s in self.lanes + self.tail_streams:
             cur.wait_stream(s)
         for t in _tensors(out):
             t.record_stream(cur)

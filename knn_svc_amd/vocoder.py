@@ -100,7 +100,8 @@ class Vocoder:
         self._graphs = {}          # frame bucket -> (hipGraph, static inputs, device frame count, static output); insertion order = LRU
         self._seen = set()
         self._graph_pool = None if not torch.cuda.is_available() else torch.cuda.graph_pool_handle()
-        self.max_graphs = 32
+        self._graph_pools = {0: self._graph_pool}
+        self.max_graphs = 48            # (bucket, mode, tail) instances
         self.use_graphs = True
         self.parallel_resblocks = os.environ.get("KNNSVC_PAR_RESBLOCKS", "1") != "0"
         self._branch = {}
@@ -134,14 +135,19 @@ class Vocoder:
         convolutions' own zero padding, rows past it are not written), which makes the bucket's graph compute exactly what
         an exact-length run computes (`test_vocoder_bucket_graph_equals_exact_length`).  A shape is run eagerly at first
         sight and captured when it comes back; capture does not synchronise the device (ops.capture_graph), so meeting a new
-        bucket inside the dataset-mode stream pipeline costs one eager pass, not a pipeline stall.  LRU cache, one shared
-        memory pool (the graphs only ever replay one after the other on the tail stream)."""
+        bucket inside the dataset-mode stream pipeline costs one eager pass, not a pipeline stall.  LRU cache; the graphs of ONE
+        tail stream share a memory pool (they only ever replay one after the other), each further tail of the stream pipeline
+        has its own instances and its own pool (pipeline.current_tail())."""
         N = c.shape[0]
         if not self.use_graphs or torch.cuda.is_current_stream_capturing():
             return self._forward(c, f0, harm)
         q = self.BUCKET_FRAMES
         Nb = -(-N // q) * q
         key = Nb if self._par() else (Nb, "serial")
+        from . import pipeline
+        slot = pipeline.current_tail()          # tail stream index of the stream pipeline (0 outside one): graphs replayed from
+        if slot:                                # different tail streams may overlap — one instance and one memory pool per tail
+            key = (key, slot)
         ent = self._graphs.get(key)
         if ent is None:
             if key not in self._seen:                      # first sight: eager, exact length
@@ -152,7 +158,9 @@ class Vocoder:
             sf = torch.zeros(Nb, device=dev, dtype=torch.float32)
             sh = torch.zeros(Nb, harm.shape[1], device=dev, dtype=torch.float32) if harm is not None else None
             nd = torch.full((1,), N, device=dev, dtype=torch.int32)
-            g, out = ops.capture_graph(lambda: self._forward(sc, sf, sh, n_dyn=nd), self.device, self._graph_pool)
+            if slot not in self._graph_pools:
+                self._graph_pools[slot] = torch.cuda.graph_pool_handle()
+            g, out = ops.capture_graph(lambda: self._forward(sc, sf, sh, n_dyn=nd), self.device, self._graph_pools[slot])
             ent = self._graphs[key] = (g, sc, sf, sh, nd, out)
             while len(self._graphs) > self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))            # least recently used
