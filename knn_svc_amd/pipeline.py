@@ -65,7 +65,11 @@ class LanePipeline:
         # Only with several lanes (dataset mode, serving: the generator runs with its ResBlock branches in series there): next to
         # the generator's own branch streams the extra tails oversubscribe the hardware queues — the depth-2 pipeline of bench.py
         # (one lane) went from 35 to 470-750 ms per step with three tails.
-        n_tails = int(os.environ.get("KNNSVC_TAILS", "0")) or (3 if lanes > 1 else 1)
+        # Why not more: with HIP's 8 hardware queues four tails are a little faster still (cfg 3: 2140 -> 2400 xRT) but FIVE collapse
+        # (cfg 5 share 3170 -> 530 xRT: streams that depend on each other end up sharing queues), and 12 / 16 queues are slower at
+        # any tail count (tools/final_profiles.sh, profiles/r03_tail_streams_ab.txt) — three keeps two streams of headroom, fewer
+        # when the caller asks for more than three lanes.
+        n_tails = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
         self.tail_streams = [torch.cuda.Stream(device=self.device, priority=pr) for _ in range(max(1, n_tails))]
         self.tail_stream = self.tail_streams[0]
 
