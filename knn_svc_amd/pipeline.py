@@ -70,6 +70,10 @@ class LanePipeline:
         # any tail count (tools/final_profiles.sh, profiles/r03_tail_streams_ab.txt) — three keeps two streams of headroom, fewer
         # when the caller asks for more than three lanes.
         n_tails = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
+        if "KNNSVC_TAILS" not in os.environ and n_tails > 2:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+                n_tails = 2            # RCCL brings streams of its own (unmeasured on this side: no multi-GPU node): one more of headroom
         self.tail_streams = [torch.cuda.Stream(device=self.device, priority=pr) for _ in range(max(1, n_tails))]
         self.tail_stream = self.tail_streams[0]
 
