@@ -120,7 +120,12 @@ class KNeighborsVC:
                 rows = list(csv.reader(fp, delimiter=",", quotechar='"'))
             required = [r[2] for i, r in enumerate(rows) if i != 0 and r[-1] == "0"]
         f0only = "wavlm_only" in ckpt_type or "no_harm_no_amp" in ckpt_type
-        written = []
+        # Files are encoded and written by a small thread pool while the next speaker pair is on the GPU (a pair's 80 files cost
+        # the host ~20 ms during which the device idled: 7 % of a cfg-3 run, tools/timeline_cmd.sh); the paths are collected in
+        # order at the end, where a failed write raises.
+        from concurrent.futures import ThreadPoolExecutor
+        writer = ThreadPoolExecutor(max_workers=2, thread_name_prefix="knnsvc-writer")
+        pending = []
         pairs = [(s, t) for i, s in enumerate(src_spk) for j, t in enumerate(tgt_spk)
                  if not (src_dataset_path == tgt_dataset_path and i == j)]
         # One process per GPU, two ways to share a dataset run, never both at once:
@@ -132,30 +137,33 @@ class KNeighborsVC:
         rank, ws = kdist.world()
         shard = os.environ.get("KNNSVC_POOL_SHARD") == "1" and ws > 1
         my_pairs = pairs if shard else kdist.my_share(pairs)
-        for s, t in my_pairs:
-            print(f"{s} -> {t}")
-            common = dict(topk=topk, device=self.device, prioritize_f0=prioritize_f0, ckpt_type=ckpt_type,
-                          src_dataset_path=src_dataset_path, tgt_dataset_path=tgt_dataset_path,
-                          required_subset=required, duration_limit=duration_limit,
-                          pool_sharded=shard, share_items=shard)
-            # the generator of every utterance is the tail stage of the match pipeline (same kernels and inputs as
-            # `vocode` after the fact, ddsp_matcher.py:1114-1128, but enqueued under the next utterances' matching);
-            # one finiteness check per speaker pair instead of one host sync per utterance
-            preds = {}
-            if not f0only:
-                match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting, post_opt=post_opt,
-                                        vocode_fn=self._vocode_async, waves_out=preds, **common)
-            else:
-                match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting,
-                                        vocode_fn=lambda c, f0, _h: self._vocode_async(c, f0), waves_out=preds, **common)
-            if preds:      # max |x| of a waveform is NaN / inf iff the waveform holds one
-                self._check_finite(torch.stack([p.abs().max() for p in preds.values()]))
-            for k, pred in preds.items():
-                out = os.path.join(converted_audio_dir, os.path.basename(s), os.path.basename(k).split(".")[0],
-                                   os.path.basename(t) + "." + os.path.basename(k).split(".")[-1])
-                Path(out).parent.mkdir(parents=True, exist_ok=True)
-                assert pred.dim() == 1
-                out = audio_io.save_audio(out, pred[None, :].cpu().numpy(), sample_rate=self.sr)
-                written.append(out)
-            print(f"{os.path.basename(s)}, {os.path.basename(t)} -> {converted_audio_dir}")
+        try:
+            for s, t in my_pairs:
+                print(f"{s} -> {t}")
+                common = dict(topk=topk, device=self.device, prioritize_f0=prioritize_f0, ckpt_type=ckpt_type,
+                              src_dataset_path=src_dataset_path, tgt_dataset_path=tgt_dataset_path,
+                              required_subset=required, duration_limit=duration_limit,
+                              pool_sharded=shard, share_items=shard)
+                # the generator of every utterance is the tail stage of the match pipeline (same kernels and inputs as
+                # `vocode` after the fact, ddsp_matcher.py:1114-1128, but enqueued under the next utterances' matching);
+                # one finiteness check per speaker pair instead of one host sync per utterance
+                preds = {}
+                if not f0only:
+                    match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting, post_opt=post_opt,
+                                            vocode_fn=self._vocode_async, waves_out=preds, **common)
+                else:
+                    match_at_inference_time(Path(s), Path(t), self.wavlm, self.weighting, self.weighting,
+                                            vocode_fn=lambda c, f0, _h: self._vocode_async(c, f0), waves_out=preds, **common)
+                if preds:      # max |x| of a waveform is NaN / inf iff the waveform holds one
+                    self._check_finite(torch.stack([p.abs().max() for p in preds.values()]))
+                for k, pred in preds.items():
+                    out = os.path.join(converted_audio_dir, os.path.basename(s), os.path.basename(k).split(".")[0],
+                                       os.path.basename(t) + "." + os.path.basename(k).split(".")[-1])
+                    Path(out).parent.mkdir(parents=True, exist_ok=True)
+                    assert pred.dim() == 1
+                    pending.append(writer.submit(audio_io.save_audio, out, pred[None, :].cpu().numpy(), self.sr))
+                print(f"{os.path.basename(s)}, {os.path.basename(t)} -> {converted_audio_dir}")
+            written = [f.result() for f in pending]
+        finally:
+            writer.shutdown(wait=True)
         return kdist.gather_paths(written)
