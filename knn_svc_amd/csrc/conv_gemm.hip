@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
     const int b = z / a.groups, g = z - b * a.groups;
     // XCD-aware order (gemm2_core.h, quad_order_decode)
     int mt, nt;
-    if (!quad_order_decode((int)blockIdx.x, (a.m + G::BM - 1) / G::BM, (a.n + G::BN - 1) / G::BN, mt, nt)) return;
+    if (!quad_order_decode((int)blockIdx.x, (a.m + G::BM - 1) / G::BM, (a.n + G::BN - 1) / G::BN, mt, nt, (int)blockIdx.z)) return;
     const int m0 = mt * G::BM, n0 = nt * G::BN;
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;

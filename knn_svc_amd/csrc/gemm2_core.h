@@ -53,11 +53,25 @@ __host__ __device__ __forceinline__ bool quad_order_swap(long gx, long gy) {
     // of the last group only, nothing idles for long)
     return (gx8 - gx) * 16 > gx8 && (gx8 - gx) * gy8 > (gy8 - gy) * gx8;
 }
+// Small grids where EITHER dimension would be padded by more than 1/16: plain order, no padding ids.  A padding id is not free — the
+// workgroup needs its 128 KB of LDS before it can run and exit, workgroups are dispatched in order, and id i goes to XCD i mod 8: an
+// XCD (32 CUs, one workgroup each) that is handed 42 ids runs two rounds even if a quarter of them are padding.  The feature
+// extractor's last layers (1500 / 3000 rows per chunk = 6 / 12 row tiles x 2 column tiles x 21 chunks) ran 2 / 3 rounds that way;
+// unpadded they are 252 / 504 ids = 1 / 2 rounds.  (L2 panel sharing is moot at these sizes.)
+__host__ __device__ __forceinline__ bool quad_order_linear(long gx, long gy) {
+    const long gx8 = (gx + 7) / 8 * 8, gy8 = (gy + 7) / 8 * 8;
+    return (gx8 - gx) * 16 > gx8 && (gy8 - gy) * 16 > gy8;
+}
 __host__ __device__ __forceinline__ long quad_order_ids(long gx, long gy) {
+    if (quad_order_linear(gx, gy)) return gx * gy;
     return quad_order_swap(gx, gy) ? (gy + 7) / 8 * 8 * gx : (gx + 7) / 8 * 8 * gy;
 }
-// id L in [0, quad_order_ids) -> tile (mt, nt); false: padding
-__device__ __forceinline__ bool quad_order_decode(int L, int gx, int gy, int& mt, int& nt) {
+// rot: rotates which XCD gets which row of a group of 8 (a batched launch passes its batch index): every batch slice has the same
+// padding rows, and unrotated they would starve the same XCDs in every slice — the feature extractor's last layers (1500 / 3000
+// rows per chunk = 6 / 12 row tiles, padded to 8 / 16, x 21 chunks) ran 2 and 3 rounds of tiles on six / four busy XCDs instead of
+// 1 and 2 on eight.
+__device__ __forceinline__ bool quad_order_decode(int L, int gx, int gy, int& mt, int& nt, int rot = 0) {
+    if (quad_order_linear(gx, gy)) { mt = L % gx; nt = L / gx; return true; }
     const bool sw = quad_order_swap(gx, gy);
     const int ga = sw ? gy : gx, gb = sw ? gx : gy;            // ga: dealt over the XCDs
     const int ga8 = (ga + 7) / 8 * 8;
@@ -67,7 +81,7 @@ __device__ __forceinline__ bool quad_order_decode(int L, int gx, int gy, int& mt
     if (L < full) { c0 = (L / (CW * ga8)) * CW; cw = CW; L -= (c0 / CW) * CW * ga8; }
     else { c0 = (gb / CW) * CW; cw = gb - c0; L -= full; }
     const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
-    const int at = grp * 8 + (rem & 7), bt = c0 + (rem >> 3);
+    const int at = grp * 8 + ((rem + rot) & 7), bt = c0 + (rem >> 3);
     mt = sw ? bt : at; nt = sw ? at : bt;
     return at < ga;
 }
