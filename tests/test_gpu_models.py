@@ -284,6 +284,34 @@ def test_lane_pipeline_matches_sequential_order():
         assert torch.equal(a0 * 2.0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
 
 
+def test_generators_on_three_tails_equal_one_generator():
+    """The stream pipeline runs the tail of item i on tail stream i mod 3 when it has several lanes; the generator keeps one hipGraph
+    instance (and one memory pool) per tail.  Seven utterances of three lengths through three tails — first sight (eager), capture
+    and replay on every tail — give the waveforms of the same generator run on one stream."""
+    from knn_svc_amd import pipeline
+    from knn_svc_amd.vocoder import Vocoder, serial_resblocks
+    voc = Vocoder(S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, "mix"), 2), C.HIFIGAN_V1, "mix", DEV)
+    g = torch.Generator().manual_seed(11)
+    items = []
+    for i in range(7):
+        N = (120, 95, 150)[i % 3]
+        c = torch.randn(N, 1024, generator=g).to(DEV); harm = (torch.rand(N, 49, generator=g) * 0.02).to(DEV)
+        _, f0 = S.synth_clip(N * 320, 30 + i); f0 = torch.from_numpy(f0[:N].copy()).to(DEV)
+        items.append((c, f0, harm))
+    with serial_resblocks():
+        ref = [voc.forward(*it).clone() for it in items]
+        seen = []
+        pipe = pipeline.LanePipeline(DEV, lanes=3)
+        assert len(pipe.tail_streams) == 3
+        for _ in range(3):                      # eager, capture, replay on each tail
+            out = pipe.run(items, lambda it: it, lambda it, h: (seen.append(pipeline.current_tail()), voc.forward(*h))[1])
+    torch.cuda.synchronize()
+    assert seen[:7] == [0, 1, 2, 0, 1, 2, 0] and pipeline.current_tail() == 0
+    assert any(isinstance(k, tuple) and k[-1] in (1, 2) for k in voc._graphs)          # instances of the other tails exist
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+
+
 def test_prematch_files_match_reference(golden, tmp_path):
     """per_spk_extract on the GPU writes the reference's files (g12: pool.npy, pool_harmonics.npy, per-utterance
     pickles with slice / nearest_nbrs / nearest_nbrs_f0_priority / amp_ratio / harmonics_best_weight_para)."""
