@@ -57,7 +57,8 @@ __host__ __device__ __forceinline__ bool quad_order_swap(long gx, long gy) {
 // workgroup needs its 128 KB of LDS before it can run and exit, workgroups are dispatched in order, and id i goes to XCD i mod 8: an
 // XCD (32 CUs, one workgroup each) that is handed 42 ids runs two rounds even if a quarter of them are padding.  The feature
 // extractor's last layers (1500 / 3000 rows per chunk = 6 / 12 row tiles x 2 column tiles x 21 chunks) ran 2 / 3 rounds that way;
-// unpadded they are 252 / 504 ids = 1 / 2 rounds.  (L2 panel sharing is moot at these sizes.)
+// unpadded they are 252 / 504 ids = 1 / 2 rounds.  (L2 panel sharing is moot at these sizes — NOT for the long layers: the unpadded
+// order on the 48 007-row layer saves a round of 32 and still loses, 3.97 vs 3.85 ms, same box.)
 __host__ __device__ __forceinline__ bool quad_order_linear(long gx, long gy) {
     const long gx8 = (gx + 7) / 8 * 8, gy8 = (gy + 7) / 8 * 8;
     return (gx8 - gx) * 16 > gx8 && (gy8 - gy) * 16 > gy8;
