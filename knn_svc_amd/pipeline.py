@@ -67,8 +67,11 @@ class LanePipeline:
         # (one lane) went from 35 to 470-750 ms per step with three tails.
         # Why not more: with HIP's 8 hardware queues four tails are a little faster still (cfg 3: 2140 -> 2400 xRT) but FIVE collapse
         # (cfg 5 share 3170 -> 530 xRT: streams that depend on each other end up sharing queues), and 12 / 16 queues are slower at
-        # any tail count (tools/final_profiles.sh, profiles/r03_tail_streams_ab.txt) — three keeps two streams of headroom, fewer
-        # when the caller asks for more than three lanes.
+        # any tail count (tools/final_profiles.sh, profiles/r03_tail_streams_sweep.txt).  The numbers fit FOUR hardware queues for
+        # high-priority streams: four tails fill them, a fifth shares one with a tail it waits for — and the generator's own
+        # branch streams inherit the tail's priority, which is why tails + parallel branches collapsed at 3 x 3 streams.  Three
+        # leaves one such queue spare for whatever else the process created at that priority; fewer when the caller asks for
+        # more than three lanes.
         n_tails = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
         if "KNNSVC_TAILS" not in os.environ and n_tails > 2:
             import torch.distributed as dist
