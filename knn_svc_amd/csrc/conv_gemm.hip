@@ -806,8 +806,12 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm2win_kernel(ConvArgs a) {
     Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
     const int tid = threadIdx.x;
     const int w_off0 = ((m0 - a.pad + (tid >> 3)) * a.ldx + (tid & 7) * 4) * 4;
-    G::mainloop(lds, a.cin / 32, a.taps, a.dil, w_off0, a.ldx * 4, bl, acc, FastALoader<1>::desc(a, xz),
-                Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale, a.a_slope);
+    if constexpr (G::DEEP)
+        G::mainloop_deep(lds, a.cin / 32, a.taps, a.dil, w_off0, a.ldx * 4, bl, acc, FastALoader<1>::desc(a, xz),
+                         Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale, a.a_slope);
+    else
+        G::mainloop(lds, a.cin / 32, a.taps, a.dil, w_off0, a.ldx * 4, bl, acc, FastALoader<1>::desc(a, xz),
+                    Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale, a.a_slope);
     conv_epilogue_any<G>(a, acc, m0, n0, b, g);
 }
 
@@ -1179,6 +1183,7 @@ using R256 = Gemm2Ring<256, 128, 2, 2, 4, 2, 3>;       // 128x64 wave tiles, 72 
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
 using W160 = Gemm2Win<160, 128, 1, 4, 5, 1, 64>;      // 224-row window (32 KB) + 18 KB: still 3 blocks / CU; see the dispatch rule
 using W128S = Gemm2Win<64, 128, 2, 2, 1, 2, 64>;      // short time axes (first generator stage): twice the blocks, 37 KB
+using W128D = Gemm2Win<64, 128, 2, 2, 1, 2, 64, 1>;   // the same tile with the weight slabs requested two steps ahead (mainloop_deep)
 using W64 = Gemm2Win<256, 64, 4, 1, 2, 2, 64>;        // 320 rows (45 KB) + 9 KB
 using W32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // 320 rows + 4.5 KB
 using W64P = Gemm2Win<256, 64, 4, 1, 2, 2, 128>;      // k = 128 positional conv: 384 rows (54 KB) + 9 KB
@@ -1357,6 +1362,13 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
                     // fewer than ~2/3 of the chip's 768 resident slots at 128-row tiles: halve the tile height
                     static const bool small_on = [] { const char* e = getenv("KNNSVC_WIN_SMALL"); return !(e && e[0] == '0'); }();
                     if (small_on && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 512) {
+                        static const bool deep_on = [] { const char* e = getenv("KNNSVC_WIN_DEEP"); return !(e && e[0] == '0'); }();
+                        // two steps of weight prefetch where a launch leaves at most one workgroup per CU (nothing else hides the L2
+                        // round trip: 3750 x 256, k = 11: 70 -> 59 us); with more workgroups per CU the neighbours already do and the
+                        // second register set only costs (15 000 x 256, k = 7: 61 -> 66 us).  Same products, same order: same bits.
+                        if (deep_on && cdiv64(d->m, 64) * cdiv64(d->n, 128) * d->batches * d->groups <= 256) {
+                            g_last_kernel = "W128D"; return launch2win<W128D, 4>(a, d->batches, st);
+                        }
                         g_last_kernel = "W128S"; return launch2win<W128S, 4>(a, d->batches, st);
                     }
                     // Tile-count quantisation: 768 blocks are resident at once (3 per CU); a launch of 938 128-row tiles (the

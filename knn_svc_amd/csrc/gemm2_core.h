@@ -1152,8 +1152,9 @@ struct Gemm2QuadS {
 // The next slab's window travels in registers during the tap loop (W_F4 float4 per thread).  Sums over K are taken in
 // a different order than in Gemm2Tile (slab-major instead of tap-major): equal up to fp32 rounding of the accumulation.
 // -------------------------------------------------------------------------------------------------
-template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_, int HALO_>
+template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_, int HALO_, int DEEP_ = 0>
 struct Gemm2Win {
+    static constexpr int DEEP = DEEP_;          // 1: weight slabs requested two steps ahead (mainloop_deep)
     typedef f32x16 acc_t;
     static constexpr int NR = 16;
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_, HALO = HALO_;
@@ -1277,6 +1278,102 @@ struct Gemm2Win {
 #undef KN_STAGE_W
 #undef KN_LOAD_B
 #undef KN_STAGE_B
+    }
+
+    // The same loop with the weight slabs requested TWO steps ahead (DEEP = 1: the 64-row tiles of under-filled launches).  In
+    // `mainloop` the slab of step s + 1 is requested at the top of step s and staged at its end: one step (~400 cycles of MFMAs) to
+    // cover an L2 round trip, and on a grid that leaves one workgroup per CU nothing else runs meanwhile — a what-if build without
+    // the weight loads ran the generator's C = 256, k = 11 convolution in 71 instead of 91 us, and dataset mode on 5-10 s utterances
+    // spends more GPU time in these launches than in anything else.  Here two register sets alternate: the slab staged at the end
+    // of step s was requested at the end of step s - 2.  Steps are walked flat (channel slab outer, tap inner, as `mainloop`: the
+    // same products in the same order); the window of the next channel slab travels as before.
+    template <class BLoad, class RA, class RB>
+    __device__ __forceinline__ static void mainloop_deep(float* lds_generic, int ncs, int taps, int dil, int w_off0, int row_bytes,
+                                                         BLoad& bload, f32x16 (&acc)[TM][TN], RA ra_desc, RB rb_desc,
+                                                         float a_scale, float a_slope) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int w_st = (tid >> 3) * PITCH + (tid & 7) * 8;
+        const int li = lane & 31, lh = lane >> 5;
+        const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
+        const int b_frag = BOFF + (wn * TN * 32 + li) * PITCH + lh * 16;
+        const int tap_step = dil * PITCH;
+        const int nsteps = ncs * taps;
+        f32x4 rw[W_F4];
+        g2_u32x4 rb[2][B_P];
+        // slab of flat step s in the tap-major weight image: tap * ncs + cs, with s = cs * taps + tap
+        auto slab_of = [&](int s) { const int c = s / taps; return (s - c * taps) * ncs + c; };
+#define KN_D_LOAD_W(CS)                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < W_F4; ++j)                                                          \
+        rw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_desc, w_off0 + j * 32 * row_bytes + (CS) * 128, 0, 0));
+#define KN_D_STAGE_W()                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < W_F4; ++j) {                                                        \
+        f32x4 v = rw[j];                                                                                      \
+        if (a_slope != 1.0f) { _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a_slope; } \
+        g2_u32x2 hi, lo;                                                                                      \
+        f16x2_split4(v, a_scale, hi, lo);                                                                     \
+        *(lds_u2*)(lds + w_st + 32 * j * PITCH) = hi;                                                         \
+        *(lds_u2*)(lds + w_st + 32 * j * PITCH + 64) = lo;                                                    \
+    }
+#define KN_D_LOAD_B(SET, S)                                                                                    \
+    { const int sl_ = slab_of(S); bload.begin(sl_); _Pragma("unroll") for (int j = 0; j < B_P; ++j) rb[SET][j] = bload(sl_, j, rb_desc); }
+#define KN_D_STAGE_B(SET)                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < B_P; ++j) {                                                         \
+        const int q = tid + 256 * j;                                                                          \
+        if (B_PIECES % 256 == 0 || q < B_PIECES) *(lds_u4*)(lds + BOFF + (q >> 3) * PITCH + (q & 7) * 16) = rb[SET][j]; \
+    }
+        KN_D_LOAD_W(0)
+        KN_D_LOAD_B(0, 0)
+        KN_D_STAGE_W()
+        KN_D_STAGE_B(0)
+        if (nsteps > 1) KN_D_LOAD_B(1, 1)              // step s lives in set s & 1
+        if (nsteps > 2) KN_D_LOAD_B(0, 2)
+        __syncthreads();
+        int cs = 0, tap = 0, tap_off = 0;
+        // one step; SET = parity of step s + 1, whose slab is staged at the end of step s and whose set is reloaded with step s + 3
+#define KN_D_STEP(SET)                                                                                         \
+    {                                                                                                          \
+        const bool last_tap = tap + 1 == taps;                                                                 \
+        const bool more_cs = cs + 1 < ncs;                                                                     \
+        if (tap == 0 && more_cs) { KN_D_LOAD_W(cs + 1) }                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+            f16x8 fa[TM][2], fb[TN][2];                                                                        \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                 \
+                    fa[i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + a_frag + tap_off + i * 32 * PITCH + p * 64 + ks * 32)); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                    \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                 \
+                    fb[j][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + b_frag + j * 32 * PITCH + p * 64 + ks * 32)); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
+                    f32x16 c = acc[i][j];                                                                      \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], c, 0, 0, 0);               \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], c, 0, 0, 0);               \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], c, 0, 0, 0);               \
+                    acc[i][j] = c;                                                                             \
+                }                                                                                              \
+        }                                                                                                      \
+        __syncthreads();                                                                                       \
+        if (s + 1 < nsteps) { KN_D_STAGE_B(SET) }                                                              \
+        if (s + 3 < nsteps) { KN_D_LOAD_B(SET, s + 3) }                                                        \
+        if (last_tap && more_cs) { KN_D_STAGE_W() }                                                            \
+        __syncthreads();                                                                                       \
+        if (last_tap) { tap = 0; tap_off = 0; ++cs; } else { ++tap; tap_off += tap_step; }                     \
+    }
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            KN_D_STEP(1)                                // even step s: stages step s + 1 (odd -> set 1)
+            ++s;
+            KN_D_STEP(0)                                // odd step: stages step s + 1 (even -> set 0)
+            --s;
+        }
+        if (s < nsteps) { KN_D_STEP(1) }
+#undef KN_D_STEP
+#undef KN_D_LOAD_W
+#undef KN_D_STAGE_W
+#undef KN_D_LOAD_B
+#undef KN_D_STAGE_B
     }
 
     // Phase 2 of the fused ResBlock pair (conv_pair_kernel): the same tap loop with the A operand ALREADY resident in LDS for

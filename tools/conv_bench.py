@@ -8,6 +8,7 @@ from knn_svc_amd import ops
 M, CIN, N, TAPS, DIL = (int(v) for v in sys.argv[1:6])
 resid = len(sys.argv) > 6 and sys.argv[6] == "1"
 iters = int(sys.argv[7]) if len(sys.argv) > 7 else 20
+torch.manual_seed(0)
 x = torch.randn(M, CIN, device="cuda"); w = torch.randn(N, TAPS * CIN, device="cuda") / (TAPS * CIN) ** 0.5
 b = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda"); r = torch.randn(M, N, device="cuda") if resid else None
 ops.attach_split(w)
@@ -21,4 +22,4 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 by = 4.0 * (M * CIN + M * N * (2 if resid else 1))
 print(f"{ops.last_conv_kernel():6s} m={M} cin={CIN} n={N} taps={TAPS} dil={DIL} resid={int(resid)}: {ms * 1e3:8.1f} us  "
-      f"{2.0 * M * N * CIN * TAPS / ms / 1e9:7.1f} TFLOP/s  {by / ms / 1e6:7.1f} GB/s")
+      f"{2.0 * M * N * CIN * TAPS / ms / 1e9:7.1f} TFLOP/s  {by / ms / 1e6:7.1f} GB/s  checksum {float(out.double().sum()):.9e}")
