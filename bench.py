@@ -1,6 +1,7 @@
 """Headline benchmark: end-to-end kNN-SVC conversion throughput (xRT) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU;
+                                                            without RANK in the environment it starts its N ranks itself)
 
 One *step* = one cold conversion per rank on synthetic inputs already resident in HBM:
 WavLM-Large (6 layers) encode of a 10-minute target pool shard (20 x 30 s) and a 30 s source,
@@ -22,6 +23,34 @@ import json
 import os
 import sys
 import time
+
+
+def _self_launch_ranks():
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment (the shape of the driver's one-GPU command with another
+    N): start the N ranks ourselves.  This runs before anything is imported that could touch the GPU; the ranks are CHILD processes
+    of `python -m torch.distributed.run` (never an exec of this process), their stdout / stderr are ours, so rank 0's JSON line is
+    relayed as it is, and a failing rank makes this process exit non-zero."""
+    if "RANK" in os.environ or "--gpus" not in " ".join(sys.argv[1:]):
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args()[0].gpus
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:                 # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n} without RANK: launching {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch_ranks()
 
 import numpy as np
 import torch
@@ -412,7 +441,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    assert a.gpus == ws, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    if a.gpus != ws:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={ws} (torch.distributed.run --nproc-per-node must equal --gpus)")
     global STRONG
     STRONG = a.scaling == "strong"
     if STRONG and ws > POOL_CLIPS:

@@ -199,7 +199,8 @@ def _side_stream(device) -> "torch.cuda.Stream":
     idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=idx, priority=torch.cuda.current_stream(idx).priority)
+        from .pipeline import new_stream
+        _SIDE[key] = new_stream(idx, priority=torch.cuda.current_stream(idx).priority, kind="partner")
     return _SIDE[key]
 
 
@@ -224,7 +225,8 @@ def _knn_stream(device) -> "torch.cuda.Stream":
     """The stream the grouped kNN searches of dataset mode run on (ahead of the lanes that consume their results)."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _KNN_STREAMS:
-        _KNN_STREAMS[key] = torch.cuda.Stream(device=device)
+        from .pipeline import new_stream
+        _KNN_STREAMS[key] = new_stream(device, kind="knn")
     return _KNN_STREAMS[key]
 
 

@@ -129,7 +129,8 @@ def capture_graph(fn, device, pool=None):
     idx = torch.cuda.current_device() if idx is None else idx
     side = _CAPTURE_STREAMS.get(idx)
     if side is None:
-        side = _CAPTURE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+        from .pipeline import new_stream
+        side = _CAPTURE_STREAMS[idx] = new_stream(idx, kind="capture")
     cur = torch.cuda.current_stream(idx)
     side.wait_stream(cur)
     g = torch.cuda.CUDAGraph()
@@ -511,18 +512,19 @@ KNN_OVERFLOW = 2                  # flag bit: the fused route's candidate buffer
 
 def knn_fused_on() -> bool:
     import os
-    return os.environ.get("KNNSVC_KNN_FUSED", "1") != "0" and not _FUSED_OFF[0]
+    return os.environ.get("KNNSVC_KNN_FUSED", "1") != "0" and not getattr(_FUSED_OFF, "on", False)
 
 
-_FUSED_OFF = [False]
+import threading as _threading
+_FUSED_OFF = _threading.local()      # per host thread (the request-queue worker's retry must not reroute the main thread's searches)
 
 
 class fused_off:
     """Context: every search inside takes the dot-matrix route (the retry after a candidate-buffer overflow)."""
     def __enter__(self):
-        self.prev = _FUSED_OFF[0]; _FUSED_OFF[0] = True
+        self.prev = getattr(_FUSED_OFF, "on", False); _FUSED_OFF.on = True
     def __exit__(self, *a):
-        _FUSED_OFF[0] = self.prev
+        _FUSED_OFF.on = self.prev
 
 
 def knn_sample_rows(npc: int) -> int:

@@ -45,12 +45,67 @@ def _tensors(obj):
             yield from _tensors(v)
 
 
+# ---- stream census.  HIP maps streams onto hardware queues; the measurements of round 3 (profiles/r03_tail_streams_sweep.txt) fit
+# FOUR queues for high-priority streams: up to four tail streams are fine, a FIFTH shares a queue with a stream it waits for and
+# the pipeline collapses (cfg 5 share 3170 -> 530 xRT).  Every stream the package creates goes through new_stream(), so the number
+# of live high-priority streams is known, and the tail count is a function of it with a hard cap below the cliff.
+MAX_TAILS = 4                      # never more, whatever KNNSVC_TAILS says: the fifth is the cliff
+HIPRI_QUEUES = 4
+_STREAMS = []                      # (weakref to stream, priority, kind)
+
+
+def new_stream(device, priority: int = 0, kind: str = "") -> "torch.cuda.Stream":
+    import weakref
+    s = torch.cuda.Stream(device=device, priority=priority)
+    _STREAMS.append((weakref.ref(s), int(priority), kind))
+    return s
+
+
+def rccl_streams():
+    """(streams, high-priority streams) a live RCCL process group brings: torch's ProcessGroupNCCL runs its collectives on one
+    stream per device taken from the stream pool, high priority only if the group was created with is_high_priority_stream."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+        return 0, 0
+    hi = 0
+    try:
+        pg = dist.distributed_c10d._get_default_group()
+        hi = 1 if pg._get_backend(torch.device("cuda")).options.is_high_priority_stream else 0
+    except Exception:               # private API: unknown -> assume the worse case
+        hi = 1
+    return 1, hi
+
+
+def stream_census(device=None):
+    """Live streams this process created through the package, by priority class, plus RCCL's."""
+    live = [(p, k) for r, p, k in _STREAMS if r() is not None]
+    n_rccl, hi_rccl = rccl_streams()
+    return {"high": sum(1 for p, _k in live if p < 0) + hi_rccl, "normal": sum(1 for p, _k in live if p >= 0) + n_rccl - hi_rccl,
+            "rccl": n_rccl, "tails": sum(1 for p, k in live if k == "tail")}
+
+
+def tail_budget(requested: int, device=None) -> int:
+    """Tail streams a new pipeline may create: the request, capped (a) at MAX_TAILS, (b) at the high-priority queues that are
+    not already taken by high-priority streams OTHER than tails and their partner / branch streams (those follow a tail's
+    work in order and were part of every measurement), (c) at 2 under an RCCL group — its stream is one more live stream next to
+    lanes and tails, and the five-stream cliff has only been measured without it (no multi-GPU node so far): one more of
+    headroom until it has."""
+    c = stream_census(device)
+    n = max(1, min(int(requested), MAX_TAILS))
+    live = [(p, k) for r, p, k in _STREAMS if r() is not None]
+    other_hi = sum(1 for p, k in live if p < 0 and k not in ("tail", "partner", "branch")) + rccl_streams()[1]
+    n = max(1, min(n, HIPRI_QUEUES - other_hi))
+    if c["rccl"] and n > 2:
+        n = 2
+    return n
+
+
 class LanePipeline:
     def __init__(self, device, lanes: int = 1):
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         self.device = torch.device(device)
-        self.lanes = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
+        self.lanes = [new_stream(self.device, kind="lane") for _ in range(lanes)]
         # The tail carries the single-workgroup recurrences: high priority puts it (and its partner stream, see
         # matching._side_stream) on hardware queues of their own — normal-priority streams can collide with each
         # other on a queue (more so once RCCL has created its streams) but never with these — and lets a lone
@@ -72,12 +127,9 @@ class LanePipeline:
         # branch streams inherit the tail's priority, which is why tails + parallel branches collapsed at 3 x 3 streams.  Three
         # leaves one such queue spare for whatever else the process created at that priority; fewer when the caller asks for
         # more than three lanes.
-        n_tails = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
-        if "KNNSVC_TAILS" not in os.environ and n_tails > 2:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-                n_tails = 2            # RCCL brings streams of its own (unmeasured on this side: no multi-GPU node): one more of headroom
-        self.tail_streams = [torch.cuda.Stream(device=self.device, priority=pr) for _ in range(max(1, n_tails))]
+        self.n_tails_requested = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
+        n_tails = tail_budget(self.n_tails_requested, self.device)
+        self.tail_streams = [new_stream(self.device, priority=pr, kind="tail") for _ in range(n_tails)]
         self.tail_stream = self.tail_streams[0]
 
     def run(self, items, head, tail=None):

@@ -43,6 +43,7 @@ class TargetVoice:
         self.ref_path = str(ref_path)
         self.ref_id = os.path.basename(self.ref_path).split(".")[0]
         with torch.inference_mode():
+            vc.wavlm.set_layer_mix(M._mix_of(vc.weighting, vc.wavlm))
             mp, _s, _a, _spec, f0p, hp = M.get_complete_spk_pool(Path(ref_path), vc.wavlm, device=vc.device,
                                                                  duration_limit=duration_limit)
             keys = list(mp)
@@ -61,6 +62,7 @@ class TargetVoice:
         self.ref_path, self.ref_id, self.files = name, name, [f"{name}#{i}" for i in range(len(clips))]
         dev = vc.device
         with torch.inference_mode():
+            vc.wavlm.set_layer_mix(M._mix_of(vc.weighting, vc.wavlm))
             g = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev)
             feats, f0s, harms = [], [], []
             for b in range(0, len(clips), 32):
@@ -104,20 +106,35 @@ class BatchConverter:
             f0 = np.ascontiguousarray(f0, dtype=np.float32)
         return w, f0
 
+    def load_checked(self, src):
+        """_load + the checks that do not need the encoder: a request that fails them fails alone (RequestQueue), before it can
+        take a batch down with it.  -> (wav, f0)."""
+        w, f0 = self._load(src)
+        if w.dim() != 1:
+            raise ValueError(f"request: expected a mono waveform [L], got shape {tuple(w.shape)}")
+        T = M.frames_of(int(w.shape[0]), self.vc.wavlm)
+        if T < 1:
+            raise ValueError(f"request: expected a mono waveform of at least one frame, got shape {tuple(w.shape)}")
+        if not (len(f0) >= T and len(f0) - T <= 1):
+            raise ValueError(f"request: f0 has {len(f0)} frames for a waveform of {T} frames (expected {T} or {T + 1})")
+        return w, f0
+
     @torch.inference_mode()
-    def convert(self, sources) -> list:
-        """-> one waveform tensor [T_i * 320] per source, in order."""
+    def convert(self, sources, loaded=None) -> list:
+        """-> one waveform tensor [T_i * 320] per source, in order.  ``loaded``: the sources already through load_checked."""
         if len(sources) == 0:
             return []
         vc, tg = self.vc, self.target
         dev = vc.device
-        loaded = [self._load(s) for s in sources]
+        vc.wavlm.set_layer_mix(M._mix_of(vc.weighting, vc.wavlm))      # the shared encoder may have been left in another mix
+        loaded = loaded if loaded is not None else [self._load(s) for s in sources]
         wavs = [w for w, _ in loaded]
         feats = vc.wavlm.encode_many(wavs, max_batch=self.max_encode_batch, pow2_batches=True)
         f0s = []
         for (w, f0), ft in zip(loaded, feats):
             T = ft.shape[0]
-            assert abs(len(f0) - T) <= 1 and len(f0) >= T, [len(f0), T]
+            if not (abs(len(f0) - T) <= 1 and len(f0) >= T):
+                raise ValueError(f"f0 has {len(f0)} frames for {T} feature frames")
             f0s.append(f0[:T].contiguous().to(dev) if isinstance(f0, torch.Tensor)
                        else torch.from_numpy(np.ascontiguousarray(f0[:T])).to(dev, non_blocking=True))
         items = list(range(len(sources)))
@@ -171,6 +188,7 @@ class RequestQueue:
         self._q = queue.Queue()
         self._stop = False
         self.batches = []                                    # sizes of the batches run so far (observability / tests)
+        self.isolated = 0                                    # batches that failed as a whole and were re-run request by request
         self._th = threading.Thread(target=self._loop, name="knnsvc-batcher", daemon=True)
         self._th.start()
 
@@ -185,14 +203,16 @@ class RequestQueue:
         dev = self.conv.vc.device
         if dev.type == "cuda" and dev.index is not None:     # a new host thread starts on device 0
             torch.cuda.set_device(dev)
+        import time
         while True:
             first = self._q.get()
             if first is None:
                 return
             batch = [first]
-            try:
+            deadline = time.monotonic() + self.max_wait       # ONE deadline per batch, set by its first request: a trickle of
+            try:                                              # arrivals cannot hold it longer than max_wait_ms
                 while len(batch) < self.max_batch:
-                    nxt = self._q.get(timeout=self.max_wait)
+                    nxt = self._q.get(timeout=max(0.0, deadline - time.monotonic()))
                     if nxt is None:
                         self._q.put(None)                    # finish this batch, then stop
                         break
@@ -200,14 +220,35 @@ class RequestQueue:
             except queue.Empty:
                 pass
             self.batches.append(len(batch))
+            self._run(batch)
+
+    def _run(self, batch):
+        """One batch; a request that cannot be loaded, or whose data makes the conversion fail (a NaN source, an f0 track of the
+        wrong length), fails ALONE: the others of its batch are converted without it."""
+        good, loaded = [], []
+        for s, fut in batch:
             try:
-                ys = self.conv.convert([s for s, _ in batch])
-                for (_s, fut), y in zip(batch, ys):
-                    fut.set_result(y.detach().cpu())
-            except BaseException as e:                       # a failed batch fails its requests, not the server
-                for _s, fut in batch:
-                    if not fut.done():
-                        fut.set_exception(e)
+                loaded.append(self.conv.load_checked(s))
+                good.append((s, fut))
+            except BaseException as e:
+                fut.set_exception(e)
+        if not good:
+            return
+        try:
+            ys = self.conv.convert([s for s, _ in good], loaded=loaded)
+            for (_s, fut), y in zip(good, ys):
+                fut.set_result(y.detach().cpu())
+            return
+        except BaseException as e:
+            if len(good) == 1:
+                good[0][1].set_exception(e)
+                return
+        self.isolated += 1
+        for (s, fut), ld in zip(good, loaded):                # the batch failed as a whole: find the offender(s) one by one
+            try:
+                fut.set_result(self.conv.convert([s], loaded=[ld])[0].detach().cpu())
+            except BaseException as e:
+                fut.set_exception(e)
 
     def close(self):
         self._stop = True

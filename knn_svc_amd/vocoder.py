@@ -28,7 +28,8 @@ def _fold(sd, name):
     return torch._weight_norm(sd[name + ".weight_v"].float(), sd[name + ".weight_g"].float(), 0)
 
 
-_SERIAL = [False]
+import threading as _threading
+_SERIAL = _threading.local()          # per host thread: the request-queue worker must not switch the main thread's generators to serial
 
 
 class serial_resblocks:
@@ -38,9 +39,9 @@ class serial_resblocks:
     per generator made the cfg 5 share 25-35 % SLOWER (12.0 -> 15.7-18.4 ms per source), while the north-star pipeline (one
     lane) gains 7 % from them."""
     def __enter__(self):
-        self.prev = _SERIAL[0]; _SERIAL[0] = True
+        self.prev = getattr(_SERIAL, "on", False); _SERIAL.on = True
     def __exit__(self, *a):
-        _SERIAL[0] = self.prev
+        _SERIAL.on = self.prev
 
 
 class Vocoder:
@@ -101,13 +102,13 @@ class Vocoder:
         self._seen = set()
         self._graph_pool = None if not torch.cuda.is_available() else torch.cuda.graph_pool_handle()
         self._graph_pools = {0: self._graph_pool}
-        self.max_graphs = 48            # (bucket, mode, tail) instances
+        self.max_graphs = 48            # (bucket, mode) instances PER tail stream (Vocoder._evict)
         self.use_graphs = True
         self.parallel_resblocks = os.environ.get("KNNSVC_PAR_RESBLOCKS", "1") != "0"
         self._branch = {}
 
     def _par(self) -> bool:
-        return self.parallel_resblocks and not _SERIAL[0]
+        return self.parallel_resblocks and not getattr(_SERIAL, "on", False)
 
     def _branch_streams(self, dev):
         """Two side streams per (device, current stream) for the ResBlock branches (the generator may run on several streams)."""
@@ -115,7 +116,8 @@ class Vocoder:
         key = (idx, torch.cuda.current_stream(idx).cuda_stream)
         if key not in self._branch:
             pr = torch.cuda.current_stream(idx).priority
-            self._branch[key] = [torch.cuda.Stream(device=idx, priority=pr) for _ in range(2)]
+            from .pipeline import new_stream
+            self._branch[key] = [new_stream(idx, priority=pr, kind="branch") for _ in range(2)]
         return self._branch[key]
 
     # -------------------------------------------------------------------------------------------
@@ -161,18 +163,36 @@ class Vocoder:
             if slot not in self._graph_pools:
                 self._graph_pools[slot] = torch.cuda.graph_pool_handle()
             g, out = ops.capture_graph(lambda: self._forward(sc, sf, sh, n_dyn=nd), self.device, self._graph_pools[slot])
-            ent = self._graphs[key] = (g, sc, sf, sh, nd, out)
-            while len(self._graphs) > self.max_graphs:
-                self._graphs.pop(next(iter(self._graphs)))            # least recently used
+            ent = self._graphs[key] = (g, sc, sf, sh, nd, out, [None])
+            self._evict(slot)
         else:
             self._graphs[key] = self._graphs.pop(key)                 # most recently used
-        g, sc, sf, sh, nd, out = ent
+        g, sc, sf, sh, nd, out, last = ent
         sc[:N].copy_(c); sf[:N].copy_(f0)
         if sh is not None:
             sh[:N].copy_(harm)
         nd.fill_(N)
         g.replay()
-        return out[:N * self.hop].clone()
+        y = out[:N * self.hop].clone()
+        last[0] = torch.cuda.current_stream(c.device).record_event()       # the entry may be destroyed once this has passed
+        return y
+
+    def _evict(self, slot) -> None:
+        """LRU per tail stream (``max_graphs`` instances EACH: the key space is buckets x tails, and the tails replay
+        independently).  An evicted key is forgotten altogether — its next sight is an eager pass again, not an immediate
+        re-capture, so a length distribution wider than the cache degrades to eager passes instead of a capture per call — and
+        only an entry whose last replay has finished is destroyed (its static buffers go back to the tail's pool)."""
+        mine = [k for k in self._graphs if (k[1] if isinstance(k, tuple) and not isinstance(k[1], str) else 0) == slot]
+        extra = len(mine) - self.max_graphs
+        for k in mine:                                                    # insertion order = least recently used first
+            if extra <= 0:
+                break
+            ev = self._graphs[k][6][0]
+            if ev is not None and not ev.query():
+                continue                                                  # still in flight: try the next oldest
+            self._graphs.pop(k)
+            self._seen.discard(k)
+            extra -= 1
 
     def _forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None, n_dyn: torch.Tensor | None = None) -> torch.Tensor:
         """``n_dyn`` (device int32 [1], <= N): the valid frame count of a forward laid out for N = a bucket's frames."""

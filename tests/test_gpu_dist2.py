@@ -158,3 +158,23 @@ def test_sharded_knn_two_ranks_on_one_gpu_equals_unsharded_search():
     port = 38200 + (os.getpid() % 1500)
     r0, r1 = _launch(_knn_worker, 2, (port,))
     assert r0 and r1
+
+
+def test_bench_self_launches_its_ranks_rehearsal():
+    """`python bench.py --gpus 2` with no RANK in the environment — the shape of the driver's own command — starts its two ranks
+    itself (child processes of torch.distributed.run, before anything touches the GPU) and relays rank 0's JSON line.  Rehearsal
+    mode: both ranks on cuda:0 under gloo (KNNSVC_BENCH_REHEARSE=1), so the N > 1 code path runs end to end on a one-GPU box."""
+    import json
+    import subprocess
+    _clean_parent()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KNNSVC_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for mode in ("weak", "strong"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scaling", mode,
+                            "--no-cpu-baseline", "--no-other-configs"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (mode, r.stderr[-3000:])
+        assert "launching 2 ranks" in r.stderr
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["scaling"] == mode and line["value"] > 0, line

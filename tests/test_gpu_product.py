@@ -101,6 +101,46 @@ def test_request_queue_batches_and_returns_each_request_its_own_waveform(tmp_pat
         rq.submit(reqs[0])
 
 
+def test_request_queue_a_bad_request_fails_alone_and_one_deadline_per_batch(tmp_path):
+    """(a) a malformed request (an f0 track of the wrong length) and a poisonous one (NaN samples: the batch's kNN
+    search raises "containing nan") fail ONLY their own Futures — the other requests of the same batch are converted and equal
+    their stand-alone conversions; (b) the batching window is one deadline per batch, set by its first request: a trickle of
+    arrivals spaced closer than max_wait cannot hold the first request for max_batch x max_wait."""
+    import time
+    from knn_svc_amd import ops, serving
+    vc = _tiny_vc()
+    pool = tmp_path / "tgt"
+    _write_pool(pool)
+    tv = serving.TargetVoice(vc, str(pool))
+    conv = serving.BatchConverter(vc, tv, "mix", "post_opt_0.2")
+    reqs = []
+    for i in range(4):
+        w, f = S.synth_clip(16000 + 1500 * i + 11, seed=840 + i)
+        reqs.append((w, (f * 1.1).astype(np.float32)))
+    alone = [conv.convert([r])[0].cpu() for r in reqs]
+    bad_f0 = (reqs[1][0], reqs[1][1][:-7])
+    nan_w = reqs[2][0].copy(); nan_w[5000:5100] = np.nan
+    rq = serving.RequestQueue(conv, max_batch=8, max_wait_ms=400.0)
+    futs = [rq.submit(r) for r in (reqs[0], bad_f0, (nan_w, reqs[2][1]), reqs[3])]
+    with pytest.raises(ValueError):
+        futs[1].result(timeout=60)
+    with pytest.raises(ops.KnnSvcError):
+        futs[2].result(timeout=60)
+    assert torch.equal(futs[0].result(timeout=60), alone[0]) and torch.equal(futs[3].result(timeout=60), alone[3])
+    assert rq.batches == [4] and rq.isolated == 1, (rq.batches, rq.isolated)
+    rq.close()
+    # (b) five requests 120 ms apart with max_wait 300 ms: the first batch closes 300 ms after ITS first request
+    rq = serving.RequestQueue(conv, max_batch=8, max_wait_ms=300.0)
+    t0 = time.monotonic()
+    futs = []
+    for i in range(5):
+        futs.append(rq.submit(reqs[i % 4]))
+        time.sleep(0.12)
+    [f.result(timeout=60) for f in futs]
+    rq.close()
+    assert len(rq.batches) >= 2 and rq.batches[0] <= 4, rq.batches          # per-arrival timers would have made it one batch of 5
+
+
 def test_cfg5_share_through_the_product_entry_equals_per_item_path():
     """BASELINE cfg 5, one GPU's share at full size: 32 x 30 s sources against a resident 60-minute pool (180 000 frames),
     WavLM-Large (6 layers) + the full generator with seeded weights, mix, post_opt_0.2, through serving.BatchConverter (grouped
