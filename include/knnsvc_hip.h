@@ -257,26 +257,41 @@ int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const 
                       int64_t mask_lo, int64_t mask_hi,
                       int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
 
-/* Fused route (no [nq, np] dot matrix in HBM; lib_ongaku_test.py:148-175 + ddsp_prematch_dataset.py:1195-1210 at BASELINE cfg 5
- * sizes).  knnsvc_knn_screen: q.p^T on the f16x2 matrix-core path (both operands pre-split by knnsvc_split_f16x2_dyn with the
- * range slots q_absmax / p_absmax), every product screened in registers: first conservatively against thr[row], then — the few
- * survivors — exactly: the reference's distance of the pair as a (distance, pool index) key against (thr[row], thr_idx[row]),
- * the row's k-th best key over ANY subset of this pool (e.g. a strided sample searched with knnsvc_conv_gemm + knnsvc_knn_select:
- * thr = its k-th distance, thr_idx = that row's index IN THIS POOL).  Exactly the pairs with key <= that key are appended to
- * cand[row][0 .. cap) as (pool index, dot) (8 bytes each); cand_count[row] counts them (caller zeroes cand_count and
- * overflow_flag).  overflow_flag != 0 afterwards: some row had more than cap such pairs — the caller must fall back to the
- * dot-matrix route.  knnsvc_knn_refine: the reference's distance formula on the candidates, ascending top-k with
- * knnsvc_knn_select's keys, NaN flag, mask and idx_offset semantics: identical results to evaluating every pair.
+/* Fused route (no [nq, np] dot matrix in HBM; lib_ongaku_test.py:148-175 + ddsp_prematch_dataset.py:1195-1210: the reference's
+ * 20-row cdist + topk loop over the whole pool).  The caller walks the pool's rows in EPOCHS [p_base, p_base + np) of growing
+ * size (knn_svc_amd/ops.py: knn_epochs); each epoch is one knnsvc_knn_screen + one knnsvc_knn_refine.
+ * knnsvc_knn_screen: q.p^T on the f16x2 matrix-core path (both operands pre-split by knnsvc_split_f16x2_dyn with the range
+ * slots q_absmax / p_absmax; p_f16x2 / p_norm / p_sq point at the epoch's first row), every product screened in registers: first
+ * conservatively against the row's threshold, then — the few survivors — exactly: the reference's distance of the pair as a
+ * (distance, pool index) key.
+ *   thr == thr_idx == NULL (the first epoch): every 256 x 256 tile bounds its rows itself — at least 32 of its columns lie at
+ *     or below the bound it derives, so no row's top-k (k <= 32) can lie beyond it;
+ *   otherwise (thr[row], thr_idx[row]) = the row's k-th best key over the rows searched so far (knnsvc_knn_refine's thr_out /
+ *     thr_idx_out; the index in the chunk's index space, i.e. without idx_offset): exactly the pairs with key <= it pass.
+ * Survivors are appended to cand[row][0 .. cap) as (pool index = p_base + row in epoch, order-preserving bits of the distance;
+ * 0xFFFFFFFF = NaN), 8 bytes each; cand_count[row] counts them (the caller zeroes cand_count and the flag once; refine
+ * resets the counts).  Bit 1 of *overflow_flag set afterwards: some row had more than cap survivors — the caller must fall
+ * back to the dot-matrix route (the same word and bit as knnsvc_knn_refine's `flags`: one flag per search).  mask_lo / mask_hi: chunk rows [lo, hi) compete at distance exactly 1.
+ * cold_ws (first epoch only, else NULL; nq * (1 + 2 * ceil(np / 256)) + 32 * ceil(nq / 256) words the caller zeroes): [nq] the best
+ * bound found for each row — knnsvc_knn_refine's row_bound: it starts from it and drops the survivors of weaker tiles unseen —,
+ * then the per-half-tile bounds and arrival counters through which the tiles of a row tile, running side by side, tighten each
+ * other's bounds (a bounded wait; only tightness depends on it, never the result).
+ * knnsvc_knn_refine: prev_idx / prev_dist (NULL in the first epoch: the previous refine's out_idx / out_dist, [nq, k]) + the
+ * candidates -> ascending top-k with knnsvc_knn_select's keys and idx_offset semantics — after the last epoch identical to
+ * evaluating every pair.  flags: bit 0 = a NaN distance was met, bit 1 (final_pass only) = a row ended with fewer than k
+ * entries although no NaN was seen (the caller repeats the search on the dot-matrix route).  thr_out / thr_idx_out (NULL after
+ * the last epoch): the next epoch's thresholds.
  * nq * dim and np * dim below 2^28 per call (chunk larger searches).
- * max_blocks: the kernel is persistent (a block walks tiles); 0 = one block per CU, otherwise at most this many blocks
+ * max_blocks: the screen kernel is persistent (a block walks tiles); 0 = one block per CU, otherwise at most this many blocks
  * (rounded down to a multiple of 8), so that a search inside a stream pipeline leaves CUs to the other streams' kernels. */
 int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
                       const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
-                      int32_t dim, const float* thr, const int64_t* thr_idx, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count,
-                      void* cand, int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream);
-int knnsvc_knn_refine(const int32_t* cand_count, const void* cand, int32_t cap, const float* q_norm, const float* q_sq,
-                      int64_t nq, const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
-                      int64_t mask_lo, int64_t mask_hi, int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
+                      int32_t dim, const float* thr, const int64_t* thr_idx, int64_t mask_lo, int64_t mask_hi, int64_t p_base,
+                      int32_t* cand_count, void* cand, int32_t cap, uint32_t* cold_ws, int32_t* overflow_flag, int32_t max_blocks,
+                      void* stream);
+int knnsvc_knn_refine(int32_t* cand_count, const void* cand, int32_t cap, int64_t nq, int32_t k, int64_t idx_offset,
+                      const uint32_t* row_bound, const int64_t* prev_idx, const float* prev_dist, int64_t* out_idx, float* out_dist, float* thr_out,
+                      int64_t* thr_idx_out, int32_t final_pass, int32_t* flags, void* stream);
 
 /* Merge `parts` per-shard top-k lists ([parts][nq][k], e.g. after an RCCL all-gather) into one. */
 int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx, int32_t parts, int64_t nq,

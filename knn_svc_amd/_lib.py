@@ -77,8 +77,8 @@ SIGNATURES = {
     "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, i64, i64, vp, vp, vp, sz, vp, vp]),
     "knnsvc_knn_select": (i32, [vp, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i64, vp, vp, vp, vp]),
     "knnsvc_knn_merge": (i32, [vp, vp, i32, i64, i32, vp, vp, vp]),
-    "knnsvc_knn_screen": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, i64, i64, vp, vp, i32, vp, i32, vp]),
-    "knnsvc_knn_refine": (i32, [vp, vp, i32, vp, vp, i64, vp, vp, i64, i32, i64, i64, i64, vp, vp, vp, vp]),
+    "knnsvc_knn_screen": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, i64, i64, i64, vp, vp, i32, vp, vp, i32, vp]),
+    "knnsvc_knn_refine": (i32, [vp, vp, i32, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "knnsvc_log_f0_median": (i32, [vp, i64, vp, vp, vp]),
     "knnsvc_shift_f0": (i32, [vp, i64, vp, vp, vp, vp]),
     "knnsvc_f0_rerank": (i32, [vp, i64, i32, vp, vp, vp, vp]),

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
             best = wave_sort64(v, lane);
         }
         if (lane < k) {
-            out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull) + idx_offset;
+            out_idx[row * k + lane] = (best == KEY_INF ? 0l : (long)(unsigned)(best & 0xFFFFFFFFull)) + idx_offset;      // unfilled (NaN row): a valid row, NaN distance
             out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
         }
     }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const unsigned long
         best = wave_sort64(v, lane);
     }
     if (lane < k) {
-        out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull) + idx_offset;
+        out_idx[row * k + lane] = (best == KEY_INF ? 0l : (long)(unsigned)(best & 0xFFFFFFFFull)) + idx_offset;      // unfilled (NaN row): a valid row, NaN distance
         out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
     }
 }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void knn_merge_pairs_kernel(const float* __res
         best = wave_sort64(v, lane);
     }
     if (lane < k) {
-        out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull);
+        out_idx[row * k + lane] = best == KEY_INF ? 0l : (long)(unsigned)(best & 0xFFFFFFFFull);
         out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
     }
 }
@@ -358,7 +358,18 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
     if (row >= rows) return;
     const float* xr = x + row * (long)ldx;
     double s = 0.0;
-    for (int c = lane; c < dim; c += 64) { const double v = xr[c]; s += v * v; }
+    if ((dim & 3) == 0 && (ldx & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+        // 16-byte loads, four independent fp64 chains per lane (the scalar walk was one dependent chain of 4-byte loads: 3.6 TB/s)
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int c = lane * 4; c < dim; c += 256) {
+            const f32x4 v = *(const f32x4*)(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] = fma((double)v[e], (double)v[e], s4[e]);
+        }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    } else {
+        for (int c = lane; c < dim; c += 64) { const double v = xr[c]; s += v * v; }
+    }
     s = wave_sum_d(s);
     if (lane == 0) {
         const float nr = (float)sqrt(s);
@@ -374,17 +385,23 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
 }
 
 // -------------------------------------------------------------------------------------------------
-// Fused route for LARGE query sets (BASELINE cfg 5: 24 000+ query frames per search): no [Nq, Np] dot matrix.
-//   pass 1 (host, existing kernels): exact top-k against a SAMPLE of the pool -> thr[row] = a distance the row's k-th best
-//           cannot exceed;
-//   pass 2 (knn_screen_kernel): q.p^T on the 256x256 / 128x128-wave-tile f16x2 main loop (Gemm2QuadR, the fastest loop of
-//           the library at K = 1024: no output to store here), each accumulator element screened IN REGISTERS against its
-//           row's thr with the same conservative margin as knn_select_kernel; the few survivors (pool index, dot) are
-//           compacted per row into a candidate buffer — LDS-staged per tile, one global atomic per (tile, row);
-//   pass 3 (knn_refine_kernel): the reference's distance formula on the candidates only, top-k with the same keys.
-// The candidate set is a superset of the true top-k (thr is an exact k-th distance over a subset; the margin covers the
-// screen's rounding), so the result is identical to evaluating the formula on every pair.  Traffic: 8 B per survivor
-// (~0.4 % of the pairs at a 1/22 sample) instead of 8 B per pair.
+// Fused route (default from 256 query frames on: the north-star point, dataset mode, serving, cfg 5): no [Nq, Np] dot matrix.
+// The pool's columns are walked in EPOCHS of growing size; every epoch is one persistent launch of knn_screen_kernel (q.p^T on
+// the Gemm2QuadS main loop, each accumulator element screened IN REGISTERS against its row's threshold, the reference's distance
+// formula evaluated on the few survivors, (pool index, distance bits) compacted per row into a candidate buffer) followed by
+// knn_refine_kernel (the row's top-k so far + the new candidates -> top-k, and the k-th KEY as the next epoch's threshold).
+//   epoch 0 (COLD = true): no threshold exists yet, so each tile bounds its rows itself.  Per row and column half (one wave: 16
+//           lanes x 8 columns) the 16th largest of the 32 maxima over groups of 4 columns of dot / |p| is bracketed by bisection:
+//           at least 16 + 16 distinct columns of the tile lie at or above the smaller of the two halves' bounds, so the row's true
+//           top-k cannot lie beyond it (plus the screen's rounding margin).  About 40 of a tile's 256 columns pass per row;
+//   epoch e > 0: the threshold is the exact k-th (distance, index) KEY over everything seen so far: exactly {key <= key_k}
+//           passes — its size is the rank of that key among the new columns (about k x new / seen), however many
+//           near-identical rows the pool holds.
+// Round 3 took its threshold from a separate pass over a strided sample of the pool (a GEMM + a selection: 0.15 ms whatever the
+// size, 1 ms at 24 000 x 180 000) and lost to the dot-matrix route below 2048 query frames; here the first epoch IS part of the
+// search.  The candidate set of every epoch is a superset of the true top-k among its columns, and the distances are computed by
+// ref_distance from the very dot-product bits of the dot-matrix route, so the result is identical to it — indices and distance
+// bits (tests: fused == dot matrix, sharded == unsharded, grouped == ungrouped).
 // -------------------------------------------------------------------------------------------------
 typedef unsigned kn_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t knn_rsrc(const void* p, int bytes) {
@@ -411,14 +428,49 @@ using QG = Gemm2QuadS;
 constexpr int SCR_LIST = 3072;                       // entries of the tile list in LDS (flushed to the rows' global slots when full)
 constexpr int SCR_QD = 40;                           // entries of a lane's queue (drained before a column's 32 elements could overflow it)
 
-// Persistent: block b walks tiles b, b + gridDim.x, ... (gridDim.x a multiple of 8: a tile keeps its XCD).  The host caps the
-// grid (`max_blocks`): inside a stream pipeline the search then leaves CUs to the single-workgroup recurrences and the generator
-// of the other items instead of occupying every CU with a 128 KB-LDS block (VERDICT r2 #5b).
+// Persistent: block b walks tiles b, b + gridDim.x, ... in the XCD-aware order of gemm2_core.h (for grids that order pads —
+// quad_order_ids a multiple of 8 — and gridDim.x a multiple of 8, a block's tiles stay on its XCD; small grids use the plain order
+// and make no such promise).  The host caps the grid (`max_blocks`): inside a stream pipeline the search then leaves CUs to the
+// single-workgroup recurrences and the generator of the other items instead of occupying every CU with a 128 KB-LDS block.
+// p2 / pn / psq point at the epoch's first pool row, np = its rows, p_base = that row's index in the chunk (candidate indices, the
+// mask range and thr_idx live in the chunk's index space).
+__device__ __forceinline__ float knn_row_fold_min(float v) {       // all 16 lanes of a DPP row get the row's minimum
+#define KN_F(CTRL) v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)));
+    KN_F(0xB1) KN_F(0x4E) KN_F(0x141) KN_F(0x140)
+#undef KN_F
+    return v;
+}
+__device__ __forceinline__ float knn_row_fold_max(float v) {
+#define KN_F(CTRL) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)));
+    KN_F(0xB1) KN_F(0x4E) KN_F(0x141) KN_F(0x140)
+#undef KN_F
+    return v;
+}
+__device__ __forceinline__ int knn_row_fold_add(int v) {
+#define KN_F(CTRL) v += __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+    KN_F(0xB1) KN_F(0x4E) KN_F(0x141) KN_F(0x140)
+#undef KN_F
+    return v;
+}
+#ifdef KN_KNN_PROF        // timing aid (tools/knn_prof.py): per block and tile, 10 ns ticks: start / main loop done / cold bound done / coarse pass
+__device__ long long kn_knn_prof_buf[4096 * 8];        // + drains done / tile done, survivors pushed by thread 0's wave, drains
+#define KN_KP(SLOT, VAL) { if (threadIdx.x == 0 && kp_tile < 4096) kn_knn_prof_buf[kp_tile * 8 + (SLOT)] = (long long)(VAL); }
+#define KN_KP_T(SLOT) KN_KP(SLOT, __builtin_amdgcn_s_memrealtime())
+#else
+#define KN_KP(SLOT, VAL)
+#define KN_KP_T(SLOT)
+#endif
+constexpr int XCH_MAX = 88;                          // half-tile bounds a row reads in the first epoch's exchange (2 x 44 column tiles)
+constexpr int COLD_STEPS_XCH = 2;                    // ... when the tiles also exchange bounds (the tile's own bound is the backstop then)
+constexpr int COLD_STEPS = 5;                        // bisection steps of the cold bound (each halves the bracket of the 16th largest)
+
+template <bool COLD, bool XCH>
 __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     const float* __restrict__ q2, const float* __restrict__ q_absmax, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
     const unsigned short* __restrict__ p2, const float* __restrict__ p_absmax, const float* __restrict__ pn, const float* __restrict__ psq,
-    long np, int dim, const float* __restrict__ thr, const long* __restrict__ thr_idx, long mask_lo, long mask_hi,
-    int* __restrict__ cand_count, unsigned* __restrict__ cand, int cap, int* __restrict__ overflow, int ntiles) {
+    long np, int dim, const float* __restrict__ thr, const long* __restrict__ thr_idx, long mask_lo, long mask_hi, long p_base,
+    int* __restrict__ cand_count, unsigned* __restrict__ cand, int cap, unsigned* __restrict__ cold_ws, int* __restrict__ overflow,
+    int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int gx = (int)((nq + 255) / 256), gy = (int)((np + 255) / 256);
     const float out_scale = 1.0f / (knn_pick_scale(q_absmax) * knn_pick_scale(p_absmax));
@@ -426,6 +478,11 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     int mt, nt;
     if (!quad_order_decode(vt, gx, gy, mt, nt)) continue;          // XCD-aware order, padding ids (gemm2_core.h)
     const int m0 = mt * 256, n0 = nt * 256;
+#ifdef KN_KNN_PROF
+    const int kp_tile = vt;
+    int kp_drains = 0, kp_pushed = 0;
+#endif
+    KN_KP_T(0)
 
     typename QG::acc_t acc[QG::TM][QG::TN];
 #pragma unroll
@@ -440,6 +497,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     QG::mainloop(lds, dim / 32, row_off, step, knn_rsrc(q2, (int)(nq * row_bytes)), knn_rsrc(p2, (int)(np * (long)(dim / 32) * 128)),
                  (int)np, dim, m0, n0, acc);
     __syncthreads();                                   // the operand stages are free: row data, counters and the survivor list
+    KN_KP_T(1)
 
     // ---- screening epilogue.  Round 2's form tested every accumulator element under a branch that held two LDS atomics: with
     // ~1 survivor per (row, tile) some lane of a wave took the slow path at ~40 % of its 256 elements — 40-80 us per tile next to a
@@ -460,15 +518,16 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     float* s_a2 = s_a1 + 256;                          // [256] eps' |q|^2 / out_scale
     float* s_qn = s_a2 + 256;                          // [256] |q|, |q|^2: the exact formula's row operands
     float* s_qsq = s_qn + 256;
-    unsigned* s_khi = (unsigned*)(s_qsq + 256);        // [256] key32: distance bits, pool index
+    unsigned* s_khi = (unsigned*)(s_qsq + 256);        // [256] the row's threshold KEY: distance bits, pool index
     unsigned* s_klo = s_khi + 256;
     float* s_pn = (float*)(s_klo + 256);               // [256] |p|, |p|^2 of the tile's pool rows: the exact formula's column operands
     float* s_psq = s_pn + 256;
     int* s_cnt = (int*)(s_psq + 256);                  // [256] entries per row in the current list
     int* s_base = s_cnt + 256;                         // [256] their first slot in the row's global candidate list
     int* s_n = s_base + 256;                           // [1] entries in the tile list
-    unsigned* s_list = (unsigned*)(s_n + 4);           // [SCR_LIST][3]: row << 16 | position in row, pool index, dot bits
+    unsigned* s_list = (unsigned*)(s_n + 4);           // [SCR_LIST][3]: row << 16 | position in row, pool index, distance bits
     unsigned* s_queue = s_list + SCR_LIST * 3;         // [SCR_QD][256][2]: lane queues: row << 8 | column, dot bits
+    float* s_T = (float*)s_queue;                      // COLD: [2][256] per column half, [8] |p| range (the queues are still empty)
     // (laundered: derived from a plain threadIdx.x, the epilogue's per-lane rows / columns / LDS addresses are loop-invariant,
     //  get hoisted out of the tile loop and then live — and spill — across the main loop, which has no register to spare)
     int tid = threadIdx.x;
@@ -476,25 +535,176 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     const int lane = tid & 63, wave = tid >> 6;
     constexpr float EPS = 4.5e-6f;
     const float inv_os = 1.0f / out_scale;             // powers of two: exact
+    const bool masked = mask_lo < mask_hi;
+    const long pc0 = p_base + n0;                      // chunk index of the tile's first pool row
+    // `t` = a distance the row's k-th best cannot exceed -> the coarse test's row constants and the exact test's key
+    auto set_row = [&](float t, unsigned klo_v) __attribute__((always_inline)) {
+        const long r = (long)m0 + tid;
+        const bool v = r < nq;
+        const float n_ = s_qn[tid], sq_ = s_qsq[tid];
+        s_a1[tid] = v ? n_ * ((1.0f - t) - EPS) * inv_os : 3.0e38f;        // rows past nq: nothing survives
+        s_a2[tid] = v ? EPS * sq_ * inv_os : 0.f;
+        // a NaN / +inf threshold (a NaN query row, a tile that cannot bound the row) keeps every pair: the refine pass sees them all
+        const bool open = !(t < __builtin_inff());
+        s_khi[tid] = open ? 0xFFFFFFFFu : sortable(t);
+        s_klo[tid] = open ? 0xFFFFFFFFu : klo_v;
+    };
     {
         const long r = (long)m0 + tid;
         const bool v = r < nq;
-        const float t = v ? thr[r] : 0.f, n_ = v ? qn[r] : 0.f, sq_ = v ? qsq[r] : 0.f;
-        s_a1[tid] = v ? n_ * ((1.0f - t) - EPS) * inv_os : 3.0e38f;        // rows past nq: nothing survives
-        s_a2[tid] = v ? EPS * sq_ * inv_os : 0.f;
-        s_qn[tid] = n_; s_qsq[tid] = sq_;
-        // a NaN / +inf threshold (a NaN query row) keeps every pair: the refine pass then reports it
-        const bool open = !(t < __builtin_inff());
-        s_khi[tid] = open ? 0xFFFFFFFFu : sortable(t);
-        s_klo[tid] = open ? 0xFFFFFFFFu : (unsigned)(v ? thr_idx[r] : 0);
+        s_qn[tid] = v ? qn[r] : 0.f; s_qsq[tid] = v ? qsq[r] : 0.f;
         s_cnt[tid] = 0;
         if (tid == 0) s_n[0] = 0;
         const long pc = (long)n0 + tid;
         s_pn[tid] = pc < np ? pn[pc] : 0.f;
         s_psq[tid] = pc < np ? psq[pc] : 0.f;
+        if (!COLD) set_row(v ? thr[r] : 0.f, (unsigned)(v ? thr_idx[r] : 0));
     }
     __syncthreads();
-    const bool masked = mask_lo < mask_hi;
+    if (COLD) {
+        // ---- no threshold yet: the tile bounds its rows itself.  sim = acc / |p| orders a row's columns by approximate cosine
+        // (|q| and the operand scales are row constants).  Each lane takes the maxima of its two groups of 4 columns per row; a
+        // row's 16 lanes of THIS wave then bracket the 16th largest of their 32 group maxima by bisection (DPP row folds, no LDS):
+        // lo always has >= 16 group maxima — 16 distinct columns — at or above it.  Both column halves together: 32 distinct
+        // columns with sim >= min(lo_0, lo_1), so the row's k-th best (k <= 32) approximate distance is at most
+        // t = 1 - that / |q|, its exact one at most t + g (g: knn_select_kernel's margin between the formula and the approximation,
+        // bounded over the tile's |p| range; doubled for this form's own roundings).  Masked columns and columns past np are
+        // no witnesses (sim = -inf); they are still pushed by the coarse pass below when they have to be.
+        float rp[QG::TN], bias[QG::TN];
+        float pmin = __builtin_inff(), pmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < QG::TN; ++j) {
+            const int col = QG::acc_col(wave, lane, j);
+            const long p = pc0 + col;
+            const float v_pn = s_pn[col];
+            const bool ok = (long)n0 + col < np && v_pn > 0.f && !(masked && p >= mask_lo && p < mask_hi);
+            rp[j] = ok ? __builtin_amdgcn_rcpf(v_pn) : 0.f;
+            bias[j] = ok ? 0.f : -__builtin_inff();
+            if (ok) { pmin = fminf(pmin, v_pn); pmax = fmaxf(pmax, v_pn); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pmin = fminf(pmin, __shfl_xor(pmin, o, 64)); pmax = fmaxf(pmax, __shfl_xor(pmax, o, 64)); }
+        if (lane == 0) { s_T[512 + wave * 2] = pmin; s_T[512 + wave * 2 + 1] = pmax; }
+#pragma unroll
+        for (int i = 0; i < QG::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < QG::NR; ++r) {
+                float ga = -__builtin_inff(), gb = -__builtin_inff();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ga = fmaxf(ga, fmaf(acc[i][j][r], rp[j], bias[j]));
+                    gb = fmaxf(gb, fmaf(acc[i][j + 4][r], rp[j + 4], bias[j + 4]));
+                }
+                // bracket of the 16th largest T* of the row's 32 group maxima: u = the smallest of the 16 lane maxima (16 values at or
+                // above it), v = the largest of the lanes' SMALLER group maxima — only lane maxima lie above v, so either fewer than 16
+                // values do (T* <= v) or all 16 lane maxima do (T* = u): T* in [u, max(u, v)].  Both ends sit inside the bulk of the
+                // row's values; the row maximum (an outlier whenever the tile holds a true neighbour) would stretch the bracket
+                // over the whole range and leave the bisection's resolution coarser than the bulk is wide (everything passes)
+                float lo = knn_row_fold_min(fmaxf(ga, gb));
+                float hi = fmaxf(lo, knn_row_fold_max(fminf(ga, gb)));
+#pragma unroll
+                for (int it = 0; it < (XCH ? COLD_STEPS_XCH : COLD_STEPS); ++it) {
+                    const float mid = 0.5f * lo + 0.5f * hi;
+                    const int c = knn_row_fold_add((ga >= mid ? 1 : 0) + (gb >= mid ? 1 : 0));
+                    if (c >= 16) lo = mid; else hi = mid;
+                }
+                const float hb = knn_row_fold_max(fmaxf(ga, gb));                 // this half's best column of the row
+                if ((lane & 15) == 0) {
+                    const int row = QG::acc_row(wave, lane, i, r);
+                    s_T[(wave & 1) * 256 + row] = lo;
+                    s_T[520 + (wave & 1) * 256 + row] = hb;
+                }
+            }
+        __syncthreads();
+        KN_KP_T(7)
+        {
+            const float T = fminf(s_T[tid], s_T[256 + tid]);                       // (-inf: a half without 16 witnesses)
+            const float lo_p = fminf(fminf(s_T[512], s_T[514]), fminf(s_T[516], s_T[518]));
+            const float hi_p = fmaxf(fmaxf(s_T[513], s_T[515]), fmaxf(s_T[517], s_T[519]));
+            const float n_ = s_qn[tid];
+            // approximate distance of the weakest witness, then the margin  3.8e-6 (1 + |q|/|p| + |p|/|q|)  at its largest, twice
+            const float t = 1.0f - T * out_scale / n_;
+            const float g = 7.6e-6f * (1.0f + n_ / lo_p + hi_p / n_);
+            const float te = t + g;
+            const bool fin = n_ > 0.f && T > -__builtin_inff() && te < __builtin_inff();
+            float tb = fin ? te : __builtin_inff();
+            // ---- exchange between the tiles of this row tile (they run side by side in the first epoch).  One tile's 256 columns
+            // cannot bound a row below their own 32nd best — the 12 % quantile of the pool; the tiles TOGETHER can: every column
+            // half publishes the bound of its single best column per row, and once 32 such bounds of distinct columns are in, the
+            // 32nd smallest of them bounds the row's k-th best over the whole epoch (the 0.5 % quantile for neighbours spread over
+            // the pool; neighbours packed into one tile are what the tile's own bound handles).  Only tightness depends on who
+            // has published when: a word that is still zero reads as "no bound".  The wait for the other tiles is bounded (8 us).
+            if (cold_ws && XCH) {
+                unsigned* best = cold_ws + nq;                                     // [2 gy][nq], zero-filled by the caller
+                unsigned* arrived = cold_ws + nq * (long)(1 + 2 * gy) + (long)mt * 32;     // [gx] counters, one cache line each
+                const long r = (long)m0 + tid;
+                if (r < nq && n_ > 0.f) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float B = s_T[520 + h * 256 + tid];
+                        const float b = (1.0f - B * out_scale / n_) + g;
+                        if (B > -__builtin_inff() && b < __builtin_inff())
+                            __hip_atomic_store(&best[(long)(2 * nt + h) * nq + r], ~sortable(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                // (the bounds went out as device-scope stores; this waits for their acknowledgement — no L2 write-back as a device-scope
+                //  fence would do: a reader that sees the counter before a bound only gets a weaker bound)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                if (tid == 0) {
+                    atomicAdd(arrived, 1u);
+                    const long long t_end = (long long)__builtin_amdgcn_s_memrealtime() + 800;        // 100 MHz ticks
+                    while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)gy &&
+                           (long long)__builtin_amdgcn_s_memrealtime() < t_end)
+                        __builtin_amdgcn_s_sleep(24);
+                }
+                __syncthreads();
+                KN_KP_T(5)
+                if (r < nq && n_ > 0.f) {
+                    float v[XCH_MAX];
+                    unsigned w[XCH_MAX];
+                    int n_pub = 0;
+                    float vmin = __builtin_inff(), vmax = -__builtin_inff();
+                    // (plain loads through this XCD's L2: the words were stored through to memory, and nothing of this launch has read
+                    //  their lines on this XCD earlier than the tiles that wait here together — a stale zero would only mean a weaker
+                    //  bound.  All of them in flight at once, planes past 2 gy re-read plane 0: behind a branch each, the compiler
+                    //  waited for every load before issuing the next — 24 us.)
+#pragma unroll
+                    for (int x = 0; x < XCH_MAX; ++x) w[x] = best[(long)(x < 2 * gy ? x : 0) * nq + r];
+#pragma unroll
+                    for (int x = 0; x < XCH_MAX; ++x) {
+                        const bool pub = w[x] != 0u && x < 2 * gy;
+                        v[x] = pub ? unsortable(~w[x]) : __builtin_inff();
+                        if (pub) { ++n_pub; vmin = fminf(vmin, v[x]); vmax = fmaxf(vmax, v[x]); }
+                    }
+#ifdef KN_KNN_PROF_LOADS
+                    KN_KP_T(6)
+#endif
+                    if (n_pub >= 32) {              // 32nd smallest, from above: `hi` always has >= 32 published bounds at or below it
+                        float lo = vmin, hi = vmax;
+#pragma unroll 1
+                        for (int it = 0; it < 10; ++it) {
+                            const float mid = 0.5f * lo + 0.5f * hi;
+                            int c = 0;
+#pragma unroll
+                            for (int x = 0; x < XCH_MAX; ++x) c += v[x] <= mid ? 1 : 0;
+                            if (c >= 32) hi = mid; else lo = mid;
+                        }
+                        tb = fminf(tb, hi);
+                    }
+                }
+            }
+#ifndef KN_KNN_PROF_LOADS
+            KN_KP_T(6)
+#endif
+            set_row(tb, 0xFFFFFFFFu);
+            // the best bound found for the row (stored inverted: atomicMax over a zero-filled word): the refine pass starts from it
+            // and drops the survivors of tiles that had to work with weaker bounds unseen
+            if (tb < __builtin_inff() && cold_ws && (long)m0 + tid < nq) atomicMax(&cold_ws[m0 + tid], ~sortable(tb));
+        }
+        __syncthreads();
+    }
+    KN_KP_T(2)
     float ra1[QG::TM][QG::NR], ra2[QG::TM][QG::NR];
 #pragma unroll
     for (int i = 0; i < QG::TM; ++i)
@@ -509,24 +719,49 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
     auto drain_and_flush = [&]() __attribute__((always_inline)) {
         int e = 0;
         for (;;) {
-            for (; e < qcnt; ++e) {
-                const unsigned* qe = s_queue + ((e * 256 + tid) << 1);
-                const unsigned code = qe[0];
-                const int row = (int)(code >> 8), col = (int)(code & 255u);
-                // the EXACT test (2): the distance the refine pass would compute for this pair, as a key against key32[row]
-                const float dot = __uint_as_float(qe[1]);
-                const long p = (long)n0 + col;
-                float d = ref_distance(dot, s_qsq[row], s_psq[col], s_qn[row], s_pn[col]);
-                const bool isnan = d != d;
-                if (masked && p >= mask_lo && p < mask_hi) d = 1.f;      // a masked pool row competes at exactly 1
-                const unsigned hi = sortable(d), khi = s_khi[row];
-                if (!(isnan || hi < khi || (hi == khi && (unsigned)p <= s_klo[row]))) continue;
-                const int pos = atomicAdd(&s_n[0], 1);
-                if (pos >= SCR_LIST) break;                          // list full: this entry and the rest after the flush
-                const int lp = atomicAdd(&s_cnt[row], 1);
-                s_list[pos * 3] = ((unsigned)row << 16) | (unsigned)lp;
-                s_list[pos * 3 + 1] = (unsigned)p;
-                s_list[pos * 3 + 2] = qe[1];
+            // one queue entry per lane and trip; the wave's survivors of a trip take their places in the tile list with ONE LDS
+            // atomic (a cold tile lets ~10 000 pairs through: one atomic each on a single address serialised the whole block —
+            // 125 us per tile; warm tiles have a handful)
+            bool stalled = false;
+            for (;;) {
+                const bool have = e < qcnt && !stalled;
+                if (__ballot(have) == 0ull) break;
+                bool pass = false;
+                unsigned hi = 0, p32 = 0;
+                int row = 0;
+                if (have) {
+                    const unsigned* qe = s_queue + ((e * 256 + tid) << 1);
+                    const unsigned code = qe[0];
+                    row = (int)(code >> 8);
+                    const int col = (int)(code & 255u);
+                    // the EXACT test: the reference's distance of this pair — from this very dot product — as a key against the row's
+                    const float dot = __uint_as_float(qe[1]);
+                    const long p = pc0 + col;
+                    float d = ref_distance(dot, s_qsq[row], s_psq[col], s_qn[row], s_pn[col]);
+                    const bool isnan = d != d;
+                    if (masked && p >= mask_lo && p < mask_hi) d = 1.f;      // a masked pool row competes at exactly 1
+                    hi = isnan ? 0xFFFFFFFFu : sortable(d);                   // (NaN: kept, the refine pass reports it)
+                    p32 = (unsigned)p;
+                    const unsigned khi = s_khi[row];
+                    pass = hi < khi || (hi == khi && p32 <= s_klo[row]) || isnan;
+                }
+                const unsigned long long bm = __ballot(pass);
+                if (bm) {
+                    const int first = __builtin_ctzll(bm);
+                    int base = 0;
+                    if (lane == first) base = atomicAdd(&s_n[0], __popcll(bm));
+                    base = __builtin_amdgcn_readlane(base, first);
+                    const int pos = base + __popcll(bm & ((1ull << lane) - 1ull));
+                    if (pass) {
+                        if (pos < SCR_LIST) {
+                            const int lp = atomicAdd(&s_cnt[row], 1);
+                            s_list[pos * 3] = ((unsigned)row << 16) | (unsigned)lp;
+                            s_list[pos * 3 + 1] = p32;
+                            s_list[pos * 3 + 2] = hi;
+                        } else stalled = true;                        // list full: this entry and the rest after the flush
+                    }
+                }
+                if (have && !stalled) ++e;
             }
             __syncthreads();
             { const int c = s_cnt[tid]; s_base[tid] = c ? atomicAdd(&cand_count[m0 + tid], c) : 0; }
@@ -556,68 +791,153 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
 #pragma unroll
     for (int j = 0; j < QG::TN; ++j) {
         const int col = QG::acc_col(wave, lane, j);
-        const long p = (long)n0 + col;
-        const bool pv = p < np;
-        const float v_pn = pv ? pn[p] : 0.f;
-        const float v_b2 = pv ? EPS * psq[p] * inv_os : -__builtin_inff();       // columns past np: the bound becomes +inf
+        const long p = pc0 + col;
+        const bool pv = (long)n0 + col < np;
+        const float v_pn = s_pn[col];
+        const float v_b2 = pv ? EPS * s_psq[col] * inv_os : -__builtin_inff();   // columns past np: the bound becomes +inf
         const bool in_mask = masked && pv && p >= mask_lo && p < mask_hi;
 #pragma unroll
-        for (int i = 0; i < QG::TM; ++i)
+        for (int i = 0; i < QG::TM; ++i) {
+            // (NaN anywhere: the comparison fails and the pair goes to the exact test, which keeps NaN distances; a masked pool row
+            //  competes at exactly 1, whatever its dot product.)  The four rows a lane holds of one 16 x 16 tile share ONE branch: the
+            //  four compare masks are OR-ed on the scalar unit — a survivor is rare, the exec-mask round trip per element was not
+            bool c[QG::NR];
 #pragma unroll
-            for (int r = 0; r < QG::NR; ++r) {
-                const float bound = fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2));
-                // (NaN anywhere: the comparison fails and the pair goes to the exact test, which keeps NaN distances;
-                //  a masked pool row competes at exactly 1, whatever its dot product)
-                if ((!(acc[i][j][r] <= bound) || in_mask) && pv) {
+            for (int r = 0; r < QG::NR; ++r) c[r] = !(acc[i][j][r] <= fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2))) || in_mask;
+            if ((c[0] || c[1] || c[2] || c[3]) && pv) {
+#pragma unroll
+                for (int r = 0; r < QG::NR; ++r) {
                     const int row = QG::acc_row(wave, lane, i, r);
-                    if ((long)m0 + row < nq) push(row, col, acc[i][j][r]);
+                    if (c[r] && (long)m0 + row < nq) push(row, col, acc[i][j][r]);
                 }
             }
-        if (__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR)) drain_and_flush();
+        }
+        // (a rolled loop over the groups with the elements behind a switch would hold the drain code once instead of eight times —
+        //  tried: the register allocator answers with 600-700 spilled registers)
+#ifdef KN_WHATIF_NOCHECK
+        continue;
+#endif
+#ifdef KN_KNN_PROF
+        kp_pushed += qcnt;
+        if (__builtin_expect(__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR), 0)) { ++kp_drains; drain_and_flush(); }
+#else
+        if (__builtin_expect(__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR), 0)) drain_and_flush();      // (unlikely: laid out behind the hot path)
+#endif
     }
+    KN_KP_T(3)
     drain_and_flush();
-    if (capped) atomicOr(overflow, 1);
+    KN_KP_T(4)
+#ifdef KN_KNN_PROF
+    if (!COLD) { KN_KP(5, kp_pushed) KN_KP(6, kp_drains) }
+#endif
+    if (capped) atomicOr(overflow, 2);             // bit 1 of the search's flag: the candidate buffer overflowed
     __syncthreads();                                   // the list is consumed: the stages take the next tile's operands
   }
 }
 
-// one wave per query row: exact distances of its candidates, ascending top-k (same keys / order as knn_select_kernel)
-__global__ __launch_bounds__(256) void knn_refine_kernel(const int* __restrict__ cand_count, const unsigned* __restrict__ cand, int cap,
-                                                        const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
-                                                        const float* __restrict__ pn, const float* __restrict__ psq, long np, int k, long idx_offset,
-                                                        long mask_lo, long mask_hi, long* __restrict__ out_idx, float* __restrict__ out_dist,
-                                                        int* nan_flag) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+// One wave per query row: the row's list so far (an earlier epoch's output) + the new candidates -> ascending top-k, same keys /
+// order as knn_select_kernel; the k-th key goes out as the next epoch's threshold and the row's candidate count is reset.  A
+// candidate is (pool index, distance bits): the screen evaluated the reference's formula; 0xFFFFFFFF marks a NaN distance.
+// Candidates are filtered against the list's current k-th key 256 at a time; a survivor is rare once the list is warm and is
+// inserted by ballot + lane shift, bursts go through the bitonic merge (round 3 merged every 32 candidates: 2 ms at cfg-5 size).
+__global__ __launch_bounds__(256) void knn_refine_kernel(int* __restrict__ cand_count, const unsigned* __restrict__ cand, int cap, long nq,
+                                                        int k, long idx_offset, const unsigned* __restrict__ row_bound,
+                                                        const long* __restrict__ prev_idx,
+                                                        const float* __restrict__ prev_dist, long* __restrict__ out_idx,
+                                                        float* __restrict__ out_dist, float* __restrict__ thr_out,
+                                                        long* __restrict__ thr_idx_out, int final_pass, int* flags) {
+    __shared__ unsigned long long scratch[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
     if (row >= nq) return;
     int cnt = cand_count[row];
     cnt = cnt < cap ? cnt : cap;
-    const float v_qn = qn[row], v_qsq = qsq[row];
-    const unsigned* cr = cand + row * (long)cap * 2;
-    unsigned long long best = KEY_INF;                                  // lanes < k: the sorted list
+    const unsigned long long* cr = (const unsigned long long*)(cand + row * (long)cap * 2);      // little endian: index | bits << 32
+    unsigned long long* my_scratch = scratch[wave];
+    unsigned long long mine = KEY_INF;                                  // lanes < k: the sorted list
     bool saw_nan = false;
-    for (int base = 0; base < cnt; base += 32) {
-        unsigned long long v = lane < 32 ? best : KEY_INF;
-        // (p < np: when the screen overflowed, reserved slots may never have been written — the caller discards the result then,
-        //  but nothing may be read through a garbage index)
-        if (lane >= 32 && base + lane - 32 < cnt && (long)cr[(base + lane - 32) * 2] < np) {
-            const unsigned p = cr[(base + lane - 32) * 2];
-            const float dot = __uint_as_float(cr[(base + lane - 32) * 2 + 1]);
-            float d = ref_distance(dot, v_qsq, psq[p], v_qn, pn[p]);
-            if (d != d) saw_nan = true;
-            if ((long)p >= mask_lo && (long)p < mask_hi) d = 1.f;
-            if (d < __builtin_inff()) v = ((unsigned long long)sortable(d) << 32) | p;      // NaN / +inf never enter
-        }
-        v = wave_sort64(v, lane);
-        best = lane < k ? v : KEY_INF;
+    if (prev_idx && lane < k) {
+        const float d = prev_dist[row * k + lane];
+        if (d < __builtin_inff()) mine = ((unsigned long long)sortable(d) << 32) | (unsigned)(prev_idx[row * k + lane] - idx_offset);
     }
-    if (__ballot(saw_nan)) { if (lane == 0) atomicOr(nan_flag, 1); }
+    // (a list handed over by an earlier epoch is sorted and its unused tail is KEY_INF: already in list form)
+    // first epoch: the row's k-th best cannot lie beyond the best bound a tile derived for it (ties at the bound pass: index = max)
+    unsigned long long bound_key = KEY_INF;
+    if (row_bound) { const unsigned b = ~row_bound[row]; if (b != 0xFFFFFFFFu) bound_key = ((unsigned long long)b << 32) | 0xFFFFFFFFull; }
+#define KN_THR() ({ const unsigned long long t_ = readlane64(mine, k - 1); t_ < bound_key ? t_ : bound_key; })
+    unsigned long long thr = KN_THR();
+    constexpr unsigned INF_BITS = 0xFF800000u;                          // sortable(+inf): NaN / +inf never enter
+    for (int base = 0; base < cnt; base += 256) {
+        unsigned long long kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = base + u * 64 + lane;
+            kv[u] = KEY_INF;
+            if (x < cnt) {
+                const unsigned long long raw = cr[x];
+                const unsigned p = (unsigned)raw, hi = (unsigned)(raw >> 32);
+                if (hi == 0xFFFFFFFFu) saw_nan = true;
+                else if (hi < INF_BITS) kv[u] = ((unsigned long long)hi << 32) | p;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (base + u * 64 >= cnt) break;
+            const bool f = kv[u] <= thr && kv[u] != KEY_INF;           // (<=: the bound key itself is no list entry; list keys are unique)
+            unsigned long long b = __ballot(f);
+            if (b == 0ull) continue;
+            const int total = __popcll(b);
+            if (total <= 8) {
+                while (b) {
+                    const int l = __builtin_ctzll(b); b &= b - 1;
+                    const unsigned long long key = readlane64(kv[u], l);
+                    if (key <= thr) { list_insert(mine, key, lane, k); thr = KN_THR(); }
+                }
+            } else {
+                if (f) my_scratch[__popcll(b & ((1ull << lane) - 1ull))] = kv[u];
+                __builtin_amdgcn_wave_barrier();
+                for (int s0 = 0; s0 < total; s0 += 32) {
+                    unsigned long long v = mine;                       // lanes < 32: the list (KEY_INF beyond k)
+                    if (lane >= 32) v = (s0 + lane - 32) < total ? my_scratch[s0 + lane - 32] : KEY_INF;
+                    v = wave_sort64(v, lane);
+                    mine = lane < k ? v : KEY_INF;
+                }
+                __builtin_amdgcn_wave_barrier();
+                thr = KN_THR();
+            }
+        }
+    }
+#undef KN_THR
+    thr = readlane64(mine, k - 1);
+    const bool nan_row = __ballot(saw_nan) != 0ull;
+    if (lane == 0) {
+        cand_count[row] = 0;                                            // the next epoch starts an empty list
+        int fl = nan_row ? 1 : 0;
+        // fewer than k entries at the end without a NaN in sight: the candidate set was NOT a superset of the top-k — cannot happen
+        // by construction; if it ever does, the caller repeats the search on the dot-matrix route instead of using a short list
+        if (final_pass && thr == KEY_INF && !nan_row) fl |= 2;
+        if (fl) atomicOr(flags, fl);
+        if (thr_out) {
+            thr_out[row] = thr == KEY_INF ? __builtin_inff() : unsortable((unsigned)(thr >> 32));
+            thr_idx_out[row] = (long)(unsigned)(thr & 0xFFFFFFFFull);
+        }
+    }
     if (lane < k) {
-        out_idx[row * k + lane] = (long)(unsigned)(best & 0xFFFFFFFFull) + idx_offset;
-        out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
+        // (an unfilled place — a NaN row — is a VALID row index with a NaN distance, as knn_select_kernel leaves it: the flag is read
+        //  by the host only after the later stages have been enqueued, and those gather pool rows through these indices)
+        out_idx[row * k + lane] = (mine == KEY_INF ? 0l : (long)(unsigned)(mine & 0xFFFFFFFFull)) + idx_offset;
+        out_dist[row * k + lane] = unsortable((unsigned)(mine >> 32));
     }
 }
 
+#ifdef KN_KNN_PROF
+}  // namespace
+extern "C" int knnsvc_debug_knn_prof(long long* host, int n_tiles) {
+    if (n_tiles > 4096) n_tiles = 4096;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(kn_knn_prof_buf), (size_t)n_tiles * 8 * sizeof(long long)) == hipSuccess ? 0 : 3;
+}
+namespace {
+#endif
 int split_count(long nq, long np) {
     // The kernel needs 109 KB of LDS, so one block is resident per CU: aim for ONE wave of <= 256 blocks and let
     // every block walk as many 128-row pool tiles as possible — the first tile of a block pays a full top-32
@@ -714,20 +1034,26 @@ extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_n
 
 extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q_norm, const float* q_sq, int64_t nq,
                                  const void* p_f16x2, const float* p_absmax, const float* p_norm, const float* p_sq, int64_t np,
-                                 int32_t dim, const float* thr, const int64_t* thr_idx, int64_t mask_lo, int64_t mask_hi, int32_t* cand_count,
-                                 void* cand, int32_t cap, int32_t* overflow_flag, int32_t max_blocks, void* stream) {
-    KN_REQUIRE(q_f16x2 && q_absmax && q_norm && q_sq && p_f16x2 && p_absmax && p_norm && p_sq && thr && thr_idx && cand_count && cand && overflow_flag,
+                                 int32_t dim, const float* thr, const int64_t* thr_idx, int64_t mask_lo, int64_t mask_hi, int64_t p_base,
+                                 int32_t* cand_count, void* cand, int32_t cap, uint32_t* cold_ws, int32_t* overflow_flag, int32_t max_blocks,
+                                 void* stream) {
+    KN_REQUIRE(q_f16x2 && q_absmax && q_norm && q_sq && p_f16x2 && p_absmax && p_norm && p_sq && cand_count && cand && overflow_flag,
                "knn_screen: null pointer");
-    KN_REQUIRE(nq > 0 && np > 0 && dim >= 32 && dim % 32 == 0 && cap > 0, "knn_screen: bad sizes (dim must be a multiple of 32)");
+    KN_REQUIRE((thr == nullptr) == (thr_idx == nullptr), "knn_screen: thr and thr_idx come together (both null: the first epoch)");
+    KN_REQUIRE(nq > 0 && np > 0 && dim >= 32 && dim % 32 == 0 && cap > 0 && p_base >= 0, "knn_screen: bad sizes (dim must be a multiple of 32)");
     KN_REQUIRE(nq * (long)dim * 4 < (1L << 30) && np * (long)dim * 4 < (1L << 30), "knn_screen: operands must stay below 1 GiB (chunk the call)");
+    KN_REQUIRE(p_base + np < (1ll << 32), "knn_screen: pool rows must fit 32 bits");
     KN_REQUIRE(((uintptr_t)q_f16x2 & 15) == 0 && ((uintptr_t)p_f16x2 & 15) == 0, "knn_screen: 16-byte alignment");
     KN_REQUIRE(max_blocks >= 0, "knn_screen: max_blocks must be >= 0 (0 = one block per CU)");
     static_assert(QG::LDS_BYTES >= (256 * 10 + 4) * 4 + SCR_LIST * 12 + SCR_QD * 256 * 8, "epilogue state fits the operand stages");
     static_assert(SCR_QD > QG::TM * QG::NR, "a lane queue holds more than one column's elements");
+    static_assert(SCR_QD * 256 * 8 >= (520 + 512) * 4, "the cold pass's per-half bounds fit the (empty) queue area");
     static bool attr = false;
     static int cus = 0;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)knn_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QG::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)knn_screen_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, QG::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)knn_screen_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, QG::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)knn_screen_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, QG::LDS_BYTES) != hipSuccess)
             return knnsvc_fail(KNNSVC_EHIP, "knn_screen: hipFuncSetAttribute failed");
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -736,21 +1062,30 @@ extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, con
     const long ntiles = quad_order_ids(cdiv64(nq, 256), cdiv64(np, 256));
     KN_REQUIRE(ntiles < (1L << 31), "knn_screen: too many tiles (chunk the call)");
     long blocks = max_blocks > 0 && max_blocks < cus ? max_blocks : cus;
-    blocks = blocks / 8 * 8 > 0 ? blocks / 8 * 8 : 8;
-    if (blocks > ntiles) blocks = ntiles;              // (ntiles is a multiple of 8)
-    hipLaunchKernelGGL(knn_screen_kernel, dim3((unsigned)blocks), dim3(256), QG::LDS_BYTES, (hipStream_t)stream,
-                       (const float*)q_f16x2, q_absmax, q_norm, q_sq, (long)nq, (const unsigned short*)p_f16x2, p_absmax, p_norm, p_sq,
-                       (long)np, dim, thr, (const long*)thr_idx, (long)mask_lo, (long)mask_hi, cand_count, (unsigned*)cand, cap, overflow_flag, (int)ntiles);
+    if (blocks >= 8) blocks = blocks / 8 * 8;          // a multiple of 8: with the padded (XCD-aware) tile order a block's tiles keep their XCD
+    if (blocks > ntiles) blocks = ntiles;
+    const long gy = cdiv64(np, 256);
+    const bool xch = !thr && cold_ws && 2 * gy >= 40 && 2 * gy <= XCH_MAX;      // the exchange pays from ~20 column tiles on (>= 32 bounds needed)
+#define KN_LAUNCH(COLD_, XCH_)                                                                                                       \
+    hipLaunchKernelGGL((knn_screen_kernel<COLD_, XCH_>), dim3((unsigned)blocks), dim3(256), QG::LDS_BYTES, (hipStream_t)stream,       \
+                       (const float*)q_f16x2, q_absmax, q_norm, q_sq, (long)nq, (const unsigned short*)p_f16x2, p_absmax, p_norm, p_sq, \
+                       (long)np, dim, thr, (const long*)thr_idx, (long)mask_lo, (long)mask_hi, (long)p_base, cand_count,              \
+                       (unsigned*)cand, cap, (unsigned*)cold_ws, overflow_flag, (int)ntiles)
+    if (thr) KN_LAUNCH(false, false);
+    else if (xch) KN_LAUNCH(true, true);
+    else KN_LAUNCH(true, false);
+#undef KN_LAUNCH
     return knnsvc_check_launch("knn_screen");
 }
 
-extern "C" int knnsvc_knn_refine(const int32_t* cand_count, const void* cand, int32_t cap, const float* q_norm, const float* q_sq,
-                                 int64_t nq, const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
-                                 int64_t mask_lo, int64_t mask_hi, int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream) {
-    KN_REQUIRE(cand_count && cand && q_norm && q_sq && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_refine: null pointer");
-    KN_REQUIRE(nq > 0 && np > 0 && cap > 0 && k >= 1 && k <= KMAX, "knn_refine: bad sizes");
+extern "C" int knnsvc_knn_refine(int32_t* cand_count, const void* cand, int32_t cap, int64_t nq, int32_t k, int64_t idx_offset,
+                                 const uint32_t* row_bound, const int64_t* prev_idx, const float* prev_dist, int64_t* out_idx, float* out_dist, float* thr_out,
+                                 int64_t* thr_idx_out, int32_t final_pass, int32_t* flags, void* stream) {
+    KN_REQUIRE(cand_count && cand && out_idx && out_dist && flags, "knn_refine: null pointer");
+    KN_REQUIRE((prev_idx == nullptr) == (prev_dist == nullptr) && (thr_out == nullptr) == (thr_idx_out == nullptr), "knn_refine: pointer pairs come together");
+    KN_REQUIRE(nq > 0 && cap > 0 && k >= 1 && k <= KMAX, "knn_refine: bad sizes");
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream, cand_count,
-                       (const unsigned*)cand, cap, q_norm, q_sq, (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi,
-                       (long*)out_idx, out_dist, nan_flag);
+                       (const unsigned*)cand, cap, (long)nq, k, (long)idx_offset, (const unsigned*)row_bound, (const long*)prev_idx, prev_dist, (long*)out_idx, out_dist,
+                       thr_out, (long*)thr_idx_out, final_pass, flags);
     return knnsvc_check_launch("knn_refine");
 }

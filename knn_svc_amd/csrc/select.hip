@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256) void concat_reselect_kernel(
                     total = total + fabsf(lp - lq);
                 }
             }
+            // A NaN cost (NaN features: the reference has exited in fast_cosine_dist by then, here the flag is read only after
+            // everything is enqueued) must still rank: as +inf, ties by candidate number.  Unranked, all eight candidates took
+            // rank 0, the kept-row broadcast read slot 64, and the next frame gathered pool rows through garbage indices.
+            if (!(total == total)) total = __builtin_inff();
             int rank = 0;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {          // v_readlane (an SGPR broadcast), not a ds_bpermute round trip per candidate
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 total = w * med + s_match[lane];
                 if (use_f0) total = total + fabsf(s_cf0[lane] - s_sf0[cur]);      // both already log2(f0 + 1e-5)
             }
+            if (!(total == total)) total = __builtin_inff();       // NaN costs rank as +inf, ties by candidate number (see above)
             int rank = 0;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {          // v_readlane (an SGPR broadcast), not a ds_bpermute round trip per candidate

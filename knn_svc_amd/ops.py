@@ -501,13 +501,14 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
 
 
 KNN_ROUTE_COUNTS = {"chunks": 0, "fused": 0, "dot": 0}     # which route each (search, pool chunk) took: tests assert on it
-# Below these the dot matrix is small and its route is faster (tools/knn_bench.py, profiles/r03_knn_bench.txt; ms, fused / dot matrix:
-# 1500 x 30 000: 0.540 / 0.479, 3000 x 30 000: 0.875 / 0.930, 6000 x 30 000: 1.55 / 1.62, 24 000 x 180 000: 21.8 / 36.0): the threshold
-# pass (sample GEMM + selection, ~0.15 ms whatever the size) has to be earned back.  Round 2 had 4096 / 32768.
-KNN_FUSED_MIN_Q = int(_os.environ.get("KNNSVC_KNN_FUSED_MIN_Q", "2048"))
+# The fused route (epochs of knnsvc_knn_screen + knnsvc_knn_refine, no dot matrix) from 256 query frames x 8192 pool rows on.
+# Round 3 (threshold from a separate sample pass: ~0.15 ms whatever the size) had 2048 / 8192; round 2 4096 / 32768.
+KNN_FUSED_MIN_Q = int(_os.environ.get("KNNSVC_KNN_FUSED_MIN_Q", "256"))
 KNN_FUSED_MIN_P = int(_os.environ.get("KNNSVC_KNN_FUSED_MIN_P", "8192"))
 KNN_FUSED_CAP = 4096
 KNN_OVERFLOW = 2                  # flag bit: the fused route's candidate buffer overflowed
+KNN_EPOCH_GROWTH = int(_os.environ.get("KNNSVC_KNN_EPOCH_GROWTH", "4"))
+KNN_COLD_TILES_MAX = 44           # column tiles of the first epoch: ~45 candidates per (row, tile) have to fit the buffer twice over
 
 
 def knn_fused_on() -> bool:
@@ -527,44 +528,59 @@ class fused_off:
         _FUSED_OFF.on = self.prev
 
 
-def knn_sample_rows(npc: int) -> int:
-    """Pool rows in the threshold sample of the fused route: ~1/8 of the chunk, 1024 .. 8192.  A row's expected survivors are
-    32 * stride (its k-th best over a 1-in-stride sample sits at the (32 * stride)-th place of the whole chunk)."""
-    return max(1024, min(8192, npc // 8))
+def knn_epochs(nq: int, npc: int, blocks: int = 256):
+    """Column-tile ranges [(t0, t1), ...] (tiles of 256 pool rows) of the fused route's epochs.  The first epoch has no
+    thresholds (every tile bounds its rows itself and lets ~45 of its 256 columns per row through), so it is about ONE round
+    of workgroups — enough columns for a useful k-th distance (at least 4 tiles), few enough for the candidate buffer; every
+    later epoch multiplies the rows seen by KNN_EPOCH_GROWTH: a row's survivors per epoch are ~k x (new rows / rows seen), and
+    each epoch boundary costs one refine launch and the tail of a round.  A last epoch much smaller than its predecessor is
+    merged into it."""
+    gx, gy = -(-nq // 256), -(-npc // 256)
+    e0 = min(gy, max(4, min(KNN_COLD_TILES_MAX, max(1, blocks) // gx)))
+    out, c = [(0, e0)], e0
+    while c < gy:
+        nxt = min(gy, c * KNN_EPOCH_GROWTH)
+        if gy - nxt < (nxt - c) // 2:
+            nxt = gy
+        out.append((c, nxt)); c = nxt
+    return out
 
 
 def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offset, mask, idx_out, dist_out, flag, max_blocks=0):
-    """One pool chunk without a [nq, np] dot matrix (knnsvc_knn_screen / knnsvc_knn_refine): thr = each row's exact k-th
-    distance over an evenly strided SAMPLE of the chunk (the dot-matrix route on a few thousand pool rows), then the whole chunk
-    through the screening GEMM with those thresholds, then the reference formula on the survivors.  A row with more survivors
-    than the candidate buffer holds (many near-identical pool rows, e.g. silence) sets bit 1 of ``flag``; nothing here reads it."""
+    """One pool chunk without a [nq, np] dot matrix: the chunk's rows in epochs (knn_epochs), each one knnsvc_knn_screen (the
+    first without thresholds, the later ones against the row's k-th key so far) + one knnsvc_knn_refine (list so far + the new
+    candidates -> list, next thresholds).  A row with more survivors than the candidate buffer holds (pathological data: e.g.
+    thousands of bit-identical pool rows inside the first epoch) sets bit 1 of ``flag``; nothing here reads it."""
     lib = _lib.load()
     nq, dim = q.shape
     npc = pc.shape[0]
     dev = q.device
-    stride = max(1, npc // knn_sample_rows(npc))
-    sample = pc[::stride].contiguous()
-    sn, ss = row_norms(sample)
-    sflag = torch.zeros(1, device=dev, dtype=torch.int32)
-    # sampled rows inside the masked range must compete at 1 here as they do globally (unmasked, a query's own frames would
-    # pull thr below its true k-th distance): sample row j is pool row j * stride
-    smask = (-(-max(mask[0], 0) // stride), -(-max(mask[1], 0) // stride)) if mask[0] < mask[1] else (0, 0)
-    si, sd = _knn_topk_gemm(q, sample, k, 0, qn, qs, sn, ss, sflag, smask, None, allow_fused=False)
-    thr = sd[:, k - 1].contiguous()
-    thr_idx = (si[:, k - 1] * stride).contiguous()                 # sample row j is pool row j * stride
+    row_u16 = (dim // 32) * 64                                     # int16 elements of one pool row in the split image
+    blocks = int(max_blocks) if max_blocks else 256
     q_rows = max(256, min(nq, ((1 << 28) - 1) // dim // 256 * 256, (1 << 30) // (KNN_FUSED_CAP * 8) // 256 * 256))
-    over = torch.zeros(1, device=dev, dtype=torch.int32)
-    nan_tmp = torch.zeros(1, device=dev, dtype=torch.int32)
     for q0 in range(0, nq, q_rows):
         m = min(q_rows, nq - q0)
-        cnt = torch.zeros(m, device=dev, dtype=torch.int32)
+        epochs = knn_epochs(m, npc, blocks)
+        # one fill: candidate counts [m] | the first epoch's workspace: row bounds [m], per-half-tile bounds [2 gy0][m] (the tiles'
+        # exchange, knn.hip), arrival counters [gx] one cache line each
+        gy0 = epochs[0][1] - epochs[0][0]
+        zeroed = torch.zeros(m * (2 + 2 * gy0) + 32 * -(-m // 256), device=dev, dtype=torch.int32)
+        cnt, bound = zeroed[:m], zeroed[m:]
         cand = torch.empty(m * KNN_FUSED_CAP * 2, device=dev, dtype=torch.int32)
-        check(lib.knnsvc_knn_screen(_p(q2[q0:]), _p(q_slot), _p(qn[q0:]), _p(qs[q0:]), m, _p(p2), _p(p_slot), _p(pn), _p(ps), npc, dim,
-                                    _p(thr[q0:]), _p(thr_idx[q0:]), mask[0], mask[1], _p(cnt), _p(cand), KNN_FUSED_CAP, _p(over), int(max_blocks), _stream()), "knn_screen")
-        check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn), _p(ps), npc, k, idx_offset,
-                                    mask[0], mask[1], _p(idx_out[q0:]), _p(dist_out[q0:]), _p(nan_tmp), _stream()), "knn_refine")
-    # flag |= nan | sample nan | overflow << 1 (flags are 0/1)
-    flag.copy_(flag | nan_tmp | sflag | (over.clamp(max=1) * KNN_OVERFLOW))
+        thr = torch.empty(m, device=dev, dtype=torch.float32)
+        thr_idx = torch.empty(m, device=dev, dtype=torch.int64)
+        for e, (t0, t1) in enumerate(epochs):
+            c0, c1 = t0 * 256, min(t1 * 256, npc)
+            last = e == len(epochs) - 1
+            # both kernels OR their bits straight into the search's flag (bit 0: NaN distance, bit 1: candidate-buffer overflow
+            # or a short list): no glue kernels between the launches
+            check(lib.knnsvc_knn_screen(_p(q2[q0:]), _p(q_slot), _p(qn[q0:]), _p(qs[q0:]), m, _p(p2[c0 * row_u16:]), _p(p_slot), _p(pn[c0:]),
+                                        _p(ps[c0:]), c1 - c0, dim, _p(thr) if e else _p(None), _p(thr_idx) if e else _p(None), mask[0], mask[1],
+                                        c0, _p(cnt), _p(cand), KNN_FUSED_CAP, _p(None) if e else _p(bound), _p(flag), int(max_blocks), _stream()), "knn_screen")
+            check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, m, k, idx_offset, _p(None) if e else _p(bound),
+                                        _p(idx_out[q0:]) if e else _p(None),
+                                        _p(dist_out[q0:]) if e else _p(None), _p(idx_out[q0:]), _p(dist_out[q0:]), _p(None) if last else _p(thr),
+                                        _p(None) if last else _p(thr_idx), 1 if last else 0, _p(flag), _stream()), "knn_refine")
 
 
 def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False, mask=None,

@@ -51,14 +51,22 @@ def _tensors(obj):
 # of live high-priority streams is known, and the tail count is a function of it with a hard cap below the cliff.
 MAX_TAILS = 4                      # never more, whatever KNNSVC_TAILS says: the fifth is the cliff
 HIPRI_QUEUES = 4
-_STREAMS = []                      # (weakref to stream, priority, kind)
+_STREAMS = []                      # (owner or None, priority, kind): owner = weak reference to the LanePipeline that made it
 
 
-def new_stream(device, priority: int = 0, kind: str = "") -> "torch.cuda.Stream":
+def new_stream(device, priority: int = 0, kind: str = "", owner=None) -> "torch.cuda.Stream":
+    """Every stream of the package.  Streams made for a LanePipeline count while that pipeline is alive (weak reference to the
+    PIPELINE — torch's stream objects themselves do not survive being weakly referenced: the process dies in the garbage
+    collector); all others are cached for the life of the process by their makers."""
     import weakref
     s = torch.cuda.Stream(device=device, priority=priority)
-    _STREAMS.append((weakref.ref(s), int(priority), kind))
+    _STREAMS.append((weakref.ref(owner) if owner is not None else None, int(priority), kind))
     return s
+
+
+def _live():
+    _STREAMS[:] = [e for e in _STREAMS if e[0] is None or e[0]() is not None]
+    return [(p, k) for _o, p, k in _STREAMS]
 
 
 def rccl_streams():
@@ -78,7 +86,7 @@ def rccl_streams():
 
 def stream_census(device=None):
     """Live streams this process created through the package, by priority class, plus RCCL's."""
-    live = [(p, k) for r, p, k in _STREAMS if r() is not None]
+    live = _live()
     n_rccl, hi_rccl = rccl_streams()
     return {"high": sum(1 for p, _k in live if p < 0) + hi_rccl, "normal": sum(1 for p, _k in live if p >= 0) + n_rccl - hi_rccl,
             "rccl": n_rccl, "tails": sum(1 for p, k in live if k == "tail")}
@@ -92,7 +100,7 @@ def tail_budget(requested: int, device=None) -> int:
     headroom until it has."""
     c = stream_census(device)
     n = max(1, min(int(requested), MAX_TAILS))
-    live = [(p, k) for r, p, k in _STREAMS if r() is not None]
+    live = _live()
     other_hi = sum(1 for p, k in live if p < 0 and k not in ("tail", "partner", "branch")) + rccl_streams()[1]
     n = max(1, min(n, HIPRI_QUEUES - other_hi))
     if c["rccl"] and n > 2:
@@ -105,7 +113,7 @@ class LanePipeline:
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         self.device = torch.device(device)
-        self.lanes = [new_stream(self.device, kind="lane") for _ in range(lanes)]
+        self.lanes = [new_stream(self.device, kind="lane", owner=self) for _ in range(lanes)]
         # The tail carries the single-workgroup recurrences: high priority puts it (and its partner stream, see
         # matching._side_stream) on hardware queues of their own — normal-priority streams can collide with each
         # other on a queue (more so once RCCL has created its streams) but never with these — and lets a lone
@@ -129,7 +137,7 @@ class LanePipeline:
         # more than three lanes.
         self.n_tails_requested = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
         n_tails = tail_budget(self.n_tails_requested, self.device)
-        self.tail_streams = [new_stream(self.device, priority=pr, kind="tail") for _ in range(n_tails)]
+        self.tail_streams = [new_stream(self.device, priority=pr, kind="tail", owner=self) for _ in range(n_tails)]
         self.tail_stream = self.tail_streams[0]
 
     def run(self, items, head, tail=None):

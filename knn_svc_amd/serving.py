@@ -112,6 +112,8 @@ class BatchConverter:
         w, f0 = self._load(src)
         if w.dim() != 1:
             raise ValueError(f"request: expected a mono waveform [L], got shape {tuple(w.shape)}")
+        if not bool(torch.isfinite(w).all()):          # (one small host read per request: a server checks its inputs at the door)
+            raise ValueError("request: the waveform contains NaN or infinite samples")
         T = M.frames_of(int(w.shape[0]), self.vc.wavlm)
         if T < 1:
             raise ValueError(f"request: expected a mono waveform of at least one frame, got shape {tuple(w.shape)}")

@@ -174,8 +174,8 @@ class Vocoder:
         nd.fill_(N)
         g.replay()
         y = out[:N * self.hop].clone()
-        last[0] = torch.cuda.current_stream(c.device).record_event()       # the entry may be destroyed once this has passed
-        return y
+        last[0] = torch.cuda.current_stream(c.device)       # the entry may be destroyed once this stream has drained (a stream
+        return y                                            # object, not an event: events held at interpreter exit crash in hipEventDestroy)
 
     def _evict(self, slot) -> None:
         """LRU per tail stream (``max_graphs`` instances EACH: the key space is buckets x tails, and the tails replay
@@ -187,9 +187,9 @@ class Vocoder:
         for k in mine:                                                    # insertion order = least recently used first
             if extra <= 0:
                 break
-            ev = self._graphs[k][6][0]
-            if ev is not None and not ev.query():
-                continue                                                  # still in flight: try the next oldest
+            st = self._graphs[k][6][0]
+            if st is not None and not st.query():
+                continue                                                  # its stream is still busy: try the next oldest
             self._graphs.pop(k)
             self._seen.discard(k)
             extra -= 1

@@ -208,6 +208,46 @@ def gen_knn():
          small=small.numpy())
 
 
+def knn_ties_inputs():
+    """Inputs of fixture G3b (shared with the tests): exact ties of every kind the path can meet — duplicated pool rows, a block
+    of 400 bit-identical "silence" rows, queries that ARE pool rows, queries that are the silence row."""
+    q = S.clustered_features(200, 1024, seed=23, n_centres=25)
+    p = S.clustered_features(4096, 1024, seed=24, n_centres=25)
+    g = torch.Generator().manual_seed(25)
+    sil = 0.05 * torch.randn(1, 1024, generator=g)
+    p[100:164] = p[0:64]                       # duplicated pool rows (pairs at identical distance from every query)
+    p[2000:2003] = p[1999:2000]                # a quadruple
+    p[500:900] = sil                           # 400 identical rows
+    q[:20] = p[:20]                            # queries that are pool rows (and their duplicates at 100..119)
+    q[20:30] = sil                             # queries that are the silence row: 400-way tie at the smallest distance
+    q[30:40] = sil + 1e-3 * torch.randn(10, 1024, generator=g)
+    return q, p
+
+
+def gen_knn_ties():
+    print("G3b kNN top-32 with exact ties (duplicated / identical pool rows), and the f0 re-rank on the reference's own lists")
+    q, p = knn_ties_inputs()
+    idxs, vals = [], []
+    for s in range(0, len(q), 20):
+        d = R_lo.fast_cosine_dist(q[s:s + 20], p)
+        t = d.topk(k=32, dim=-1, largest=False)
+        idxs.append(t.indices); vals.append(t.values)
+    idx, val = torch.cat(idxs), torch.cat(vals)
+    mi, mv = knn_ref.knn_topk(q, p, 32)
+    eq(val, mv, "knn dist (ties)")             # the distances are pinned; WHICH of several tied rows torch.topk returns is recorded
+    qf0, pf0 = _f0_track(200, 26) * 1.2, _f0_track(4096, 27)
+    shifted = select_ref.shift_query_f0(qf0, pf0)
+    ranked = R_dp.sort_by_f0_compatibility(shifted, pf0, idx)
+    eq(ranked, select_ref.rerank_by_f0(shifted, pf0, idx), "f0 rerank (ties)")
+    full = torch.cat([R_lo.fast_cosine_dist(q[s:s + 20], p) for s in range(0, len(q), 20)])
+    ties_at_k = int(((full <= val[:, -1:]).sum(1) > 32).sum())
+    print(f"     rows whose 32nd distance is shared with rows outside the list: {ties_at_k} of {len(q)}; "
+          f"torch.topk lists in ascending index order inside tie groups: "
+          f"{float((((val[:, 1:] > val[:, :-1]) | (idx[:, 1:] > idx[:, :-1])).all(1)).float().mean()):.3f} of the rows")
+    save("g3b_knn_ties", idx=idx.numpy().astype(np.int32), dist=val.numpy(), qf0=qf0.numpy(), pf0=pf0.numpy(),
+         shifted=shifted.numpy(), ranked=ranked.numpy().astype(np.int32))
+
+
 # ---------------------------------------------------------------- G4: selection
 def _f0_track(n, seed):
     _, f0 = S.synth_clip(n * 320, seed)
@@ -493,7 +533,7 @@ def gen_sample():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "select", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
+    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "select", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

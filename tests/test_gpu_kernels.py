@@ -1,5 +1,7 @@
 """GPU: each HIP kernel against the CPU oracle / a plain torch fp32 reference of the same op,
 called through the C ABI (knn_svc_amd.ops -> libknnsvc_hip.so)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -405,6 +407,65 @@ def test_knn_golden(golden):
     assert all(len(set(r.tolist())) == 32 for r in idx)
 
 
+def test_knn_golden_with_exact_ties(golden):
+    """Fixture G3b (reference-generated, tests/gen_golden.py: knn_ties): duplicated pool rows, a block of 400 bit-identical
+    rows, queries that are pool rows / the identical row.  torch.topk returns tied rows in no particular order (the fixture
+    records what it did: only 62 % of its rows list ties by ascending index); this build's rule is lower index first on every
+    route and device count.  Checked: the distances are the reference's position by position; wherever the reference's list has
+    no tie the indices are the reference's; every returned index has the distance the reference formula gives it; nothing
+    closer was left out; ties come out lower index first; and the f0 re-rank (a STABLE sort over the 32, so it inherits the
+    tie order of its input) reproduces the reference's output on the reference's own lists."""
+    from oracle import knn_ref
+    ops = _ops()
+    g = golden("g3b_knn_ties")
+    q, p = _knn_ties_inputs()
+    ref_i, ref_d = _t(g["idx"]).long(), _t(g["dist"])
+    full = torch.cat([knn_ref.cosine_dist(q[s0:s0 + 20], p) for s0 in range(0, len(q), 20)])      # the reference formula, 20 rows at a time
+    for fused in ("0", "1"):
+        os.environ["KNNSVC_KNN_FUSED_MIN_Q"] = "1"
+        os.environ["KNNSVC_KNN_FUSED"] = fused
+        try:
+            idx, dist = ops.knn_topk(q.to(DEV), p.to(DEV), 32)
+        finally:
+            os.environ.pop("KNNSVC_KNN_FUSED", None); os.environ.pop("KNNSVC_KNN_FUSED_MIN_Q", None)
+        idx, dist = idx.cpu(), dist.cpu()
+        assert float((dist - ref_d).abs().max()) < 5e-6
+        got_ref_d = full.gather(1, idx)
+        assert float((got_ref_d - dist).abs().max()) < 5e-6                 # each returned row really lies at that distance
+        kth = dist[:, -1:]
+        assert int(((full < kth - 5e-6).sum(1) > 32).sum()) == 0           # nothing closer than the list's end was left out
+        assert all(len(set(r.tolist())) == 32 for r in idx)
+        # positions whose reference distance is separated from every other pool row's by more than the rounding gap: same index
+        srt = full.sort(1).values
+        gap_ok = torch.ones_like(ref_d, dtype=torch.bool)
+        for r in range(ref_d.shape[0]):
+            d = srt[r, :40]
+            lonely = torch.ones(40, dtype=torch.bool)
+            lonely[1:] &= (d[1:] - d[:-1]) > 2e-6
+            lonely[:-1] &= (d[1:] - d[:-1]) > 2e-6
+            gap_ok[r] = lonely[:32]
+        assert bool((idx[gap_ok] == ref_i[gap_ok]).all()) and float(gap_ok.float().mean()) > 0.5
+        assert bool(((dist[:, 1:] > dist[:, :-1]) | (idx[:, 1:] > idx[:, :-1])).all())      # ties: lower index first
+        assert bool(((idx[20:30] >= 500) & (idx[20:30] < 900)).all()) and bool((idx[20:30, 0] == 500).all())
+    ranked = ops.f0_rerank(ref_i.to(DEV), _t(g["shifted"]).to(DEV), _t(g["pf0"]).to(DEV)).cpu()
+    assert torch.equal(ranked, _t(g["ranked"]).long())
+
+
+def _knn_ties_inputs():
+    """== tests/gen_golden.py: knn_ties_inputs (the generator imports the reference and cannot travel to the GPU box)."""
+    q = S.clustered_features(200, 1024, seed=23, n_centres=25)
+    p = S.clustered_features(4096, 1024, seed=24, n_centres=25)
+    g = torch.Generator().manual_seed(25)
+    sil = 0.05 * torch.randn(1, 1024, generator=g)
+    p[100:164] = p[0:64]
+    p[2000:2003] = p[1999:2000]
+    p[500:900] = sil
+    q[:20] = p[:20]
+    q[20:30] = sil
+    q[30:40] = sil + 1e-3 * torch.randn(10, 1024, generator=g)
+    return q, p
+
+
 @pytest.mark.parametrize("nq,npool,k", [(1, 32, 32), (37, 129, 5), (130, 1000, 32), (257, 4099, 32)])
 def test_knn_ragged(nq, npool, k):
     from oracle import knn_ref
@@ -673,6 +734,88 @@ def test_knn_fused_route_equals_dot_matrix_route(monkeypatch):
     monkeypatch.setenv("KNNSVC_KNN_FUSED", "1")
     with pytest.raises(KnnSvcError):
         ops.knn_topk(qn_, pd, 32)
+
+
+@pytest.mark.parametrize("nq,npool,dim", [(1500, 30000, 1024), (300, 30000 + 77, 1024), (257, 8192 + 5, 256), (3000 + 11, 20000, 512)])
+def test_knn_fused_epochs_equal_dot_matrix_route_at_small_sizes(nq, npool, dim, monkeypatch):
+    """Round 4: the fused route starts at 256 query frames — the first epoch has no thresholds (every tile bounds its rows
+    itself), later epochs take the k-th key so far.  The north-star size (1500 x 30 000) and ragged sizes around it give the
+    dot-matrix route's indices and distance bits, plain, with an offset and with a mask that swallows a whole first-epoch tile."""
+    from knn_svc_amd import ops
+    q = S.clustered_features(nq, dim, 71, n_centres=50)
+    p = S.clustered_features(npool, dim, 72, n_centres=50)
+    p[700:700 + 64] = q[:64]                                   # exact duplicates of some queries
+    qd, pd = q.to(DEV), p.to(DEV)
+
+    def run(fused, **kw):
+        monkeypatch.setenv("KNNSVC_KNN_FUSED", "1" if fused else "0")
+        c0 = dict(ops.KNN_ROUTE_COUNTS)
+        out = ops.knn_topk(qd, pd, 32, **kw)
+        assert (ops.KNN_ROUTE_COUNTS["fused"] - c0["fused"] > 0) == fused
+        return out
+    for kw in (dict(), dict(mask=(200, 1100), idx_offset=12345), dict(mask=(npool - 300, npool))):
+        i0, d0 = run(False, **kw)
+        i1, d1 = run(True, **kw)
+        assert torch.equal(i0, i1) and torch.equal(d0, d1), kw
+    assert len(ops.knn_epochs(nq, npool)) >= 1
+
+
+def test_knn_fused_route_survives_thousands_of_identical_pool_rows_and_silence(monkeypatch):
+    """with many bit-identical pool rows (digital silence) every tied row shares one dot product.  The
+    thresholds of the fused route are KEYS (distance bits, pool index) over rows already searched with the SAME operand split
+    (no separately split sample any more), so ties are cut by index exactly as the full evaluation cuts them, a row never ends
+    with fewer than k candidates, and a short list would be flagged rather than written.  Pool: 6000 identical rows of a small
+    norm in the middle of louder material (the largest norm is far above twice theirs), queries that are nearest to them, and
+    queries that ARE them."""
+    from knn_svc_amd import ops
+    nq, npool = 600, 24000
+    g = torch.Generator().manual_seed(5)
+    p = S.clustered_features(npool, 1024, 81, n_centres=30) * 40.0
+    sil = torch.randn(1, 1024, generator=g) * 0.02
+    p[9000:15000] = sil
+    p[20000:20400] = sil * 1.0000001                           # near-identical, not identical
+    q = S.clustered_features(nq, 1024, 82, n_centres=30) * 40.0
+    q[:200] = sil + 1e-4 * torch.randn(200, 1024, generator=g)
+    q[200:260] = sil
+    qd, pd = q.to(DEV), p.to(DEV)
+    monkeypatch.setenv("KNNSVC_KNN_FUSED", "0")
+    i0, d0, f0 = ops.knn_topk(qd, pd, 32, check_nan=False, return_flag=True)
+    monkeypatch.setenv("KNNSVC_KNN_FUSED", "1")
+    c0 = ops.KNN_ROUTE_COUNTS["fused"]
+    i1, d1, f1 = ops.knn_topk(qd, pd, 32, check_nan=False, return_flag=True)
+    assert ops.KNN_ROUTE_COUNTS["fused"] > c0
+    fl = int(f1.item())
+    assert int(f0.item()) == 0 and (fl & 1) == 0
+    if fl & ops.KNN_OVERFLOW:      # allowed outcome for pathological data: flagged, and the retry gives the dot-matrix result
+        i1, d1 = ops.knn_topk(qd, pd, 32)
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    assert int(i1.max()) < npool and int(i1.min()) >= 0
+    # the tied rows come out in index order (lower index first), as torch.topk's tie rule on equal distances is replayed
+    ti, td = i1[200:260], d1[200:260]
+    assert bool(((td[:, 1:] > td[:, :-1]) | (ti[:, 1:] > ti[:, :-1])).all())
+    assert int(((ti >= 9000) & (ti < 15000)).sum()) >= 60 * 16                     # the silence block supplies most of their lists
+
+
+def test_knn_nan_rows_leave_valid_indices_behind():
+    """A NaN query row has no neighbours: its list stays unfilled.  The flag is only read after the later stages have been
+    enqueued (stream pipelines), and those gather pool rows through the indices — so an unfilled place must be a valid row
+    (index 0 + offset, NaN distance), never 0xFFFFFFFF (round 3: a NaN source in a serving batch took the process down with a
+    memory fault instead of raising "containing nan")."""
+    from knn_svc_amd import ops
+    q = S.clustered_features(700, 1024, 91, n_centres=20)
+    p = S.clustered_features(9000, 1024, 92, n_centres=20)
+    q[13] = float("nan"); q[640, 100] = float("nan")
+    for fused in ("0", "1"):
+        os.environ["KNNSVC_KNN_FUSED"] = fused
+        try:
+            i, d, f = ops.knn_topk(q.to(DEV), p.to(DEV), 32, idx_offset=5, check_nan=False, return_flag=True)
+        finally:
+            os.environ.pop("KNNSVC_KNN_FUSED", None)
+        assert int(f.item()) & 1
+        assert int(i.min()) >= 5 and int(i.max()) < 9005
+        assert bool(torch.isnan(d[13]).all()) and bool((i[13] == 5).all())
+        ok = torch.ones(700, dtype=torch.bool); ok[13] = ok[640] = False
+        assert bool(torch.isfinite(d[ok.to(DEV)]).all())
 
 
 @pytest.mark.parametrize("sr,n", [(44100, 44100 + 37), (48000, 30001), (8000, 12345), (22050, 22050), (24000, 7)])

@@ -102,9 +102,10 @@ def test_request_queue_batches_and_returns_each_request_its_own_waveform(tmp_pat
 
 
 def test_request_queue_a_bad_request_fails_alone_and_one_deadline_per_batch(tmp_path):
-    """(a) a malformed request (an f0 track of the wrong length) and a poisonous one (NaN samples: the batch's kNN
-    search raises "containing nan") fail ONLY their own Futures — the other requests of the same batch are converted and equal
-    their stand-alone conversions; (b) the batching window is one deadline per batch, set by its first request: a trickle of
+    """(a) a malformed request (an f0 track of the wrong length) and a poisonous one (NaN samples) fail ONLY their
+    own Futures, at the door — the other requests of the same batch are converted and equal their stand-alone conversions; a
+    NaN source that is handed to the converter directly raises the reference's "containing nan" instead of taking the process
+    down (round 3: NaN costs left the concat re-selection without a ranking and the next frame gathered through garbage); (b) the batching window is one deadline per batch, set by its first request: a trickle of
     arrivals spaced closer than max_wait cannot hold the first request for max_batch x max_wait."""
     import time
     from knn_svc_amd import ops, serving
@@ -124,11 +125,15 @@ def test_request_queue_a_bad_request_fails_alone_and_one_deadline_per_batch(tmp_
     futs = [rq.submit(r) for r in (reqs[0], bad_f0, (nan_w, reqs[2][1]), reqs[3])]
     with pytest.raises(ValueError):
         futs[1].result(timeout=60)
-    with pytest.raises(ops.KnnSvcError):
+    with pytest.raises(ValueError):
         futs[2].result(timeout=60)
     assert torch.equal(futs[0].result(timeout=60), alone[0]) and torch.equal(futs[3].result(timeout=60), alone[3])
-    assert rq.batches == [4] and rq.isolated == 1, (rq.batches, rq.isolated)
+    assert rq.batches == [4] and rq.isolated == 0, (rq.batches, rq.isolated)
     rq.close()
+    with pytest.raises(ops.KnnSvcError):                 # not through the queue: the whole batch is enqueued, then the flag raises
+        conv.convert([reqs[0], (nan_w, reqs[2][1]), reqs[3]])
+    torch.cuda.synchronize()
+    assert torch.equal(conv.convert([reqs[3]])[0].cpu(), alone[3])                 # ... and the device is still fine
     # (b) five requests 120 ms apart with max_wait 300 ms: the first batch closes 300 ms after ITS first request
     rq = serving.RequestQueue(conv, max_batch=8, max_wait_ms=300.0)
     t0 = time.monotonic()
