@@ -38,6 +38,10 @@ const char* knnsvc_last_error(void);
 /* Short tag of the kernel the calling thread's last knnsvc_conv_gemm dispatched to ("F128a2", "W64", "G128v8", ...):
  * measurement hook (bench.py attributes HIP-event times to kernels with it); "" before the first call. */
 const char* knnsvc_conv_gemm_last_kernel(void);
+/* The dispatcher's A/B switches (KNNSVC_QUAD, KNNSVC_QUAD_EPI, KNNSVC_EPILOGUE, KNNSVC_WIN, KNNSVC_WIN_SMALL, KNNSVC_WIN_DEEP,
+ * KNNSVC_WIN160, KNNSVC_GEMM_SMALL) are read from the environment once, at the first launch; this re-reads them (tests and A/B
+ * runs that switch a route inside one process). */
+int knnsvc_reload_knobs(void);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer on fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -350,13 +354,8 @@ int knnsvc_amp_ratio(const float* spec_q, int32_t ld_q, const float* spec_pool, 
 
 /* ------------------------------------------------------------------------------------------
  * f0 front end.  The reference runs pyworld.harvest(f0_floor 65, f0_ceil 1047, frame period 20 ms) and
- * zeroes values below 80 Hz when no `<stem>_f0.npy` exists (ddsp_prematch_dataset.py:121-128, 376-379).  This is a YIN
- * estimator with that interface (frame t at sample t*hop, n_frames = L/hop + 1), NOT a restatement of Harvest: parity with
- * pyworld is unpinned (the library is absent offline).  threshold: YIN's absolute threshold (0.1 .. 0.2).
+ * zeroes values below 80 Hz when no `<stem>_f0.npy` exists (ddsp_prematch_dataset.py:121-128, 376-379).
  * ------------------------------------------------------------------------------------------ */
-int knnsvc_f0_yin(const float* x, int64_t L, int32_t sample_rate, int32_t hop, float f0_floor, float f0_ceil,
-                  float threshold, float zero_below, float* f0, int64_t n_frames, void* stream);
-
 /* Harvest (M. Morise, Interspeech 2017) — what pyworld.harvest computes where the reference calls it
  * (ddsp_prematch_dataset.py:121-128: fs = 16000, f0_floor = 65, f0_ceil = 1047, frame_period = 20 ms, then `f0[f0 < 80] = 0`;
  * :376-379 when `<stem>_f0.npy` is missing).  x: [L] fp32 at 16 kHz on the device; f0: [n_frames] fp32,

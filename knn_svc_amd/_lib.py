@@ -81,6 +81,7 @@ SIGNATURES = {
     "knnsvc_knn_refine": (i32, [vp, vp, i32, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "knnsvc_log_f0_median": (i32, [vp, i64, vp, vp, vp]),
     "knnsvc_shift_f0": (i32, [vp, i64, vp, vp, vp, vp]),
+    "knnsvc_reload_knobs": (i32, []),
     "knnsvc_f0_rerank": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "knnsvc_concat_reselect": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, i32, f32, vp, vp]),
     "knnsvc_smooth_workspace_bytes": (sz, [i64]),
@@ -88,7 +89,6 @@ SIGNATURES = {
     "knnsvc_weighted_gather": (i32, [vp, vp, i64, i32, vp, i32, i32, i32, vp, vp]),
     "knnsvc_round_f16": (i32, [vp, i64, vp, vp]),
     "knnsvc_amp_ratio": (i32, [vp, i32, vp, i32, i64, vp, i64, i32, i32, vp, vp]),
-    "knnsvc_f0_yin": (i32, [vp, i64, i32, i32, f32, f32, f32, f32, vp, i64, vp]),
     "knnsvc_flac_info": (i32, [vp, i64, vp, vp, vp, vp, vp]),
     "knnsvc_flac_decode": (i32, [vp, i64, vp, i64, vp]),
     "knnsvc_flac_encode": (i32, [vp, i32, i64, i32, i32, vp, vp, i64, vp]),

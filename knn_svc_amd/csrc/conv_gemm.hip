@@ -830,132 +830,7 @@ int launch2win(const ConvArgs& a, int batches, hipStream_t st) {
     return knnsvc_check_launch("conv_gemm2win");
 }
 
-// A2 activations + split weights, both by LDS-DMA (gemm2_core.h, Gemm2Dma)
-template <class G>
-__global__ __launch_bounds__(256, 2) void conv_gemm2dma_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    resolve_scales(a);
-    const int z = blockIdx.z;
-    const int b = z / a.groups, g = z - b * a.groups;
-    const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
-    const int gx8 = (int)gridDim.x / gy;
-    constexpr int CW = 8;
-    int L = blockIdx.x;
-    const int full = (gy / CW) * CW * gx8;
-    int c0, cw;
-    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
-    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
-    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
-    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
-    if (m0 >= a.m) return;
-    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
-    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
-
-    typename G::acc_t acc[G::TM][G::TN];
-#pragma unroll
-    for (int i = 0; i < G::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < G::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < G::NR; ++r) acc[i][j][r] = 0.f;
-    const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
-    auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
-    // wave-uniform walk over (tap, channel): 128 bytes per slab inside a tap, then on to the next tap's first channel
-    int c_in_tap = 0, uoff = 0;
-    const int cin = a.cin, step_tap = (a.dil * a.ldx - a.cin) * 4;
-    auto step = [&](int kt) -> int {
-        if (kt > 0) { c_in_tap += 32; uoff += 128; if (c_in_tap == cin) { c_in_tap = 0; uoff += step_tap; } }
-        return uoff;
-    };
-    G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
-                a.n, a.K, m0, n0, acc);
-    conv_epilogue_any<G>(a, acc, m0, n0, b, g);
-}
-
-template <class G>
-int launch2dma(const ConvArgs& a, int batches, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_gemm2dma_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                G::LDS_BYTES) != hipSuccess)
-            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
-        attr = true;
-    }
-    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
-    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2dma_kernel<G>), grid, dim3(256), G::LDS_BYTES, st, a);
-    return knnsvc_check_launch("conv_gemm2dma");
-}
-
-// A2 activations + split weights by LDS-DMA through a ring of half-slab stages (gemm2_core.h, Gemm2Ring)
-template <class G, int MINB>
-__global__ __launch_bounds__(256, MINB) void conv_gemm2ring_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    resolve_scales(a);
-    const int z = blockIdx.z;
-    const int b = z / a.groups, g = z - b * a.groups;
-    const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
-    const int gx8 = (int)gridDim.x / gy;
-    constexpr int CW = 8;
-    int L = blockIdx.x;
-    const int full = (gy / CW) * CW * gx8;
-    int c0, cw;
-    if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
-    else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
-    const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
-    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
-    if (m0 >= a.m) return;
-    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
-    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
-
-    typename G::acc_t acc[G::TM][G::TN];
-#pragma unroll
-    for (int i = 0; i < G::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < G::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < G::NR; ++r) acc[i][j][r] = 0.f;
-    const int M = a.m, row_step = a.stride * a.ldx * 4, row_pad = a.pad * a.ldx * 4;
-    auto row_off = [&](int m) -> int { return m < M ? m * row_step - row_pad : G::OOB_OFF; };
-    // wave-uniform walk over (tap, channel): 128 bytes per slab inside a tap, then on to the next tap's first channel
-    int c_in_tap = 0, uoff = 0;
-    const int cin = a.cin, step_tap = (a.dil * a.ldx - a.cin) * 4;
-    auto step = [&](int kt) -> int {
-        if (kt > 0) { c_in_tap += 32; uoff += 128; if (c_in_tap == cin) { c_in_tap = 0; uoff += step_tap; } }
-        return uoff;
-    };
-    G::mainloop(lds, a.K / 32, row_off, step, FastALoader<1>::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)),
-                a.n, a.K, m0, n0, acc);
-#ifdef KN_T_NOEPI          // timing aid: main loop only (one store per lane keeps the accumulators live)
-    { float sink = 0.f;
-#pragma unroll
-      for (int i = 0; i < G::TM; ++i)
-#pragma unroll
-          for (int j = 0; j < G::TN; ++j)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
-      if (sink == 123456.789f) a.out[threadIdx.x] = sink; }
-#else
-    conv_epilogue_lin<G>(a, acc, m0, n0, b, g);
-#endif
-}
-
-template <class G, int MINB>
-int launch2ring(const ConvArgs& a, int batches, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_gemm2ring_kernel<G, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                G::LDS_BYTES) != hipSuccess)
-            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
-        attr = true;
-    }
-    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
-    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2ring_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, a);
-    return knnsvc_check_launch("conv_gemm2ring");
-}
-
-// A2 activations + split weights by LDS-DMA, 256x256 block / 128x128 wave tiles, hand-pipelined loop (gemm2_core.h, Gemm2Quad)
+// 256x256 block / 128x128 wave tiles, hand-pipelined loop (gemm2_core.h, Gemm2QuadS): A2 activations + split weights
 // EPI: 0 = generic epilogue (conv_epilogue_wide), 1 = bias (+ split columns), 2 = bias + GELU (+ split columns), 3 = bias + residual
 template <class G, int EPI = 0>
 __global__ __launch_bounds__(256, 1) void conv_gemm2quad_kernel(ConvArgs a) {
@@ -1032,58 +907,6 @@ int launch2quad(const ConvArgs& a, int batches, hipStream_t st) {
     dim3 grid((unsigned)quad_order_ids(cdiv64(a.m, G::BM), cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm2quad_kernel<G, EPI>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2quad");
-}
-
-template <class G, bool A2>
-__global__ __launch_bounds__(G::THREADS, 1) void conv_gemm2big_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    resolve_scales(a);
-    const int z = blockIdx.z;
-    const int b = z / a.groups, g = z - b * a.groups;
-    // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2; the fp32 A panel of a
-    // row tile is re-read by every column tile, so all column tiles of one row tile get ids that are congruent mod 8
-    // (same XCD) and adjacent in dispatch order: the panel comes from HBM once and from that L2 afterwards
-    // (what-if with cache-hot A: 0.99 -> 0.87 ms on FFN2).  Ids are grouped 8 row tiles x all column tiles.
-    const int gy = (a.n + G::BN - 1) / G::BN;
-    const int L = blockIdx.x, grp = L / (8 * gy), rem = L - grp * 8 * gy;
-    const int mt = grp * 8 + (rem & 7), nt = rem >> 3;
-    const int m0 = mt * G::BM, n0 = nt * G::BN;
-    if (m0 >= a.m) return;                                    // padding of the last group
-    const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
-    const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
-
-    f32x16 acc[G::TM][G::TN];
-#pragma unroll
-    for (int i = 0; i < G::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < G::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    typedef FastALoader<G::A_F4, G::RS> AL;
-    AL al(a, m0, threadIdx.x);
-    G::template mainloop<A2>(lds, a.K / 32, al, acc, AL::desc(a, xz), uniform_rsrc(wz, (int)((long)a.n * (a.K / 32) * 128)), a.n, a.K, n0,
-                a.a_scale);
-    conv_epilogue_lin<G>(a, acc, m0, n0, b, g);      // dispatch guarantees a plain output below 2 GiB (a.lin)
-}
-
-template <class G, bool A2>
-int launch2big_v(const ConvArgs& a, int batches, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_gemm2big_kernel<G, A2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                G::LDS_BYTES) != hipSuccess)
-            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
-        attr = true;
-    }
-    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;          // row tiles padded to whole groups of 8 (one per XCD)
-    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2big_kernel<G, A2>), grid, dim3(G::THREADS), G::LDS_BYTES, st, a);
-    return knnsvc_check_launch("conv_gemm2big");
-}
-
-template <class G>
-int launch2big(const ConvArgs& a, int batches, hipStream_t st) {
-    return a.x_split ? launch2big_v<G, true>(a, batches, st) : launch2big_v<G, false>(a, batches, st);
 }
 
 template <class G, bool A2>
@@ -1171,15 +994,7 @@ using F128 = Gemm2Tile<128, 128, 2, 2, 2, 2>;
 using F64S = Gemm2Tile<64, 64, 2, 2, 1, 1>;       // launches that would put < 256 blocks of 128x128 on the chip
 using F64 = Gemm2Tile<256, 64, 4, 1, 2, 2>;
 using F32 = Gemm2Tile<256, 32, 4, 1, 2, 1>;
-using F256 = Gemm2Big<256, 256, 2, 4, 4, 2>;
-using D128 = Gemm2Dma<128, 128, 2, 2, 2, 2>;
-using R128 = Gemm2Ring<128, 128, 2, 2, 2, 2>;
-using R128x2 = Gemm2Ring<128, 128, 2, 2, 2, 2, 2>;
-using Q256 = Gemm2QuadR;          // register-staged, 32x32x16 MFMA (KNNSVC_QUAD16=0)
-using Q256D = Gemm2Quad<4>;        // LDS-DMA ring (KNNSVC_QUAD_DMA=1, A/B)
-using Q256S = Gemm2QuadS;          // 16x16x32 MFMA, 32-k slabs (default)
-using R512 = Gemm2Ring<256, 256, 2, 2, 4, 4, 3>;       // 128x128 wave tiles, 256 accumulator registers, one block per CU
-using R256 = Gemm2Ring<256, 128, 2, 2, 4, 2, 3>;       // 128x64 wave tiles, 72 KB ring: two blocks per CU     // 2-stage ring: 32 KB, four blocks per CU
+using Q256S = Gemm2QuadS;          // 256x256 block, 16x16x32 MFMA, 32-k slabs
 using W128 = Gemm2Win<128, 128, 2, 2, 2, 2, 64>;      // window 192 rows (27 KB) + weights 18 KB: 3 blocks / CU
 using W160 = Gemm2Win<160, 128, 1, 4, 5, 1, 64>;      // 224-row window (32 KB) + 18 KB: still 3 blocks / CU; see the dispatch rule
 using W128S = Gemm2Win<64, 128, 2, 2, 1, 2, 64>;      // short time axes (first generator stage): twice the blocks, 37 KB
@@ -1210,7 +1025,37 @@ int prepare() {   // opt in to > 64 KiB of dynamic LDS once per kernel
     return 0;
 }
 
+// A/B switches of the dispatcher, read from the environment ONCE (first launch) into this struct; knnsvc_reload_knobs() re-reads
+// them (tests that switch a route inside one process call it through ops.reload_knobs()).  Round 3 called getenv ~10 times per
+// launch.  Defaults are the product configuration; none of these changes results beyond what its comment says.
+struct Knobs {
+    int quad = 1;                  // KNNSVC_QUAD: 0 = no 256x256 kernel, 1 = by shape (default), 2 = every qualifying launch
+    bool quad_epi = true;          // KNNSVC_QUAD_EPI=0: generic epilogue behind the quad kernel (bit-identical, slower)
+    bool generic_epilogue = false; // KNNSVC_EPILOGUE=g: the generic (64-bit addressed) epilogue everywhere
+    bool win = true;               // KNNSVC_WIN=0: tap-major kernel instead of the windowed one (other summation order)
+    bool win_small = true, win_deep = true, win160 = true;      // KNNSVC_WIN_SMALL / _DEEP / WIN160 = 0: tile-shape rules off
+    bool gemm_small = true;        // KNNSVC_GEMM_SMALL=0: no 64x64 tile for launches below one round of 128x128 tiles
+    bool loaded = false;
+};
+Knobs g_knobs;
+bool env_off(const char* name) { const char* e = getenv(name); return e && e[0] == '0'; }
+void load_knobs() {
+    Knobs k;
+    const char* q = getenv("KNNSVC_QUAD");
+    k.quad = q ? atoi(q) : 1;
+    k.quad_epi = !env_off("KNNSVC_QUAD_EPI");
+    const char* ep = getenv("KNNSVC_EPILOGUE");
+    k.generic_epilogue = ep && ep[0] == 'g';
+    k.win = !env_off("KNNSVC_WIN"); k.win_small = !env_off("KNNSVC_WIN_SMALL"); k.win_deep = !env_off("KNNSVC_WIN_DEEP");
+    k.win160 = !env_off("KNNSVC_WIN160"); k.gemm_small = !env_off("KNNSVC_GEMM_SMALL");
+    k.loaded = true;
+    g_knobs = k;
+}
+const Knobs& knobs() { if (!g_knobs.loaded) load_knobs(); return g_knobs; }
+
 }  // namespace
+
+extern "C" int knnsvc_reload_knobs(void) { load_knobs(); return KNNSVC_OK; }
 
 extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     KN_REQUIRE(d && d->x && d->w && d->out, "conv_gemm: null operand");
@@ -1254,7 +1099,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     a.x_split = d->x_f16x2; a.out_split = d->out_f16x2 != 0; a.split_from = d->out_f16x2 > 1 ? d->out_f16x2 : 0;
     KN_REQUIRE(d->out_f16x2 >= 0 && (d->out_f16x2 <= 1 || d->out_f16x2 % 32 == 0), "conv_gemm: out_f16x2 is 0, 1 or the first split column (a multiple of 32)");
     a.lin = !d->convt_u && (long)d->m * d->ldo * 4 < (1L << 31) && (!d->resid || (long)d->m * d->ldr * 4 < (1L << 31)) &&
-            !(getenv("KNNSVC_EPILOGUE") && getenv("KNNSVC_EPILOGUE")[0] == 'g');      // KNNSVC_EPILOGUE=g: generic epilogue (A/B)
+            !knobs().generic_epilogue;      // KNNSVC_EPILOGUE=g: generic epilogue (A/B)
 
     // 16-byte vector path needs every float4 of A and W to be aligned and inside one tap
     const bool vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
@@ -1286,51 +1131,23 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         a.x_absmax = d->x_absmax; a.w_absmax = d->w_absmax;      // device-side scales override the two above
         a.x_bound_mul = d->x_bound_mul > 0.f ? d->x_bound_mul : 1.0f; a.x_bound_add = d->x_bound_add;
         KN_REQUIRE(d->x_bound_add >= 0.f && d->x_bound_mul >= 0.f, "conv_gemm: x_bound_mul / x_bound_add must be non-negative");
-        // 256x256 double-buffered tile with LDS-DMA weights (one block per CU): fewer L2/LDS bytes per MFMA and a
-        // higher sustained clock (1.65 vs 1.39 GHz) — 279 vs 242 TFLOP/s on an isolated long-K GEMM (FFN2), but a lone
-        // block per CU cannot hide its prologue/epilogue and loses when other streams share the chip (end-to-end bench:
-        // 505 vs 511 xRT), so it is opt-in: KNNSVC_F256_KMIN=<smallest K that takes it> (read per qualifying launch).
-        if (d->n >= 256 && d->n % 256 == 0 && a.K >= 1024 && a.lin) {
-            const char* e = getenv("KNNSVC_F256_KMIN");
-            if (e && a.K >= atoi(e) && cdiv64(a.m, 256) * (d->n / 256) * d->batches * d->groups >= 384)
-                { g_last_kernel = "F256"; return launch2big<F256>(a, d->batches, st); }
-        }
         const bool quad_ok = a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
             (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
             d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
             d->bias_gstride % 4 == 0;
         KN_REQUIRE(d->fixed_tile != 2 || quad_ok, "conv_gemm: fixed_tile 2 needs the quad kernel's operand layout (split A, 16-byte rows, n % 4 == 0)");
         if (d->fixed_tile != 1 && quad_ok) {
-            // 256x256 block, 128x128 wave tiles, hand-pipelined loop: KNNSVC_QUAD=0 switches it off, =2 forces it for every
-            // qualifying launch.  Default kernel: Gemm2QuadS (v_mfma_f32_16x16x32_f16, 32-k slabs); KNNSVC_QUAD16=0 selects its
-            // predecessor Gemm2QuadR (32x32x16, 16-k half slabs), KNNSVC_QUAD_DMA=1 the LDS-DMA ring.  Default rule: K >= 1024
-            // and at least ~two rounds of tiles over the chip.  Measured under sustained load with the real epilogues
-            // (tools/quad16_ab.sh; QuadS / QuadR / 128x128 kernel, TFLOP/s): FFN2 437 / 381 / 340, QKV 374 / 324 / 328,
-            // FFN1 (GELU) 316 / 283 / 316 — with the 16x16x32 MFMA the quad tile wins or ties everywhere, so every large GEMM of
-            // the encoder takes it (end to end 649 -> 680 xRT).  KNNSVC_QUAD_KMIN / KNNSVC_QUAD_GELU=0 restore the old rule
-            // (K >= 1536, no transcendental epilogue) for A/B runs.
-            const char* qe = getenv("KNNSVC_QUAD");      // read per launch: tests and A/B runs switch it inside one process
-            const int quad = qe ? atoi(qe) : 1;
-            const long tiles = cdiv64(a.m, 256) * cdiv64(d->n, 256) * d->batches * d->groups;
-            const char* qk = getenv("KNNSVC_QUAD_KMIN");
-            const int kmin = qk ? atoi(qk) : 1024;
-            const char* qg = getenv("KNNSVC_QUAD_GELU");
-            const bool transc_ok = !(qg && qg[0] == '0') || (d->act != KNNSVC_ACT_GELU && d->act != KNNSVC_ACT_TANH);
+            // 256x256 block, 128x128 wave tiles, hand-pipelined loop (Gemm2QuadS: v_mfma_f32_16x16x32_f16, 32-k slabs): every A2
+            // launch with K >= 1024 and n >= 256 — FFN1 / FFN2 / QKV / out-proj, the conv stack, the kNN's dot matrix.
+            // KNNSVC_QUAD=0 switches it off, =2 forces it for every qualifying launch (tests, A/B runs).
             // The rule looks at the layer's shape (n, K) only, never at m or the batch: the quad kernel sums over K in another
-            // grouping than the 128x128 kernels, so a rule that counted tiles (round 2: >= 448) made an utterance's features depend,
-            // in their last bits, on how many chunks were encoded with it — enough to flip near-tied neighbours and to make a
-            // source converted in a batch differ from the same source converted alone (tests/test_gpu_product.py).
-            // KNNSVC_QUAD_MIN_TILES restores a tile threshold for A/B runs.
-            const char* qt = getenv("KNNSVC_QUAD_MIN_TILES");
-            const long min_tiles = qt ? atol(qt) : 0;
-            if (d->fixed_tile == 2 || quad == 2 || (quad == 1 && d->n >= 256 && tiles >= min_tiles && a.K >= kmin && transc_ok)) {
-                const char* qd = getenv("KNNSVC_QUAD_DMA");
-                if (qd && qd[0] == '1' && d->fixed_tile != 2) { g_last_kernel = "Q256D"; return launch2quad<Q256D>(a, d->batches, st); }
-                const char* q16 = getenv("KNNSVC_QUAD16");
-                if (q16 && q16[0] == '0' && d->fixed_tile != 2) { g_last_kernel = "Q256"; return launch2quad<Q256>(a, d->batches, st); }
+            // grouping than the 128x128 kernels, so a rule that counted tiles (round 2) made an utterance's features depend, in
+            // their last bits, on how many chunks were encoded with it — enough to flip near-tied neighbours and to make a source
+            // converted in a batch differ from the same source converted alone (tests/test_gpu_product.py).
+            const Knobs& kb = knobs();
+            if (d->fixed_tile == 2 || kb.quad == 2 || (kb.quad == 1 && d->n >= 256 && a.K >= 1024)) {
                 // specialised epilogues (conv_epilogue_wide_fast): bias (+ split), GELU (+ split), residual; KNNSVC_QUAD_EPI=0: generic
-                const char* qf = getenv("KNNSVC_QUAD_EPI");
-                const bool fast_epi = !(qf && qf[0] == '0') && !d->accumulate && a.div == 1.0f && !a.out_absmax &&
+                const bool fast_epi = kb.quad_epi && !d->accumulate && a.div == 1.0f && !a.out_absmax &&
                                       (d->act == KNNSVC_ACT_NONE || d->act == KNNSVC_ACT_GELU) && !(d->resid && d->act != KNNSVC_ACT_NONE);
                 g_last_kernel = "Q256S";
                 if (fast_epi && d->resid) return launch2quad<Q256S, 3>(a, d->batches, st);
@@ -1339,30 +1156,15 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
                 return launch2quad<Q256S>(a, d->batches, st);
             }
         }
-        if (d->n > 64 && a.x_split) {
-            // Opt-in (KNNSVC_DMA=1): both operands by LDS-DMA, double-buffered, 2 blocks/CU.  Measured 252 vs 275 TFLOP/s
-            // for the register-staged A2 kernel on FFN1: with one slab of prefetch the vmcnt(0) + barrier at the end
-            // of every slab exposes the DMA latency; it needs a 3-stage ring (1 block/CU) to pay.
-            const char* e = getenv("KNNSVC_DMA");
-            if (e && e[0] == '1') { g_last_kernel = "D128"; return launch2dma<D128>(a, d->batches, st); }
-            const char* r = getenv("KNNSVC_RING");
-            if (d->convt_u || (long)d->m * d->ldo * 4 >= (1L << 31) || (d->resid && (long)d->m * d->ldr * 4 >= (1L << 31))) r = nullptr;
-            if (r && r[0] == '1') { g_last_kernel = "R128"; return launch2ring<R128, 3>(a, d->batches, st); }
-            if (r && r[0] == '2') { g_last_kernel = "R128x2"; return launch2ring<R128x2, 4>(a, d->batches, st); }
-            if (r && r[0] == '3') { g_last_kernel = "R256"; return launch2ring<R256, 2>(a, d->batches, st); }
-            if (r && r[0] == '4') { g_last_kernel = "R512"; return launch2ring<R512, 1>(a, d->batches, st); }
-
-        }
         // stride-1 multi-tap convolutions on fp32 input: windowed kernel (A staged once per channel slab, not once per tap)
         if (!a.x_split && !d->convt_u && d->stride == 1 && d->taps >= 3 && d->dil >= 1 && d->ldx % 4 == 0) {
-            static const bool win_on = [] { const char* e = getenv("KNNSVC_WIN"); return !(e && e[0] == '0'); }();
+            const bool win_on = knobs().win;
             const int halo = (d->taps - 1) * d->dil;
             if (win_on && halo <= 64) {
                 if (d->n > 64) {
                     // fewer than ~2/3 of the chip's 768 resident slots at 128-row tiles: halve the tile height
-                    static const bool small_on = [] { const char* e = getenv("KNNSVC_WIN_SMALL"); return !(e && e[0] == '0'); }();
-                    if (small_on && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 512) {
-                        static const bool deep_on = [] { const char* e = getenv("KNNSVC_WIN_DEEP"); return !(e && e[0] == '0'); }();
+                    if (knobs().win_small && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 512) {
+                        const bool deep_on = knobs().win_deep;
                         // two steps of weight prefetch where a launch leaves at most one workgroup per CU (nothing else hides the L2
                         // round trip: 3750 x 256, k = 11: 70 -> 59 us); with more workgroups per CU the neighbours already do and the
                         // second register set only costs (15 000 x 256, k = 7: 61 -> 66 us).  Same products, same order: same bits.
@@ -1374,7 +1176,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
                     // Tile-count quantisation: 768 blocks are resident at once (3 per CU); a launch of 938 128-row tiles (the
                     // generator's C = 128 stage at 30 s: 120 000 rows) runs two rounds, the second 22 % full.  160-row tiles make
                     // it 750 — one round.  Pick the height with the fewer (rounds x rows per round).  KNNSVC_WIN160=0: off.
-                    static const bool w160_on = [] { const char* e = getenv("KNNSVC_WIN160"); return !(e && e[0] == '0'); }();
+                    const bool w160_on = knobs().win160;
                     const long z = (long)d->batches * d->groups * cdiv64(d->n, 128);
                     const long r128 = cdiv64(cdiv64(d->m, 128) * z, 768) * 128, r160 = cdiv64(cdiv64(d->m, 160) * z, 768) * 160;
                     if (w160_on && r160 < r128) { g_last_kernel = "W160"; return launch2win<W160, 3>(a, d->batches, st); }
@@ -1387,8 +1189,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             if (win_on && halo <= 128 && d->n > 32 && d->n <= 64) { g_last_kernel = "W64P"; return launch2win<W64P, 2>(a, d->batches, st); }
         }
         if (d->n > 64 && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 256) {
-            static const bool small_on = [] { const char* e = getenv("KNNSVC_GEMM_SMALL"); return !(e && e[0] == '0'); }();
-            if (small_on) { g_last_kernel = "F64S"; return launch2<F64S>(a, d->batches, st); }
+            if (knobs().gemm_small) { g_last_kernel = "F64S"; return launch2<F64S>(a, d->batches, st); }
         }
         g_last_kernel = d->n > 64 ? (a.x_split ? "F128a2" : "F128") : d->n > 32 ? "F64" : "F32";
         if (d->n > 64) return launch2<F128>(a, d->batches, st);

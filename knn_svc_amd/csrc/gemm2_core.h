@@ -215,761 +215,6 @@ struct Gemm2Tile {
 };
 
 // -------------------------------------------------------------------------------------------------
-// Large-tile variant: WM x WN waves (NT = 64 WM WN threads, one block per CU), double-buffered LDS,
-// ONE barrier per K slab.  At 128x128 the LDS port and the vector-memory path are each busy ~70-90 % of
-// the MFMA time of a slab and the three interfere; a 256x256 block halves both per MFMA and the chip
-// holds a higher clock on it (1.65 vs 1.39 GHz measured).
-//   A: fp32 from HBM -> registers (one slab ahead) -> split -> LDS rows of 144 B (as Gemm2Tile).
-//   B: the pre-split weights go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no VGPRs and no
-//      ds_write: the VGPR->LDS store path moves only ~80 B/clk per CU and was the largest stall of the slab
-//      (what-if build without staging: 380 vs 284 TFLOP/s).  A DMA instruction fills 1 KiB of CONTIGUOUS LDS
-//      (lane L -> base + 16 L), so B rows are unpadded (128 B) and bank conflicts are avoided by an XOR
-//      swizzle instead: 16-byte piece q of row r lives in slot q ^ ((r >> 1) & 7); the DMA applies it through
-//      its per-lane SOURCE address, the fragment reads through their LDS address.
-// Order inside a slab: DMA of B(kt+1) first, A loads of kt+2 later; vmcnt completes in issue order, so
-// `s_waitcnt vmcnt(#A loads)` before the barrier guarantees the DMA has landed while the A loads stay in flight.
-// -------------------------------------------------------------------------------------------------
-template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
-struct Gemm2Big {
-    typedef f32x16 acc_t;
-    static constexpr int NR = 16;               // accumulator elements per MFMA tile and lane
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
-    static constexpr int BK = 32, PITCH = 144, BROW = 128, NW = WM * WN, THREADS = 64 * NW, RS = THREADS / 8;
-    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    static_assert(BM % RS == 0 && (BN * BROW) % (1024 * NW) == 0, "staging shape");
-    static_assert(TM % 2 == 0, "row tiles alternate between two fragment slots");
-    static constexpr int A_F4 = BM / RS;                       // fp32 float4 per thread per slab
-    static constexpr int B_DMA = BN * BROW / 1024 / NW;        // LDS-DMA instructions per wave per slab
-    static constexpr int BOFF = BM * PITCH;                    // B region inside a buffer
-    static constexpr int BUF = BOFF + BN * BROW;
-    static constexpr int LDS_BYTES = 2 * BUF;
-    static constexpr int OOB_OFF = 0x40000000;
-
-    typedef __attribute__((address_space(3))) char lds_c;
-    typedef __attribute__((address_space(3))) void lds_v;
-    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
-    typedef __attribute__((address_space(3))) g2_u32x2 lds_u2;
-
-    __device__ __forceinline__ static void wait_vm(bool keep_a_loads) {   // all but the A_F4 youngest VMEM ops done
-        if (keep_a_loads) __builtin_amdgcn_s_waitcnt(0x0F70 | A_F4);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-    }
-
-    // aload: fp32 A loader (begin(kt), operator()(kt, j, desc), finish()); rb_desc: buffer resource over the split
-    // weights of this group ([N][K/32][2][32] fp16); n0: first weight row of the block
-    // A2: the activations already are in the f16x2 split layout — staging is a 16-byte copy (as Gemm2Tile's A2 path)
-    template <bool A2 = false, class ALoad, class RA, class RB>
-    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, ALoad& aload, f32x16 (&acc)[TM][TN],
-                                                    RA ra_desc, RB rb_desc, int N, int K, int n0, float a_scale) {
-        static_assert(A_F4 < 16, "vmcnt immediate");
-        static_assert(B_DMA <= TM, "the DMA pieces are issued in the first k-step, before the early waves reload A");
-        lds_c* lds = (lds_c*)lds_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave / WN, wn = wave % WN;
-        const int a_st = (tid >> 3) * PITCH + (tid & 7) * (A2 ? 16 : 8);
-        const int li = lane & 31, lh = lane >> 5;
-        const int a_frag = (wm * TM * 32 + li) * PITCH + lh * 16;
-        const int b_row = BOFF + (wn * TN * 32 + li) * BROW;
-        const int swz = (li >> 1) & 7;
-        int b_x[2][2];                                             // [k-step][plane]: swizzled slot offset of this lane's piece
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) b_x[ks][p] = ((p * 4 + ks * 2 + lh) ^ swz) * 16;
-        int b_src[B_DMA];                                          // per-lane source byte offset of each DMA piece (slab 0)
-        const int row_bytes = (K / 32) * 128;
-#pragma unroll
-        for (int t = 0; t < B_DMA; ++t) {
-            const int row = (wave * B_DMA + t) * 8 + (lane >> 3);
-            const int piece = (lane & 7) ^ ((row >> 1) & 7);
-            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + piece * 16 : OOB_OFF;
-        }
-        const bool early = wave < NW / 2;        // waves w and w + NW/2 share a SIMD (cyclic wave -> SIMD assignment)
-
-        f32x4 ra[A_F4];
-        f16x8 fa[2][2], fb[2][TN][2];
-#define KN_DMA_B1(BUFOFF, KT, T)                                                                              \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + (BUFOFF) + BOFF + (wave * B_DMA + (T)) * 1024), 16, \
-                                             b_src[T], (KT) * 128, 0, 0);
-#define KN_DMA_B(BUFOFF, KT) _Pragma("unroll") for (int t = 0; t < B_DMA; ++t) { KN_DMA_B1(BUFOFF, KT, t) }
-#define KN_LOAD_A(KT)                                                                                         \
-    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) ra[j] = aload(KT, j, ra_desc);
-#if defined(KN_WHATIF_SINK_SPLIT)
-#define KN_STAGE_A(BUFOFF)                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                       \
-        g2_u32x2 hi, lo;                                                                                     \
-        f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                                  \
-        asm volatile("" ::"v"(hi[0]), "v"(hi[1]), "v"(lo[0]), "v"(lo[1]));                                   \
-    }
-#elif defined(KN_WHATIF_SINK_RAW)
-#define KN_STAGE_A(BUFOFF)                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                       \
-        asm volatile("" ::"v"(ra[j][0]), "v"(ra[j][1]), "v"(ra[j][2]), "v"(ra[j][3]));                       \
-    }
-#else
-#define KN_STAGE_A(BUFOFF)                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                                       \
-        if constexpr (A2) {                                                                                  \
-            *(lds_u4*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = __builtin_bit_cast(g2_u32x4, ra[j]);        \
-        } else {                                                                                             \
-            g2_u32x2 hi, lo;                                                                                 \
-            f16x2_split4(aload.finish(ra[j]), a_scale, hi, lo);                                              \
-            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH) = hi;                                         \
-            *(lds_u2*)(lds + (BUFOFF) + a_st + RS * j * PITCH + 64) = lo;                                    \
-        }                                                                                                    \
-    }
-#endif
-#define KN_RD_A(BUFOFF, KS, I, SLOT)                                                                          \
-    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                            \
-        fa[SLOT][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + a_frag + (I) * 32 * PITCH + p * 64 + (KS) * 32));
-#define KN_RD_B(BUFOFF, KS)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                           \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                        \
-            fb[KS][i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + b_row + i * 32 * BROW + b_x[KS][p]));
-#define KN_MFMA_ROW(KS, I, SLOT)                                                                              \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
-        f32x16 c = acc[I][j];                                                                                \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][1], fb[KS][j][0], c, 0, 0, 0);                   \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][1], c, 0, 0, 0);                   \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][0], c, 0, 0, 0);                   \
-        acc[I][j] = c;                                                                                       \
-    }
-        aload.begin(0);
-        KN_LOAD_A(0)
-        __builtin_amdgcn_sched_barrier(0);
-        KN_DMA_B(0, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        KN_STAGE_A(0)
-        if (nk > 1) { aload.begin(1); KN_LOAD_A(1) }
-        __builtin_amdgcn_sched_barrier(0);
-        wait_vm(nk > 1);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = (kt & 1) * BUF, nxt = BUF - cur;
-            const bool st = kt + 1 < nk, ld = kt + 2 < nk;
-            KN_RD_B(cur, 0) KN_RD_A(cur, 0, 0, 0)
-            if (ld) aload.begin(kt + 2);
-            // 2 TM row steps; step r issues the fragment reads of step r+1, then its own 3 TN MFMAs
-#pragma unroll
-            for (int r = 0; r < 2 * TM; ++r) {
-                const int ks = r / TM, i = r % TM;
-                if (i + 1 < TM) { KN_RD_A(cur, ks, i + 1, (i + 1) & 1) }
-                else if (ks == 0) { KN_RD_B(cur, 1) KN_RD_A(cur, 1, 0, 0) }
-                __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
-                KN_MFMA_ROW(ks, i, i & 1)
-                __builtin_amdgcn_sched_barrier(0);
-                // one DMA piece of B(kt+1) behind each of the first row steps (its ~100-cycle issue hides under the
-                // six MFMAs just queued); all of them precede this wave's A loads of the slab (see wait_vm)
-#ifndef KN_WHATIF_NODMA
-                if (r < B_DMA && st) { KN_DMA_B1(nxt, kt + 1, r) }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                // The two waves of a SIMD (w and w + NW/2) stage A at different times — one between the k-steps, the
-                // other after the second — so one of them is always issuing MFMAs while the other splits and stores.
-                if ((r == TM - 1 && early) || (r == 2 * TM - 1 && !early)) {
-#ifndef KN_WHATIF_NOSTAGE_A
-                    if (st) { KN_STAGE_A(nxt) }
-#endif
-                    if (ld) { KN_LOAD_A(kt + 2) }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            wait_vm(ld);
-            __syncthreads();
-        }
-#undef KN_DMA_B
-#undef KN_DMA_B1
-#undef KN_LOAD_A
-#undef KN_STAGE_A
-#undef KN_RD_A
-#undef KN_RD_B
-#undef KN_MFMA_ROW
-    }
-
-    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
-        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    }
-    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
-        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
-    }
-};
-
-// -------------------------------------------------------------------------------------------------
-// DMA-fed variant for pre-split activations ("A2" layout): BOTH operands go global -> LDS by LDS-DMA
-// (buffer_load_dwordx4 ... lds) into unpadded, XOR-swizzled 128-byte rows; no staging registers, no VALU
-// split, no ds_write.  4 waves, double-buffered LDS (2 x 32 KB at 128x128: two blocks per CU), one barrier
-// per K slab: the DMA of slab kt+1 is issued piece by piece behind the MFMA groups of slab kt and
-// `s_waitcnt vmcnt(0)` + the barrier at the end of the slab publish it.  What-if builds put the operand
-// delivery of the register-staged kernel at 34 % of its time (19 % A, 10 % B); this removes the VALU,
-// LDS-store and register-wait parts of it.
-//   image: row r = 128 bytes = 8 pieces of 16 B (hi plane pieces 0-3, lo plane 4-7); piece q sits in slot
-//   q ^ ((r >> 1) & 7).  DMA instruction c of a slab fills rows 8c..8c+7 (lane L -> row 8c + L/8, slot L%8)
-//   and applies the swizzle through its per-lane SOURCE offset.
-// The A side takes the implicit-GEMM view of the conv kernel: per-lane row offsets + a wave-uniform
-// (tap, channel) offset advanced slab by slab; rows in the conv padding or past M fall outside the buffer
-// resource and land as zeros.
-// -------------------------------------------------------------------------------------------------
-template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_>
-struct Gemm2Dma {
-    typedef f32x16 acc_t;
-    static constexpr int NR = 16;               // accumulator elements per MFMA tile and lane
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_;
-    static constexpr int BK = 32, BROW = 128, NW = WM * WN, THREADS = 64 * NW;
-    static_assert(NW == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    static_assert(TM % 2 == 0, "row tiles alternate between two fragment slots");
-    static constexpr int A_DMA = BM * BROW / 1024 / NW;        // LDS-DMA instructions per wave per slab (A, B)
-    static constexpr int B_DMA = BN * BROW / 1024 / NW;
-    static_assert(A_DMA * 1024 * NW == BM * BROW && B_DMA * 1024 * NW == BN * BROW, "whole DMA pieces");
-    static constexpr int BOFF = BM * BROW;
-    static constexpr int BUF = (BM + BN) * BROW;
-    static constexpr int LDS_BYTES = 2 * BUF;
-    static constexpr int OOB_OFF = 0x40000000;
-
-    typedef __attribute__((address_space(3))) char lds_c;
-    typedef __attribute__((address_space(3))) void lds_v;
-    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
-
-    // a_row_off(m): byte offset of row m's first channel in the A buffer resource, or OOB_OFF (evaluated per lane once);
-    // a_step(kt): wave-uniform byte offset of slab kt (tap / channel walk)
-    template <class RowOff, class Step, class RA, class RB>
-    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
-                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
-        lds_c* lds = (lds_c*)lds_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave / WN, wn = wave % WN;
-        const int li = lane & 31, lh = lane >> 5;
-        const int swz = (li >> 1) & 7;
-        const int a_row = (wm * TM * 32 + li) * BROW;
-        const int b_row = BOFF + (wn * TN * 32 + li) * BROW;
-        int x_off[2][2];                                           // [k-step][plane]: swizzled slot of this lane's piece
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) x_off[ks][p] = ((p * 4 + ks * 2 + lh) ^ swz) * 16;
-        int a_src[A_DMA], b_src[B_DMA];
-        const int row_bytes = (K / 32) * 128;
-#pragma unroll
-        for (int t = 0; t < A_DMA; ++t) {
-            const int row = (wave * A_DMA + t) * 8 + (lane >> 3);
-            const int ro = a_row_off(m0 + row);
-            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
-        }
-#pragma unroll
-        for (int t = 0; t < B_DMA; ++t) {
-            const int row = (wave * B_DMA + t) * 8 + (lane >> 3);
-            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (((lane & 7) ^ ((row >> 1) & 7)) * 16) : OOB_OFF;
-        }
-        f16x8 fa[2][2], fb[2][TN][2];
-#define KN_DMA_A1(BUFOFF, UOFF, T)                                                                            \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_desc, (lds_v*)(lds + (BUFOFF) + (wave * A_DMA + (T)) * 1024), 16, a_src[T] + (UOFF), 0, 0, 0);   /* slab offset in the VGPR offset: the range check ignores soffset, and conv padding relies on it */
-#define KN_DMA_B1(BUFOFF, KT, T)                                                                              \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + (BUFOFF) + BOFF + (wave * B_DMA + (T)) * 1024), 16, b_src[T], (KT) * 128, 0, 0);
-#define KN_RD_A(BUFOFF, KS, I, SLOT)                                                                          \
-    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                            \
-        fa[SLOT][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + a_row + (I) * 32 * BROW + x_off[KS][p]));
-#define KN_RD_B(BUFOFF, KS)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                           \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                        \
-            fb[KS][i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (BUFOFF) + b_row + i * 32 * BROW + x_off[KS][p]));
-#define KN_MFMA_ROW(KS, I, SLOT)                                                                              \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
-        f32x16 c = acc[I][j];                                                                                \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][1], fb[KS][j][0], c, 0, 0, 0);                   \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][1], c, 0, 0, 0);                   \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SLOT][0], fb[KS][j][0], c, 0, 0, 0);                   \
-        acc[I][j] = c;                                                                                       \
-    }
-        {
-            const int u0 = a_step(0);
-#pragma unroll
-            for (int t = 0; t < A_DMA; ++t) { KN_DMA_A1(0, u0, t) }
-#pragma unroll
-            for (int t = 0; t < B_DMA; ++t) { KN_DMA_B1(0, 0, t) }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        constexpr int STEPS = 2 * TM;                               // row steps of a slab
-#ifdef KN_DMA_EARLY
-        constexpr int PER = A_DMA + B_DMA;                          // all pieces behind the first row step
-#else
-        constexpr int PER = (A_DMA + B_DMA + STEPS - 1) / STEPS;    // DMA pieces issued behind each row step
-#endif
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = (kt & 1) * BUF, nxt = BUF - cur;
-            const bool st = kt + 1 < nk;
-            const int un = st ? a_step(kt + 1) : 0;
-            KN_RD_B(cur, 0) KN_RD_A(cur, 0, 0, 0)
-#pragma unroll
-            for (int r = 0; r < STEPS; ++r) {
-                const int ks = r / TM, i = r % TM;
-                if (i + 1 < TM) { KN_RD_A(cur, ks, i + 1, (i + 1) & 1) }
-                else if (ks == 0) { KN_RD_B(cur, 1) KN_RD_A(cur, 1, 0, 0) }
-                __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
-                KN_MFMA_ROW(ks, i, i & 1)
-                __builtin_amdgcn_sched_barrier(0);
-                if (st) {                               // slab kt+1 -> idle buffer, a few pieces behind every MFMA group
-#pragma unroll
-                    for (int e = 0; e < PER; ++e) {
-                        const int t = r * PER + e;
-                        if (t < A_DMA) { KN_DMA_A1(nxt, un, t) }
-                        else if (t < A_DMA + B_DMA) { KN_DMA_B1(nxt, kt + 1, t - A_DMA) }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's pieces of slab kt+1 have landed
-            __syncthreads();
-        }
-#undef KN_DMA_A1
-#undef KN_DMA_B1
-#undef KN_RD_A
-#undef KN_RD_B
-#undef KN_MFMA_ROW
-    }
-
-    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
-        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    }
-    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
-        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
-    }
-};
-
-// -------------------------------------------------------------------------------------------------
-// Ring variant of the DMA-fed kernel: K advances in HALF slabs of 16 (64 bytes per operand row: 32 B of the hi
-// plane + 32 B of the lo plane), staged in a ring of STAGES buffers with TWO half-slabs of prefetch.  At 128x128 a
-// stage is 16 KB and the ring 48 KB, so three blocks still fit a CU (the double-buffered 32-wide Gemm2Dma holds two
-// and exposes its DMA latency at the end of every slab).  One barrier per half slab, 12 MFMAs per wave between two.
-//   image: row r = 64 bytes = 4 pieces of 16 B (hi k 0-7, hi k 8-15, lo k 0-7, lo k 8-15); piece q sits in slot
-//   q ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then cover
-//   all 64 banks exactly once.  DMA instruction c of a stage fills rows 16c..16c+15 (lane L -> row 16c + L/4,
-//   slot L%4) and applies the swizzle through its per-lane SOURCE offset.
-//   schedule: iteration s issues the DMA of half slab s+2 into the stage that was read in iteration s-1 (every wave
-//   is past that iteration's barrier), computes half slab s, waits with vmcnt(#pieces of s+2) for its own pieces of
-//   s+1, barrier.
-// -------------------------------------------------------------------------------------------------
-template <int BM_, int BN_, int WM_, int WN_, int TM_, int TN_, int STAGES_ = 3>
-struct Gemm2Ring {
-    typedef f32x16 acc_t;
-    static constexpr int NR = 16;
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, TM = TM_, TN = TN_, STAGES = STAGES_;
-    static constexpr int BK = 16, ROW = 64, NW = WM * WN, THREADS = 64 * NW;
-    static_assert(NW == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    static constexpr int A_DMA = BM * ROW / 1024 / NW;         // LDS-DMA instructions per wave per half slab
-    static constexpr int B_DMA = BN * ROW / 1024 / NW;
-    static_assert(A_DMA * 1024 * NW == BM * ROW && B_DMA * 1024 * NW == BN * ROW, "whole DMA pieces");
-    static constexpr int PER = A_DMA + B_DMA;
-    static_assert(PER < 16, "vmcnt immediate");
-    static constexpr int BOFF = BM * ROW;
-    static constexpr int STAGE = (BM + BN) * ROW;
-    static constexpr int LDS_BYTES = STAGES * STAGE;
-    static constexpr int OOB_OFF = 0x40000000;
-
-    typedef __attribute__((address_space(3))) char lds_c;
-    typedef __attribute__((address_space(3))) void lds_v;
-    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
-
-    // a_row_off(m): byte offset of row m's first channel in the A buffer resource, or OOB_OFF; a_step(kt): wave-uniform
-    // byte offset of the 32-channel slab kt (stateful: called once per kt, in order)
-    template <class RowOff, class Step, class RA, class RB>
-    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
-                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
-        lds_c* lds = (lds_c*)lds_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave / WN, wn = wave % WN;
-        const int li = lane & 31, lh = lane >> 5;
-        const int swz = (li >> 2) & 3;
-        const int a_row = (wm * TM * 32 + li) * ROW;
-        const int b_row = BOFF + (wn * TN * 32 + li) * ROW;
-        int x_off[2];                                              // [plane]: swizzled slot of this lane's k-half
-#pragma unroll
-        for (int p = 0; p < 2; ++p) x_off[p] = ((p * 2 + lh) ^ swz) * 16;
-        int a_src[A_DMA], b_src[B_DMA];
-        const int row_bytes = (K / 32) * 128;
-#pragma unroll
-        for (int t = 0; t < A_DMA; ++t) {
-            const int row = (wave * A_DMA + t) * 16 + (lane >> 2);
-            const int q = (lane & 3) ^ ((row >> 2) & 3);
-            const int ro = a_row_off(m0 + row);
-            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (q >> 1) * 64 + (q & 1) * 16;
-        }
-#pragma unroll
-        for (int t = 0; t < B_DMA; ++t) {
-            const int row = (wave * B_DMA + t) * 16 + (lane >> 2);
-            const int q = (lane & 3) ^ ((row >> 2) & 3);
-            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (q >> 1) * 64 + (q & 1) * 16 : OOB_OFF;
-        }
-        const int ns = 2 * nk;
-        int u_cur = 0;                                             // byte offset of the 32-channel slab being issued
-        int issued = 0;                                            // half slabs issued so far
-        // the slab offset of A travels in the VGPR offset (the range check ignores soffset and conv padding relies on it)
-#define KN_ISSUE(STG)                                                                                                     \
-    {                                                                                                                     \
-        if ((issued & 1) == 0) u_cur = a_step(issued >> 1);                                                               \
-        const int ua = u_cur + (issued & 1) * 32, ub = (issued >> 1) * 128 + (issued & 1) * 32;                           \
-        _Pragma("unroll") for (int t = 0; t < A_DMA; ++t)                                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_desc, (lds_v*)(lds + (STG) + (wave * A_DMA + t) * 1024), 16, a_src[t] + ua, 0, 0, 0); \
-        _Pragma("unroll") for (int t = 0; t < B_DMA; ++t)                                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + (STG) + BOFF + (wave * B_DMA + t) * 1024), 16, b_src[t], ub, 0, 0); \
-        ++issued;                                                                                                         \
-    }
-        // ring of STAGES buffers, PF = STAGES - 1 half slabs of prefetch (STAGES = 2: 32 KB at 128x128, four blocks per CU;
-        // STAGES = 3: 48 KB, three blocks)
-        constexpr int PF = STAGES - 1;
-        static_assert(STAGES == 2 || STAGES == 3, "ring depth");
-        int c_cur = 0, c_iss = 0;                          // ring slot of the half slab being computed / issued next
-#pragma unroll
-        for (int t = 0; t < PF; ++t)
-            if (t < ns) { KN_ISSUE(c_iss * STAGE) c_iss = c_iss + 1 == STAGES ? 0 : c_iss + 1; }
-        // wait for half slab 0: everything but the (issued - 1) younger half slabs
-        if (PF == 2 && ns > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        for (int s = 0; s < ns; ++s) {
-            if (s + PF < ns) { KN_ISSUE(c_iss * STAGE) c_iss = c_iss + 1 == STAGES ? 0 : c_iss + 1; }
-            __builtin_amdgcn_sched_barrier(0);
-            const int st_cur = c_cur * STAGE;
-            f16x8 fa[TM][2], fb[TN][2];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    fa[i][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + st_cur + a_row + i * 32 * ROW + x_off[p]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    fb[j][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + st_cur + b_row + j * 32 * ROW + x_off[p]));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], c, 0, 0, 0);   // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < ns) {                 // this wave's pieces of half slab s+1 have landed (a younger one may still fly)
-                if (PF == 2 && s + 2 < ns) __builtin_amdgcn_s_waitcnt(0x0F70 | PER); else __builtin_amdgcn_s_waitcnt(0x0F70);
-            }
-            __syncthreads();
-            c_cur = c_cur + 1 == STAGES ? 0 : c_cur + 1;
-        }
-#undef KN_ISSUE
-    }
-
-    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
-        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    }
-    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
-        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
-    }
-};
-
-// -------------------------------------------------------------------------------------------------
-// Quad variant (round 2): 256x256 block, FOUR waves, 128x128 wave tiles (16 accumulator tiles = 256 AGPRs per lane, one
-// wave per SIMD, one block per CU), both operands by LDS-DMA through a ring of four half-slab stages (16 k = 64 bytes per
-// operand row, 32 KB per stage) — and a main loop that is software-pipelined BY HAND, because with one wave per SIMD
-// nothing else hides a stall.  Why this shape: per MFMA a 128x128 wave tile reads a third of the LDS bytes of the 64x64
-// wave tiles of Gemm2Tile (8 fragment pairs feed 48 MFMAs) and a 256x256 block stages a quarter of the bytes per MFMA —
-// at 128x128 the LDS array was ~85 % busy (writes at ~83 B/clk cost more than the reads), which is what held that loop at
-// ~57 % matrix-pipe utilisation whatever fed it.  The first cut of this tile (Gemm2Ring<256,256,...>: all DMA pieces, then
-// all fragment reads, then 48 MFMAs) ran serialised — 2700 instead of 1536 cycles per half slab.  Here, per half slab h:
-//   tile step t = 0..15 (three MFMAs each);
-//   behind steps 0..7: one DMA piece each of half slab h+3 (its ~100-cycle issue hides under the MFMAs just queued);
-//   after step 7: vmcnt wait for this wave's pieces of h+1 + ONE barrier;
-//   behind steps 8..15: the 16 fragment reads of half slab h+1 into the OTHER fragment register set (two per step).
-// so the next half slab starts on MFMAs at once.  Image, swizzle and DMA piece mapping as Gemm2Ring.
-// -------------------------------------------------------------------------------------------------
-template <int STAGES_ = 4>
-struct Gemm2Quad {
-    typedef f32x16 acc_t;
-    static constexpr int NR = 16;
-    static constexpr int BM = 256, BN = 256, WM = 2, WN = 2, TM = 4, TN = 4, STAGES = STAGES_;
-    static constexpr int BK = 16, ROW = 64, NW = 4, THREADS = 256;
-    static constexpr int A_DMA = BM * ROW / 1024 / NW;         // 4 LDS-DMA instructions per wave per half slab
-    static constexpr int B_DMA = BN * ROW / 1024 / NW;         // 4
-    static constexpr int PER = A_DMA + B_DMA;                  // 8: one behind each of the first eight tile steps
-    static_assert(PER == 8 && STAGES == 4, "schedule below is written for 8 pieces and a 4-stage ring");
-    static constexpr int BOFF = BM * ROW;
-    static constexpr int STAGE = (BM + BN) * ROW;
-    static constexpr int LDS_BYTES = STAGES * STAGE;           // 128 KB
-    static constexpr int OOB_OFF = 0x40000000;
-
-    typedef __attribute__((address_space(3))) char lds_c;
-    typedef __attribute__((address_space(3))) void lds_v;
-    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
-
-    template <class RowOff, class Step, class RA, class RB>
-    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
-                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
-        lds_c* lds = (lds_c*)lds_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave / WN, wn = wave % WN;
-        const int li = lane & 31, lh = lane >> 5;
-        const int swz = (li >> 2) & 3;
-        const int a_row = (wm * TM * 32 + li) * ROW;
-        const int b_row = BOFF + (wn * TN * 32 + li) * ROW;
-        int x_off[2];                                              // [plane]: swizzled slot of this lane's k-half
-#pragma unroll
-        for (int p = 0; p < 2; ++p) x_off[p] = ((p * 2 + lh) ^ swz) * 16;
-        int a_src[A_DMA], b_src[B_DMA];
-        const int row_bytes = (K / 32) * 128;
-#pragma unroll
-        for (int t = 0; t < A_DMA; ++t) {
-            const int row = (wave * A_DMA + t) * 16 + (lane >> 2);
-            const int q = (lane & 3) ^ ((row >> 2) & 3);
-            const int ro = a_row_off(m0 + row);
-            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (q >> 1) * 64 + (q & 1) * 16;
-        }
-#pragma unroll
-        for (int t = 0; t < B_DMA; ++t) {
-            const int row = (wave * B_DMA + t) * 16 + (lane >> 2);
-            const int q = (lane & 3) ^ ((row >> 2) & 3);
-            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (q >> 1) * 64 + (q & 1) * 16 : OOB_OFF;
-        }
-        const int ns = 2 * nk;
-        int u_cur = 0, issued = 0;                                 // A byte offset of the 32-channel slab being issued; half slabs issued
-        int ua = 0, ub = 0;                                        // per-half-slab uniform offsets of the piece being issued
-        // one DMA piece (T = 0..3: A rows, 4..7: weight rows) of the half slab `issued`, into ring slot `issued % 4`
-#define KN_Q_BEGIN() { if ((issued & 1) == 0) u_cur = a_step(issued >> 1); ua = u_cur + (issued & 1) * 32; ub = (issued >> 1) * 128 + (issued & 1) * 32; }
-#define KN_Q_PIECE(T)                                                                                                     \
-    {                                                                                                                     \
-        const int stg = (issued & 3) * STAGE;                                                                             \
-        if ((T) < A_DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_desc, (lds_v*)(lds + stg + (wave * A_DMA + ((T) & 3)) * 1024), 16, a_src[(T) & 3] + ua, 0, 0, 0); \
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_desc, (lds_v*)(lds + stg + BOFF + (wave * B_DMA + ((T) & 3)) * 1024), 16, b_src[(T) & 3], ub, 0, 0); \
-    }
-        f16x8 fa[2][TM][2], fb[2][TN][2];                          // [register set][tile][plane]
-#define KN_Q_READ_A(SET, STG, I) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fa[SET][I][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + a_row + (I) * 32 * ROW + x_off[p])); }
-#define KN_Q_READ_B(SET, STG, J) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fb[SET][J][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + b_row + (J) * 32 * ROW + x_off[p])); }
-#define KN_Q_MFMA(SET, I, J)                                                                                              \
-    {                                                                                                                     \
-        f32x16 c = acc[I][J];                                                                                             \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][1], fb[SET][J][0], c, 0, 0, 0);   /* small terms first */    \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][1], c, 0, 0, 0);                             \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][0], c, 0, 0, 0);                             \
-        acc[I][J] = c;                                                                                                    \
-    }
-        // prologue: half slabs 0, 1, 2 in flight; 0 landed and read into register set 0
-#pragma unroll
-        for (int pre = 0; pre < 3; ++pre)
-            if (pre < ns) {
-                KN_Q_BEGIN()
-#pragma unroll
-                for (int t = 0; t < PER; ++t) KN_Q_PIECE(t)
-                ++issued;
-            }
-        if (ns > 2) __builtin_amdgcn_s_waitcnt(0x4F70);            // vmcnt(16): all but the two youngest half slabs
-        else if (ns > 1) __builtin_amdgcn_s_waitcnt(0x0F78);       // vmcnt(8)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TM; ++i) KN_Q_READ_A(0, 0, i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) KN_Q_READ_B(0, 0, j)
-
-        // one half slab on register set SET; the next one's fragments go to set SET ^ 1
-#define KN_Q_HALF(SET, H)                                                                                                 \
-    {                                                                                                                     \
-        const bool more_dma = issued < ns;            /* half slab H + 3 exists */                                        \
-        const bool more_rd = (H) + 1 < ns;                                                                                \
-        const int nstg = (((H) + 1) & 3) * STAGE;                                                                         \
-        if (more_dma) KN_Q_BEGIN()                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                                                  \
-            KN_Q_MFMA(SET, t >> 2, t & 3)                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                            \
-            if (t < 8) {                                                                                                  \
-                if (more_dma) KN_Q_PIECE(t)                                                                               \
-                if (t == 7) {                                                                                             \
-                    if (more_dma) ++issued;                                                                               \
-                    /* this wave's pieces of half slab H + 1 have landed: everything but the younger half slabs */       \
-                    if ((H) + 3 < ns) __builtin_amdgcn_s_waitcnt(0x4070);          /* vmcnt(16), lgkmcnt(0) */            \
-                    else if ((H) + 2 < ns) __builtin_amdgcn_s_waitcnt(0x0078);     /* vmcnt(8),  lgkmcnt(0) */            \
-                    else __builtin_amdgcn_s_waitcnt(0x0070);                       /* vmcnt(0),  lgkmcnt(0) */            \
-                    __builtin_amdgcn_s_barrier();                                                                         \
-                }                                                                                                         \
-            } else if (more_rd) {                                                                                         \
-                const int u = t - 8;                  /* two fragment pairs of H + 1 per step: A0..3 then B0..3 */        \
-                if (u < 4) KN_Q_READ_A(SET ^ 1, nstg, u)                                                                  \
-                else KN_Q_READ_B(SET ^ 1, nstg, u - 4)                                                                    \
-            }                                                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                            \
-        }                                                                                                                 \
-    }
-        for (int h = 0; h < ns; h += 2) {             // ns = 2 nk is even: two half slabs per trip, register sets 0 and 1
-            KN_Q_HALF(0, h)
-            KN_Q_HALF(1, h + 1)
-        }
-#undef KN_Q_HALF
-#undef KN_Q_MFMA
-#undef KN_Q_READ_A
-#undef KN_Q_READ_B
-#undef KN_Q_PIECE
-#undef KN_Q_BEGIN
-    }
-
-    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
-        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    }
-    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
-        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
-    }
-};
-
-// -------------------------------------------------------------------------------------------------
-// Quad variant, register-staged (the default of the two).  PMC view of the DMA-fed loop above (main loop only, FFN2):
-// matrix pipe 64 % busy, waves 45 % in issue stalls — an LDS-DMA instruction costs its wave 100-185 cycles of ISSUE
-// time (MI355X_MICROARCH.md, cycle constants), 8 pieces per half slab = ~1200 cycles against 384 for the 48 MFMAs, and
-// with one wave per SIMD nothing issues MFMAs meanwhile.  A plain 16-byte buffer load + ds_write_b128 pair issues in a
-// fraction of that, so here the operands travel global -> 8 x 4 staging VGPRs -> LDS, one piece behind each of the
-// first eight tile steps:
-//   step t < 8 : 3 MFMAs | ds_write piece t of half slab h+1 (loaded during the previous half slab) | load piece t of h+2
-//   after t = 7: lgkmcnt(0) + ONE barrier
-//   step t >= 8: 3 MFMAs | two fragment reads of h+1 into the other register set
-// The loads of a half slab have a whole half slab (~1500+ cycles) to land; the compiler's own vmcnt bookkeeping orders
-// each ds_write behind its load.  TWO stages of 32 KB suffice: h+1 is written into the stage h-1 was read from, and
-// those reads finished before the previous barrier.  Same image / swizzle / piece mapping as Gemm2Ring (a piece is what
-// one DMA instruction would move: lane L owns bytes 16 L .. 16 L + 15 of a 1 KiB run; the swizzle sits in the source offset).
-// -------------------------------------------------------------------------------------------------
-struct Gemm2QuadR {
-    typedef f32x16 acc_t;
-    static constexpr int NR = 16;
-    static constexpr int BM = 256, BN = 256, WM = 2, WN = 2, TM = 4, TN = 4;
-    static constexpr int BK = 16, ROW = 64, NW = 4, THREADS = 256;
-    static constexpr int A_P = BM * ROW / 1024 / NW, B_P = BN * ROW / 1024 / NW, PER = A_P + B_P;      // 4 + 4 pieces per wave
-    static_assert(PER == 8, "schedule below is written for 8 pieces");
-    static constexpr int BOFF = BM * ROW;
-    static constexpr int STAGE = (BM + BN) * ROW;
-    static constexpr int EPI_BYTES = NW * 32 * (TN * 32 + 4) * 4;             // conv_epilogue_wide's per-wave patches
-    static constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
-    static constexpr int OOB_OFF = 0x40000000;
-
-    typedef __attribute__((address_space(3))) char lds_c;
-    typedef __attribute__((address_space(3))) g2_u32x4 lds_u4;
-
-    template <class RowOff, class Step, class RA, class RB>
-    __device__ __forceinline__ static void mainloop(float* lds_generic, int nk, RowOff a_row_off, Step a_step, RA ra_desc,
-                                                    RB rb_desc, int N, int K, int m0, int n0, f32x16 (&acc)[TM][TN]) {
-        lds_c* lds = (lds_c*)lds_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave / WN, wn = wave % WN;
-        const int li = lane & 31, lh = lane >> 5;
-        const int swz = (li >> 2) & 3;
-        const int a_row = (wm * TM * 32 + li) * ROW;
-        const int b_row = BOFF + (wn * TN * 32 + li) * ROW;
-        int x_off[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) x_off[p] = ((p * 2 + lh) ^ swz) * 16;
-        int a_src[A_P], b_src[B_P];
-        const int row_bytes = (K / 32) * 128;
-#pragma unroll
-        for (int t = 0; t < A_P; ++t) {
-            const int row = (wave * A_P + t) * 16 + (lane >> 2);
-            const int q = (lane & 3) ^ ((row >> 2) & 3);
-            const int ro = a_row_off(m0 + row);
-            a_src[t] = ro == OOB_OFF ? OOB_OFF : ro + (q >> 1) * 64 + (q & 1) * 16;
-        }
-#pragma unroll
-        for (int t = 0; t < B_P; ++t) {
-            const int row = (wave * B_P + t) * 16 + (lane >> 2);
-            const int q = (lane & 3) ^ ((row >> 2) & 3);
-            b_src[t] = (n0 + row < N) ? (n0 + row) * row_bytes + (q >> 1) * 64 + (q & 1) * 16 : OOB_OFF;
-        }
-        const int st_dst = wave * 4 * 1024 + lane * 16;            // this lane's byte inside piece 0 of its wave (A or B region)
-        const int ns = 2 * nk;
-        int u_cur = 0, issued = 0, ua = 0, ub = 0;
-        g2_u32x4 st[PER];                                          // staging registers: one half slab in flight
-#define KN_R_BEGIN() { if ((issued & 1) == 0) u_cur = a_step(issued >> 1); ua = u_cur + (issued & 1) * 32; ub = (issued >> 1) * 128 + (issued & 1) * 32; }
-#define KN_R_LOAD(T)                                                                                                      \
-    {                                                                                                                     \
-        if ((T) < A_P) st[T] = __builtin_amdgcn_raw_buffer_load_b128(ra_desc, a_src[(T) & 3] + ua, 0, 0);                 \
-        else st[T] = __builtin_amdgcn_raw_buffer_load_b128(rb_desc, b_src[(T) & 3], ub, 0);                               \
-    }
-#define KN_R_WRITE(T, STG) { *(lds_u4*)(lds + (STG) + ((T) < A_P ? 0 : BOFF) + st_dst + ((T) & 3) * 1024) = st[T]; }
-        f16x8 fa[2][TM][2], fb[2][TN][2];
-#define KN_R_READ_A(SET, STG, I) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fa[SET][I][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + a_row + (I) * 32 * ROW + x_off[p])); }
-#define KN_R_READ_B(SET, STG, J) { _Pragma("unroll") for (int p = 0; p < 2; ++p) fb[SET][J][p] = __builtin_bit_cast(f16x8, *(const lds_u4*)(lds + (STG) + b_row + (J) * 32 * ROW + x_off[p])); }
-#define KN_R_MFMA(SET, I, J)                                                                                              \
-    {                                                                                                                     \
-        f32x16 c = acc[I][J];                                                                                             \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][1], fb[SET][J][0], c, 0, 0, 0);   /* small terms first */    \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][1], c, 0, 0, 0);                             \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I][0], fb[SET][J][0], c, 0, 0, 0);                             \
-        acc[I][J] = c;                                                                                                    \
-    }
-        // prologue: half slab 0 -> stage 0, half slab 1 in flight in the staging registers, fragments of 0 in set 0
-        KN_R_BEGIN()
-#pragma unroll
-        for (int t = 0; t < PER; ++t) KN_R_LOAD(t)
-        ++issued;
-#pragma unroll
-        for (int t = 0; t < PER; ++t) KN_R_WRITE(t, 0)
-        if (ns > 1) {
-            KN_R_BEGIN()
-#pragma unroll
-            for (int t = 0; t < PER; ++t) KN_R_LOAD(t)
-            ++issued;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): this wave's writes are in LDS (vmcnt untouched)
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < TM; ++i) KN_R_READ_A(0, 0, i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) KN_R_READ_B(0, 0, j)
-
-        // HN: half slab H + 1 exists (its pieces sit in the staging registers); ML: half slab H + 2 exists (load it).  Both are
-        // LITERALS at every use: a run-time test here would put each step into its own basic block, and the compiler's
-        // waitcnt bookkeeping then falls back to vmcnt(0) before every ds_write — a full memory latency per step (measured:
-        // 203 instead of 360 TFLOP/s).  The steady state is one straight-line block per half slab.
-#define KN_R_HALF(SET, H, HN, ML)                                                                                         \
-    {                                                                                                                     \
-        const int nstg = (((H) + 1) & 1) * STAGE;                                                                         \
-        if (ML) KN_R_BEGIN()                                                                                              \
-        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                                                  \
-            KN_R_MFMA(SET, t >> 2, t & 3)                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                            \
-            if (t < 8) {                                                                                                  \
-                if (HN) KN_R_WRITE(t, nstg)                                                                               \
-                if (ML) KN_R_LOAD(t)                                                                                      \
-                if (t == 7) {                                                                                             \
-                    if (ML) ++issued;                                                                                     \
-                    __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): writes of H + 1 done, old fragment reads done */ \
-                    __builtin_amdgcn_s_barrier();                                                                         \
-                }                                                                                                         \
-            } else if (HN) {                                                                                              \
-                const int u = t - 8;                                                                                      \
-                if (u < 4) KN_R_READ_A(SET ^ 1, nstg, u)                                                                  \
-                else KN_R_READ_B(SET ^ 1, nstg, u - 4)                                                                    \
-            }                                                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                            \
-        }                                                                                                                 \
-    }
-        int h = 0;
-        for (; h + 3 < ns; h += 2) {                  // steady state: both successors exist for both halves of the pair
-            KN_R_HALF(0, h, true, true)
-            KN_R_HALF(1, h + 1, true, true)
-        }
-        KN_R_HALF(0, h, true, false)                  // last pair (ns is even): ns - 2 still has a successor, nothing left to load
-        KN_R_HALF(1, h + 1, false, false)
-#undef KN_R_HALF
-#undef KN_R_MFMA
-#undef KN_R_READ_A
-#undef KN_R_READ_B
-#undef KN_R_WRITE
-#undef KN_R_LOAD
-#undef KN_R_BEGIN
-    }
-
-    __device__ __forceinline__ static int acc_row(int wave, int lane, int i, int r) {
-        return (wave / WN) * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    }
-    __device__ __forceinline__ static int acc_col(int wave, int lane, int j) {
-        return (wave % WN) * TN * 32 + j * 32 + (lane & 31);
-    }
-};
-
-// -------------------------------------------------------------------------------------------------
 // Gemm2QuadS: the same 256x256 block / 128x128 wave tile on v_mfma_f32_16x16x32_f16 (the hardware guide measures 1.12-1.15x
 // the FLOP/s of 32x32x16 at equal cycles on random data: the gain is clock, i.e. energy per product — exactly what bounds
 // Gemm2QuadR).  A k slab is 32 wide (one MFMA deep): LDS row = 128 B (hi 64 | lo 64) in 16-byte chunks, chunk' = chunk ^ (row & 7)

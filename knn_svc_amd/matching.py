@@ -57,15 +57,10 @@ def load_utterance(pth):
     if not os.path.isfile(f0_path):
         # same bookkeeping as the reference (:376-379): warn, compute, write the cache next to the audio.  The reference runs
         # pyworld.harvest on the host here (:121-128); this build runs Harvest on the GPU (csrc/harvest.hip, fp64, pinned on
-        # the reference's own shipped tracks).  KNNSVC_F0=yin selects the YIN estimator of round 1 instead (a different,
-        # cheaper algorithm: the track, and with it the conversion, then differs from the reference's).
+        # the reference's own shipped tracks).
         xg = torch.from_numpy(np.ascontiguousarray(x[0], dtype=np.float32)).cuda()
-        if os.environ.get("KNNSVC_F0") == "yin":
-            print(f"WARNING: {f0_path} not exists, generating (GPU YIN estimator, not harvest)...")
-            f0_new = ops.f0_yin(xg).cpu().numpy()
-        else:
-            print(f"WARNING: {f0_path} not exists, generating...")
-            f0_new = ops.f0_harvest(xg).cpu().numpy()
+        print(f"WARNING: {f0_path} not exists, generating...")
+        f0_new = ops.f0_harvest(xg).cpu().numpy()
         np.save(f0_path, f0_new)
     f0 = np.asarray(np.load(f0_path, allow_pickle=True), dtype=np.float32)
     return np.ascontiguousarray(x[0], dtype=np.float32), f0

@@ -651,6 +651,12 @@ def raise_if_nan(flag):
         raise KnnOverflow("fused kNN route: candidate buffer overflow (repeat with ops.fused_off())")
 
 
+def reload_knobs() -> None:
+    """Re-read the dispatcher's A/B switches (KNNSVC_QUAD, KNNSVC_QUAD_EPI, KNNSVC_EPILOGUE, KNNSVC_WIN*, KNNSVC_GEMM_SMALL) from
+    the environment: the library reads them once, at its first launch (csrc/conv_gemm.hip: Knobs)."""
+    check(_lib.load().knnsvc_reload_knobs(), "reload_knobs")
+
+
 def knn_merge(part_dist, part_idx):
     """[parts, nq, k] per-shard lists (global indices) -> merged (idx, dist)."""
     parts, nq, k = part_dist.shape
@@ -756,18 +762,6 @@ def amp_ratio(spec_q, spec_pool, idx):
 
 
 # ------------------------------------------------------------------ f0 front end
-def f0_yin(wav_1d, sample_rate=16000, hop=320, f0_floor=65.0, f0_ceil=1047.0, threshold=0.15, zero_below=80.0):
-    """YIN f0 track with pyworld.harvest's interface as the reference calls it (ddsp_prematch_dataset.py:121-128):
-    [L] -> [L // hop + 1], 0 = unvoiced, values below 80 Hz zeroed.  Parity with pyworld unpinned."""
-    _need(wav_1d, name="f0_yin.wav")
-    wav_1d = wav_1d.contiguous()
-    n = wav_1d.numel() // hop + 1
-    out = torch.empty(n, device=wav_1d.device, dtype=torch.float32)
-    check(_lib.load().knnsvc_f0_yin(_p(wav_1d), wav_1d.numel(), int(sample_rate), int(hop), float(f0_floor), float(f0_ceil),
-                                    float(threshold), float(zero_below), _p(out), n, _stream()), "f0_yin")
-    return out
-
-
 def f0_harvest(wav_1d, sample_rate=16000, f0_floor=65.0, f0_ceil=1047.0, frame_period=20.0, zero_below=80.0, check_status=True):
     """Harvest f0 track exactly as the reference asks pyworld for it (ddsp_prematch_dataset.py:121-128):
     [L] fp32 at 16 kHz -> [int(1000 L / fs / frame_period) + 1] fp32, 0 = unvoiced, values below 80 Hz zeroed.  All stages

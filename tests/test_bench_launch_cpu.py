@@ -21,7 +21,8 @@ def test_gpus_2_without_rank_launches_two_ranks_and_relays_their_failure():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert "launching 2 ranks" in r.stderr, r.stderr[-2000:]
-    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-3000:]       # both ranks ran bench.py's main()
+    # a rank ran bench.py's main() (torch.distributed.run stops the other one as soon as the first has failed)
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-3000:]
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 

@@ -18,6 +18,19 @@ def _ops():
     return ops
 
 
+def _knob(monkeypatch, name, value):
+    """An A/B switch of the C++ dispatcher: the library reads those once, so set the variable AND have it re-read them."""
+    monkeypatch.setenv(name, value)
+    _ops().reload_knobs()
+
+
+@pytest.fixture(autouse=True)
+def _knobs_back_to_default(monkeypatch):
+    yield
+    monkeypatch.undo()
+    _ops().reload_knobs()
+
+
 def _t(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -74,7 +87,7 @@ def test_linear_split_layout_in_and_out(monkeypatch):
     # (by default a pre-split operand with K >= 1024 takes the 256x256 kernel, whatever M: another K grouping — fp32 noise apart)
     got_q = ops.linear(ops.split_pack(x), wd, b, act=ops.ACT_GELU, x_split=True)
     assert ops.last_conv_kernel() == "Q256S" and float((got_q - ref).abs().max()) < 2e-5
-    monkeypatch.setenv("KNNSVC_QUAD", "0")          # the same 128x128 kernel for both: staging is the only difference
+    _knob(monkeypatch, "KNNSVC_QUAD", "0")          # the same 128x128 kernel for both: staging is the only difference
     got = ops.linear(ops.split_pack(x), wd, b, act=ops.ACT_GELU, x_split=True)
     assert torch.equal(ref, got)
     packed = ops.linear(x, wd, b, act=ops.ACT_GELU, out_split=True)
@@ -85,46 +98,17 @@ def test_linear_split_layout_in_and_out(monkeypatch):
     from knn_svc_amd._lib import KnnSvcError
     with pytest.raises(KnnSvcError):
         ops.linear(x, wd, b, resid=ref, out_split=True)
-    monkeypatch.setenv("KNNSVC_DMA", "1")           # opt-in kernel: both operands by LDS-DMA — same arithmetic
-    assert torch.equal(ops.linear(ops.split_pack(x), wd, b, act=ops.ACT_GELU, x_split=True), ref)
 
 
-def test_linear_f16x2_big_tile(monkeypatch):
-    """The opt-in 256x256 double-buffered tile with LDS-DMA weights (conv_gemm2big_kernel, KNNSVC_F256_KMIN): ragged
-    last row tile, bias + GELU epilogue, rows sampled from the first, a middle and the last tile against fp64; the
-    default 128x128 kernel must agree with it to fp32 rounding."""
-    ops = _ops()
-    monkeypatch.setenv("KNNSVC_F256_KMIN", "2048")
-    g = torch.Generator().manual_seed(11)
-    M, K, N = 24577 + 130, 2048, 1024
-    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
-    wd = ops.attach_split(w.to(DEV))
-    if not hasattr(wd, "_w2"):
-        pytest.skip("KNNSVC_GEMM is not f16x2")
-    o = ops.linear(x.to(DEV), wd, b.to(DEV), act=ops.ACT_GELU).cpu()
-    rows = torch.cat([torch.arange(0, 200), torch.arange(12000, 12200), torch.arange(M - 200, M)])
-    ref = torch.nn.functional.gelu(x[rows].double() @ w.double().T + b.double())
-    err = float((o[rows].double() - ref).abs().max())
-    print(f"big tile max err {err:.2e}")
-    assert err < 2e-5 and bool(torch.isfinite(o).all())
-    # pre-split (A2) activations: staging is a plain copy; this combination produced NaN before the kernel had an A2 path
-    o2 = ops.linear(ops.split_pack(x.to(DEV)), wd, b.to(DEV), act=ops.ACT_GELU, x_split=True).cpu()
-    assert ops.last_conv_kernel() == "F256" and bool(torch.isfinite(o2).all())
-    assert float((o2[rows].double() - ref).abs().max()) < 2e-5
-    monkeypatch.delenv("KNNSVC_F256_KMIN")
-    o128 = ops.linear(x.to(DEV), wd, b.to(DEV), act=ops.ACT_GELU).cpu()
-    assert float((o128 - o).abs().max()) < 2e-5
-
-
-@pytest.mark.parametrize("q16", ["0", "1"])
 @pytest.mark.parametrize("M,K,N", [(2048 + 77, 1024, 1024), (700, 2048, 520), (256, 32, 256), (31, 4096, 1028), (300, 96, 260)])
-def test_linear_quad_kernel(M, K, N, q16, monkeypatch):
-    """conv_gemm2quad_kernel (256x256 block, 128x128 wave tiles, hand-pipelined 4-stage DMA ring, LDS-transposed
-    16-byte epilogue): ragged M and N tails, 1 / 32 / 64 / 128 slabs, every epilogue operand — bias, GELU, residual,
-    accumulate, divide, range slot, split-layout output — against fp64 and against the 128x128 kernel."""
+def test_linear_quad_kernel(M, K, N, monkeypatch):
+    """conv_gemm2quad_kernel<Gemm2QuadS> (256x256 block, 128x128 wave tiles of v_mfma_f32_16x16x32_f16, hand-pipelined register
+    staging, LDS-transposed 16-byte epilogue): ragged M and N tails, 1 / 32 / 64 / 128 slabs (odd and even counts), every epilogue
+    operand — bias, GELU, residual, accumulate, divide, range slot, split-layout output — against fp64 and against the 128x128
+    kernel."""
     ops = _ops()
-    monkeypatch.setenv("KNNSVC_QUAD16", q16)          # "1": the 16x16x32-MFMA variant (Gemm2QuadS, odd and even slab counts)
-    qname = "Q256S" if q16 == "1" else "Q256"
+    q16 = "1"
+    qname = "Q256S"
     g = torch.Generator().manual_seed(17)
     x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
     r = torch.randn(M, N, generator=g)
@@ -135,7 +119,7 @@ def test_linear_quad_kernel(M, K, N, q16, monkeypatch):
     ref = x.double() @ w.double().T + b.double()
     outs = {}
     for mode in ("2", "0"):
-        monkeypatch.setenv("KNNSVC_QUAD", mode)
+        _knob(monkeypatch, "KNNSVC_QUAD", mode)
         o = ops.linear(xs, wd, b.to(DEV), x_split=True)
         assert ops.last_conv_kernel() == (qname if mode == "2" else ("F128a2" if M * N >= 256 * 128 * 128 else ops.last_conv_kernel()))
         outs[mode] = o.cpu()
@@ -164,10 +148,10 @@ def test_linear_quad_kernel(M, K, N, q16, monkeypatch):
     # the specialised epilogues (conv_epilogue_wide_fast: bias, GELU, residual, split columns) against the generic one: same
     # arithmetic in the same order -> the same bits
     if q16 == "1":
-        monkeypatch.setenv("KNNSVC_QUAD", "2")
+        _knob(monkeypatch, "KNNSVC_QUAD", "2")
         res = {}
         for epi in ("1", "0"):
-            monkeypatch.setenv("KNNSVC_QUAD_EPI", epi)
+            _knob(monkeypatch, "KNNSVC_QUAD_EPI", epi)
             r_ = [ops.linear(xs, wd, b.to(DEV), x_split=True), ops.linear(xs, wd, None, x_split=True),
                   ops.linear(xs, wd, b.to(DEV), act=ops.ACT_GELU, x_split=True),
                   ops.linear(xs, wd, b.to(DEV), resid=r.to(DEV), x_split=True)]
@@ -182,12 +166,10 @@ def test_linear_quad_kernel(M, K, N, q16, monkeypatch):
             assert not bool(bad.any()), (k_, int(bad.sum()), bad.nonzero()[:4].tolist(), float((t1 - t0).abs().max()))
 
 
-@pytest.mark.parametrize("q16", ["0", "1"])
-def test_conv_quad_kernel_taps_stride_batches(q16, monkeypatch):
+def test_conv_quad_kernel_taps_stride_batches(monkeypatch):
     """The quad kernel on a strided 3-tap convolution over a batch of sequences (WavLM's conv stack shape: A2 input,
     stride 2, per-batch strides) and with conv padding rows, against the 128x128 kernel."""
     ops = _ops()
-    monkeypatch.setenv("KNNSVC_QUAD16", q16)
     g = torch.Generator().manual_seed(19)
     B, T, Cin, Cout, k, st = 3, 2001, 256, 512, 3, 2
     x = torch.randn(B * T, Cin, generator=g)
@@ -196,13 +178,13 @@ def test_conv_quad_kernel_taps_stride_batches(q16, monkeypatch):
     t_out = (T - k) // st + 1
     res = {}
     for mode in ("2", "0"):
-        monkeypatch.setenv("KNNSVC_QUAD", mode)
+        _knob(monkeypatch, "KNNSVC_QUAD", mode)
         y = torch.empty(B * t_out, Cout, device=DEV)
         ops.conv_gemm(xs, w, y, m=t_out, n=Cout, cin=Cin, taps=k, stride=st, t_in=T, batches=B, x_bstride=T * Cin, o_bstride=t_out * Cout, x_split=True)
         yp = torch.empty(B * T, Cout, device=DEV)
         ops.conv_gemm(xs, w, yp, m=T, n=Cout, cin=Cin, taps=k, stride=1, pad=1, t_in=T, batches=B, x_bstride=T * Cin, o_bstride=T * Cout, x_split=True)
         res[mode] = (y.cpu(), yp.cpu(), ops.last_conv_kernel())
-    assert res["2"][2] == ("Q256S" if q16 == "1" else "Q256")
+    assert res["2"][2] == "Q256S"
     ref = torch.nn.functional.conv1d(x.view(B, T, Cin).transpose(1, 2).double(), w.cpu().view(Cout, k, Cin).permute(0, 2, 1).double(), stride=st)
     assert float((res["2"][0].view(B, t_out, Cout).transpose(1, 2).double() - ref).abs().max()) < 2e-5
     assert float((res["2"][0] - res["0"][0]).abs().max()) < 2e-5 and float((res["2"][1] - res["0"][1]).abs().max()) < 2e-5
@@ -555,12 +537,12 @@ def test_smooth_weights(golden):
     w, it = ops.smooth_weights(idx, p.to(DEV), 0.1, return_iters=True)
     e = _err(w, _t(g["w_wavlm"]))[0]
     print("wavlm weights max|d|", e, "iters", int(it), "ref", int(g["iters_wavlm"]))
-    assert e < 1e-3 and int(it) == int(g["iters_wavlm"])       # measured 2.8e-4; the reference's own trajectory moves by 2e-4
+    assert e < 4e-4 and int(it) == int(g["iters_wavlm"])       # measured 2.8e-4; the reference's own trajectory moves by 2e-4
     assert abs(float(w.sum(1).mean()) - 1.0) < 1e-5
     wh, ith = ops.smooth_weights(idx, _t(g["harm_pool"]).to(DEV), 1000.0, return_iters=True)
     e = _err(wh, _t(g["w_harm"]))[0]
     print("harm weights max|d|", e, "iters", int(ith), "ref", int(g["iters_harm"]))
-    assert e < 1e-3 and int(ith) == int(g["iters_harm"])       # measured 1.9e-4
+    assert e < 4e-4 and int(ith) == int(g["iters_harm"])       # measured 1.9e-4
     # weighted gather
     out = ops.weighted_gather(idx, w, p.to(DEV))
     ref = (p[idx.cpu().reshape(-1)].reshape(-1, 4, 1024) * w.cpu()[..., None]).sum(1)
@@ -832,46 +814,16 @@ def test_resample_matches_torchaudio_restatement(sr, n):
     assert float(np.abs(got - ref).max()) < 2e-6
 
 
-# ------------------------------------------------------------------ f0 front end (parity with pyworld unpinned)
-@pytest.mark.parametrize("seed", [5, 17, 101])
-def test_f0_yin_tracks_synthetic_ground_truth(seed):
-    """knnsvc_f0_yin has Harvest's interface (frame t at sample 320 t, L // 320 + 1 frames, 0 = unvoiced, < 80 Hz zeroed) but
-    is a YIN estimator: it is validated against the synthetic clips' known f0 (gliding 110-440 Hz tone + unvoiced gaps),
-    not against pyworld, which is absent offline."""
-    ops = _ops()
-    n = 6 * 16000 + 123
-    wav, f0_true = S.synth_clip(n, seed)
-    est = ops.f0_yin(torch.from_numpy(wav).to(DEV)).cpu().numpy()
-    assert est.shape == (n // 320 + 1,) == f0_true.shape
-    assert np.all((est == 0) | ((est >= 80.0) & (est <= 1047.0 * 1.01)))
-    v = f0_true > 0
-    core = v & np.roll(v, 1) & np.roll(v, -1) & np.roll(v, 2) & np.roll(v, -2)        # away from voicing transitions
-    core[:3] = core[-3:] = False
-    assert core.sum() > 100
-    rel = np.abs(est[core] - f0_true[core]) / f0_true[core]
-    voiced_hit = float(np.mean(est[core] > 0))
-    print(f"seed {seed}: voiced recall {voiced_hit:.3f}, median rel err {np.median(rel[est[core] > 0]):.4f}, "
-          f"95th pct {np.percentile(rel[est[core] > 0], 95):.4f}")
-    assert voiced_hit > 0.95
-    assert np.median(rel[est[core] > 0]) < 0.01 and np.percentile(rel[est[core] > 0], 95) < 0.03
-    gaps = (~v) & np.roll(~v, 1) & np.roll(~v, -1) & np.roll(~v, 2) & np.roll(~v, -2)
-    if gaps.sum() > 10:
-        assert float(np.mean(est[gaps] == 0)) > 0.9                                      # unvoiced stays unvoiced
-
-
+# ------------------------------------------------------------------ f0 front end (Harvest itself: tests/test_gpu_f0.py)
 def test_missing_f0_cache_is_generated_next_to_the_audio(tmp_path, monkeypatch):
-    """Without `<stem>_f0.npy` the track is computed (Harvest on the GPU; KNNSVC_F0=yin selects the YIN estimator) and written
-    next to the audio exactly as the reference does (ddsp_prematch_dataset.py:376-379); the second load reads the cache."""
+    """Without `<stem>_f0.npy` the track is computed (Harvest on the GPU) and written next to the audio exactly as the reference
+    does (ddsp_prematch_dataset.py:376-379); the second load reads the cache."""
     from knn_svc_amd import audio_io, matching
     wav, f0_true = S.synth_clip(2 * 16000, 9)
-    for sub, env in (("h", None), ("y", "yin")):
+    for sub in ("h",):
         d = tmp_path / sub; d.mkdir()
         p = d / "a.wav"
         audio_io.write_wav_pcm16(str(p), wav, 16000)
-        if env is None:
-            monkeypatch.delenv("KNNSVC_F0", raising=False)
-        else:
-            monkeypatch.setenv("KNNSVC_F0", env)
         w, f0 = matching.load_utterance(p)
         assert (d / "a_f0.npy").is_file() and f0.shape == (len(w) // 320 + 1,) and f0.dtype == np.float32
         assert np.array_equal(np.load(d / "a_f0.npy"), f0)
@@ -879,28 +831,6 @@ def test_missing_f0_cache_is_generated_next_to_the_audio(tmp_path, monkeypatch):
         assert v.sum() > 20 and np.median(np.abs(f0[v] - f0_true[:len(f0)][v]) / f0_true[:len(f0)][v]) < 0.02
         w2, f02 = matching.load_utterance(p)
         assert np.array_equal(f0, f02)
-
-
-def test_f0_yin_against_the_reference_samples_harvest_tracks():
-    """The only pyworld output available offline: the harvest f0 caches shipped with the reference's sample pair (6 s
-    excerpts, tests/golden/sample_content).  YIN is a different estimator, so this records agreement, it does not pin
-    parity: most frames get the same voicing decision and, where both are voiced, nearly the same pitch."""
-    from pathlib import Path
-    from knn_svc_amd import audio_io
-    ops = _ops()
-    fx = Path(__file__).parent / "golden" / "sample_content"
-    for name in ("src", "tgt"):
-        x, _sr = audio_io.read_wav(str(fx / f"{name}.wav"))
-        ref = np.load(fx / f"{name}_f0.npy")
-        est = ops.f0_yin(torch.from_numpy(x[0]).to(DEV)).cpu().numpy()
-        m = min(len(ref), len(est))
-        ref, est = ref[:m], est[:m]
-        both = (ref > 0) & (est > 0)
-        rel = np.abs(est[both] - ref[both]) / ref[both]
-        agree = float(np.mean((ref > 0) == (est > 0)))
-        print(f"{name}: voicing agreement with harvest {agree:.3f}, median pitch deviation {np.median(rel):.4f}, "
-              f"deviations > 30 %: {int((rel > 0.3).sum())} of {int(both.sum())}")
-        assert agree > 0.75 and np.median(rel) < 0.03 and (rel > 0.3).mean() < 0.15
 
 
 def test_grouped_knn_results_do_not_depend_on_the_grouping(monkeypatch):

@@ -182,7 +182,9 @@ def test_cfg5_share_through_the_product_entry_equals_per_item_path():
         # waveform tolerance, two orders of magnitude above that.
         assert rms < 1e-6 and mx < 1e-4, (i, rms, mx)
     assert exact == 3, "bit-identical since the re-selection kernel runs alone on its CU and the encoder is batch-invariant"
-    assert ops.KNN_ROUTE_COUNTS["dot"] > dot0
+    # (round 3: a source on its own took the dot-matrix route, so this also compared the two routes; since round 4 a 30 s source
+    #  takes the fused route as well — with another epoch plan than the grouped search: 6 row tiles instead of 12 or 24)
+    assert ops.KNN_ROUTE_COUNTS["dot"] >= dot0
 
 
 def test_cfg3_size_bulk_match_sampled_utterances_vs_oracle(tmp_path):
