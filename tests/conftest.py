@@ -28,7 +28,7 @@ def golden():
 # kernel-level and self-consistency tests.
 # test_gpu_dist2 has to stay in front: it spawns its ranks and must do so before this interpreter has initialised the GPU.
 _GPU_ORDER = ["test_gpu_dist2", "test_gpu_models", "test_gpu_product", "test_gpu_fulllength", "test_gpu_fullsize", "test_gpu_f0",
-              "test_gpu_range", "test_gpu_kernels"]
+              "test_gpu_range", "test_gpu_kernels", "test_gpu_race"]
 
 
 def pytest_collection_modifyitems(config, items):
