@@ -64,7 +64,7 @@ from knn_svc_amd import config as C, dist as kdist, ops, synthetic as S      # n
 from knn_svc_amd.matching import match_features, side_features, side_features_many               # noqa: E402
 from knn_svc_amd.pipeline import LanePipeline                                 # noqa: E402
 from knn_svc_amd.vocoder import Vocoder                                       # noqa: E402
-from knn_svc_amd.wavlm import WavLMEncoder                                    # noqa: E402
+from knn_svc_amd.wavlm import WavLMEncoder, cat_rows                          # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
@@ -187,7 +187,7 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
             Ph_loc = torch.cat([t[1] for t in sides[1:]]).contiguous()
     qf = feats[-1]
     assert qf.shape[0] == 1500
-    P_loc = torch.cat(feats[:-1]).contiguous()
+    P_loc = cat_rows(feats[:-1]).contiguous()          # no copy: the clips of one batch lie back to back in the encoder's output
     main.wait_stream(side)
     for t in (qf0, Pf0_loc, Ph_loc):
         t.record_stream(main)

@@ -705,14 +705,19 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         __syncthreads();
     }
     KN_KP_T(2)
-    float ra1[QG::TM][QG::NR], ra2[QG::TM][QG::NR];
+    // The coarse test per element:  acc > a1[row] |p| - (a2[row] + b2[col]).  a2 = eps' |q|^2 / out_scale is the margin's row part: the
+    // LARGEST one of the wave's 128 rows serves them all (a looser bound for the rows with smaller norms, by a fraction of an
+    // already tiny margin — a few more survivors, never fewer), so (a2 + b2) is one value per column and an element costs one
+    // fma and one compare instead of an add, an fma and a compare (the pass runs at one wave per SIMD: issue-bound).
+    float ra1[QG::TM][QG::NR];
 #pragma unroll
     for (int i = 0; i < QG::TM; ++i)
 #pragma unroll
-        for (int r = 0; r < QG::NR; ++r) {
-            const int row = QG::acc_row(wave, lane, i, r);
-            ra1[i][r] = s_a1[row]; ra2[i][r] = s_a2[row];
-        }
+        for (int r = 0; r < QG::NR; ++r) ra1[i][r] = s_a1[QG::acc_row(wave, lane, i, r)];
+    float a2max = fmaxf(s_a2[(wave / QG::WN) * 128 + lane], s_a2[(wave / QG::WN) * 128 + 64 + lane]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a2max = fmaxf(a2max, __shfl_xor(a2max, o, 64));
+    const int rows_left = (int)((nq - m0) < 256 ? (nq - m0) : 256);       // rows of this tile that exist (32-bit compares below)
     int qcnt = 0;
     bool capped = false;
     // all lanes: queues -> tile list -> global slots, repeated until every queue is empty (block-uniform control flow)
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         const long p = pc0 + col;
         const bool pv = (long)n0 + col < np;
         const float v_pn = s_pn[col];
-        const float v_b2 = pv ? EPS * s_psq[col] * inv_os : -__builtin_inff();   // columns past np: the bound becomes +inf
+        const float v_nb2 = pv ? -(a2max + EPS * s_psq[col] * inv_os) : __builtin_inff();   // columns past np: the bound becomes +inf
         const bool in_mask = masked && pv && p >= mask_lo && p < mask_hi;
 #pragma unroll
         for (int i = 0; i < QG::TM; ++i) {
@@ -803,12 +808,12 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
             //  four compare masks are OR-ed on the scalar unit — a survivor is rare, the exec-mask round trip per element was not
             bool c[QG::NR];
 #pragma unroll
-            for (int r = 0; r < QG::NR; ++r) c[r] = !(acc[i][j][r] <= fmaf(ra1[i][r], v_pn, -(ra2[i][r] + v_b2))) || in_mask;
+            for (int r = 0; r < QG::NR; ++r) c[r] = !(acc[i][j][r] <= fmaf(ra1[i][r], v_pn, v_nb2)) || in_mask;
             if ((c[0] || c[1] || c[2] || c[3]) && pv) {
 #pragma unroll
                 for (int r = 0; r < QG::NR; ++r) {
                     const int row = QG::acc_row(wave, lane, i, r);
-                    if (c[r] && (long)m0 + row < nq) push(row, col, acc[i][j][r]);
+                    if (c[r] && row < rows_left) push(row, col, acc[i][j][r]);
                 }
             }
         }

@@ -70,7 +70,9 @@ class TargetVoice:
                 fs = vc.wavlm.encode_many(ws, max_batch=32, pow2_batches=True)
                 sides = M.side_features_many(ws, [f for _, f in clips[b:b + 32]], [ft.shape[0] for ft in fs])
                 feats += fs; f0s += [t[0] for t in sides]; harms += [t[1] for t in sides]
-            self.feats, self.f0, self.harm = (torch.cat(x, 0).contiguous() for x in (feats, f0s, harms))
+            from .wavlm import cat_rows
+            self.feats = cat_rows(feats).contiguous()
+            self.f0, self.harm = (torch.cat(x, 0).contiguous() for x in (f0s, harms))
             if self.feats.shape[0] < C.KNN_K:
                 raise ops.KnnSvcError(f"target pool has {self.feats.shape[0]} frames; the search needs at least {C.KNN_K}")
             self.prep = M.prepare_pool(self.feats)

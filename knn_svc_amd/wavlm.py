@@ -38,6 +38,25 @@ def _bucket_lut(T: int, num_buckets: int, max_distance: int) -> torch.Tensor:
     return out + torch.where(a < max_exact, a, large)
 
 
+def cat_rows(parts):
+    """torch.cat(parts, 0) for row-major [rows_i, E] tensors — without the copy when the parts already lie back to back in one
+    buffer (the chunks of a batch come out of encode_batch as consecutive rows of its output: a 30 s clip is ONE such view, a
+    pool of 20 clips encoded in one batch is 20 adjacent ones).  The concatenation kernels were 0.34 ms of a 35 ms step."""
+    if len(parts) == 1:
+        return parts[0]
+    first = parts[0]
+    ok = first.dim() == 2 and first.is_contiguous()
+    end = first.storage_offset() + first.numel() if ok else 0
+    for t in parts[1:]:
+        ok = (ok and t.dim() == 2 and t.is_contiguous() and t.shape[1] == first.shape[1] and t.dtype == first.dtype and
+              t.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() and t.storage_offset() == end)
+        if not ok:
+            return torch.cat(parts, 0)
+        end += t.numel()
+    rows = sum(int(t.shape[0]) for t in parts)
+    return torch.as_strided(first, (rows, first.shape[1]), (first.shape[1], 1), first.storage_offset())
+
+
 def chunk_plan(n_samples: int, sr: int = C.SAMPLE_RATE, hop: int = C.HOP):
     """get_full_wavlm_features chunking (ddsp_prematch_dataset.py:275-293): 30 s windows, tails of
     <= 0.02*sr samples dropped, zero right-pad of hop - len % hop (a full hop when aligned)."""
@@ -373,5 +392,5 @@ class WavLMEncoder:
         res = []
         for u, w in enumerate(wavs):
             parts = [pieces[(u, s_)] for (s_, _l, _p) in chunk_plan(w.numel())]
-            res.append(torch.cat(parts, 0) if parts else torch.empty(0, self.E, device=self.device))
+            res.append(cat_rows(parts) if parts else torch.empty(0, self.E, device=self.device))
         return res

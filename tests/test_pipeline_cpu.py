@@ -82,3 +82,17 @@ def test_request_queue_isolates_a_batch_that_fails_as_a_whole():
     assert rq.isolated == 1 and Conv.calls == [["a", "poison", "bcd"], ["a"], ["poison"], ["bcd"]]
     assert float(batch[0][1].result()) == 1.0 and float(batch[3][1].result()) == 3.0
     assert isinstance(batch[1][1].exception(), ValueError) and isinstance(batch[2][1].exception(), RuntimeError)
+
+
+def test_cat_rows_is_a_view_for_adjacent_parts_and_a_copy_otherwise():
+    import torch
+    from knn_svc_amd.wavlm import cat_rows
+    b = torch.arange(60.).reshape(3, 5, 4)
+    whole = cat_rows([b[i, :5] for i in range(3)])
+    assert whole.data_ptr() == b.data_ptr() and torch.equal(whole, b.reshape(15, 4))
+    assert cat_rows([b[1]]).data_ptr() == b[1].data_ptr()
+    ragged = [b[0, :4], b[1, :5]]                                  # a gap between the parts: a real concatenation
+    out = cat_rows(ragged)
+    assert out.data_ptr() != b.data_ptr() and torch.equal(out, torch.cat(ragged))
+    other = [b[0], torch.ones(2, 4)]                               # different buffers
+    assert torch.equal(cat_rows(other), torch.cat(other))
