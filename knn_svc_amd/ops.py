@@ -507,6 +507,7 @@ KNN_FUSED_MIN_Q = int(_os.environ.get("KNNSVC_KNN_FUSED_MIN_Q", "256"))
 KNN_FUSED_MIN_P = int(_os.environ.get("KNNSVC_KNN_FUSED_MIN_P", "8192"))
 KNN_FUSED_CAP = 4096
 KNN_OVERFLOW = 2                  # flag bit: the fused route's candidate buffer overflowed
+KNN_DEBUG_COUNTS = None
 KNN_EPOCH_GROWTH = int(_os.environ.get("KNNSVC_KNN_EPOCH_GROWTH", "4"))
 KNN_COLD_TILES_MAX = 44           # column tiles of the first epoch: ~45 candidates per (row, tile) have to fit the buffer twice over
 
@@ -577,6 +578,8 @@ def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offse
             check(lib.knnsvc_knn_screen(_p(q2[q0:]), _p(q_slot), _p(qn[q0:]), _p(qs[q0:]), m, _p(p2[c0 * row_u16:]), _p(p_slot), _p(pn[c0:]),
                                         _p(ps[c0:]), c1 - c0, dim, _p(thr) if e else _p(None), _p(thr_idx) if e else _p(None), mask[0], mask[1],
                                         c0, _p(cnt), _p(cand), KNN_FUSED_CAP, _p(None) if e else _p(bound), _p(flag), int(max_blocks), _stream()), "knn_screen")
+            if KNN_DEBUG_COUNTS is not None:           # tools/knn_prof.py: survivors per row and epoch (a clone: refine resets the counts)
+                KNN_DEBUG_COUNTS.append((e, cnt.clone()))
             check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, m, k, idx_offset, _p(None) if e else _p(bound),
                                         _p(idx_out[q0:]) if e else _p(None),
                                         _p(dist_out[q0:]) if e else _p(None), _p(idx_out[q0:]), _p(dist_out[q0:]), _p(None) if last else _p(thr),
