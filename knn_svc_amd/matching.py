@@ -103,7 +103,8 @@ def side_features_many(wavs_gpu, f0s_host, Ts):
 def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_weights=None, device="cuda",
                           duration_limit=None, vad_trigger_level=0, shard_files=False, gather=False):
     """Per-file dicts (matching_pool, synth_pool, audio_synth_pool, spec_synth_pool, f0_pool, harmonics_pool),
-    like the reference.  matching == synth features (both weightings are the same one-hot on the live path);
+    like the reference.  matching == synth features under the encoder's CURRENT layer mix (both weightings are the same one-hot on
+    the live path; match_at_inference_time calls this once per weighting when they differ);
     ``audio_synth_pool`` is kept as None values: the live path never reads it (audio_out_feats_weighted = None,
     ddsp_prematch_dataset.py:1368).  Per-file results are kept in the device-resident pool store
     (knn_svc_amd/pool_cache.py) so that dataset mode encodes every file once instead of once per speaker pair.
@@ -295,8 +296,10 @@ def wait_for_neighbours(nn_item, ready_event, device):
 
 
 def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
-                   return_debug=False, nn32=None, nan_flags=None, pool_prep=None):
-    """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors.  ``nn32`` may carry
+                   return_debug=False, nn32=None, nan_flags=None, pool_prep=None, synth_list=None):
+    """The per-query body (ddsp_prematch_dataset.py:1189-1450) on device tensors.  ``synth_list``: the pool under the SYNTHESIS
+    layer weighting when it differs from the matching one (:349-350, 1157): the search and the concat re-selection run on
+    ``matching_list``, the smoothness weights and the weighted sums on ``synth_list`` (:1260, 1347-1350).  ``nn32`` may carry
     neighbours already found by the pool-sharded search (knn_svc_amd.dist.sharded_knn).  ``nan_flags``: a
     list that receives the kNN NaN flag instead of the host checking it here (the caller then calls
     ``ops.raise_if_nan`` on each entry once everything is enqueued — keeps a stream pipeline free of syncs)."""
@@ -333,9 +336,10 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
     idx = nn32[:, :C.KNN_USE].contiguous()
     if cw != -1:
         idx = ops.concat_reselect(idx, q, qn, P, pn, concat_weight=cw)
+    Ps = synth_list if synth_list is not None else P
     if run_adam:
-        w, it1 = ops.smooth_weights(idx, P, 0.1, return_iters=True)
-    out_feats = ops.weighted_gather(idx, w, P)
+        w, it1 = ops.smooth_weights(idx, Ps, 0.1, return_iters=True)
+    out_feats = ops.weighted_gather(idx, w, Ps)
     main.wait_stream(side)
     for t in (shifted, idx2, harm_w, w2):
         if t is not None:
@@ -349,7 +353,7 @@ def match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_li
             except ops.KnnOverflow:         # the fused route's candidate buffer overflowed: once more on the dot-matrix route
                 with ops.fused_off():
                     return match_features(query_seq, query_f0, matching_list, matching_f0, harmonics_list, ckpt_type, post_opt,
-                                          return_debug=return_debug, pool_prep=pool_prep)
+                                          return_debug=return_debug, pool_prep=pool_prep, synth_list=synth_list)
     if return_debug:
         return out_feats, harm_w, shifted, dict(nn32=nn32, idx_wavlm=idx, w_wavlm=w, idx_harm=idx2, w_harm=w2,
                                                 iters_wavlm=it1 if it1 is not None else 0,
@@ -404,10 +408,11 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     if "wavlm_only" not in ckpt_type and "no_harm_no_amp" not in ckpt_type and "mix" not in ckpt_type:
         raise NotImplementedError(ckpt_type)
     # the layer weighting (ddsp_prematch_dataset.py:349-350).  matching == synth features on the live path (ddsp_matcher.py:88-89,
-    # 319: both the one-hot on layer 6); two DIFFERENT weightings would need two feature sets per file and are not supported
+    # 319: both the one-hot on layer 6).  Two DIFFERENT weightings mean two feature sets per target file: the pool is then encoded
+    # once per weighting (the reference mixes both from one forward; this case is never taken live — correctness, not speed)
     mix_m, mix_s = _mix_of(match_weights, wavlm), _mix_of(synth_weights, wavlm)
-    if mix_m != mix_s:
-        raise NotImplementedError("different matching and synthesis layer weightings")
+    if mix_m != mix_s and (pool_sharded or share_items):
+        raise NotImplementedError("different matching and synthesis layer weightings with a sharded pool")
     wavlm.set_layer_mix(mix_m)
     if src_dataset_path is None:
         assert os.path.isfile(src_wav_file)
@@ -422,6 +427,16 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     cat = lambda pool, shape: (torch.cat([pool[k] for k in keys], 0).contiguous() if keys
                                else torch.empty(shape, device=wavlm.device, dtype=torch.float32))
     matching_list, matching_f0, harmonics_list = cat(matching_pool, (0, E)), cat(f0_pool, (0,)), cat(harm_pool, (0, C.N_HARM))
+    synth_list = None
+    if mix_m != mix_s:
+        wavlm.set_layer_mix(mix_s)
+        try:
+            _m, synth_pool, _a2, _s2, _f2, _h2 = get_complete_spk_pool(ref_wav_file, wavlm, device=device, duration_limit=duration_limit)
+        finally:
+            wavlm.set_layer_mix(mix_m)
+        assert list(synth_pool) == keys
+        synth_list = cat(synth_pool, (0, E))
+        assert synth_list.shape == matching_list.shape
     shard = None
     if pool_sharded:
         shard = matching_list                                      # this rank's rows, searched locally
@@ -481,7 +496,8 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
         def body(item):
             wait_for_neighbours(nn.get(item), nn_ready.get(item), matching_list.device)      # a group search on the kNN stream
             return match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
-                                  harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item))
+                                  harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item),
+                                  synth_list=synth_list)
         # match bodies in flight at once (each is a chain of single-workgroup recurrences: more lanes = more of them side by side)
         lanes = min(int(os.environ.get("KNNSVC_MATCH_LANES", "3")), len(items)) if matching_list.is_cuda else 1   # (CPU tensors: injected kernels in the gloo tests)
         if vocode_fn is not None and len(items) > 0:

@@ -10,8 +10,9 @@ import torch
 from . import knn_ref, select_ref, smooth_ref, synth_ref, vocoder_ref, wavlm_ref
 
 
-def utterance_features(sd_w, cfg, wav_1d: torch.Tensor, f0: torch.Tensor, n_layers: int = 6) -> dict:
-    """One file of get_complete_spk_pool (ddsp_prematch_dataset.py:331-404)."""
+def utterance_features(sd_w, cfg, wav_1d: torch.Tensor, f0: torch.Tensor, n_layers: int = 6, synth_layer=None) -> dict:
+    """One file of get_complete_spk_pool (ddsp_prematch_dataset.py:331-404).  ``synth_layer``: a synthesis weighting that is the
+    one-hot on another layer than the matching weighting (:349-350: two feature sets per file) -> extra entry "feats_synth"."""
     feats = wavlm_ref.full_features(sd_w, cfg, wav_1d, n_layers)
     T = len(feats)
     assert len(wav_1d) >= 320 * T
@@ -20,15 +21,19 @@ def utterance_features(sd_w, cfg, wav_1d: torch.Tensor, f0: torch.Tensor, n_laye
     spec = spec[:T]
     assert abs(len(f0) - T) <= 1 and len(f0) >= T
     f0 = f0[:T].float()
-    return dict(feats=feats, spec=spec, f0=f0, harm=synth_ref.harmonic_amps(spec, f0))
+    out = dict(feats=feats, spec=spec, f0=f0, harm=synth_ref.harmonic_amps(spec, f0))
+    if synth_layer is not None and synth_layer != n_layers:
+        out["feats_synth"] = wavlm_ref.full_features(sd_w, cfg, wav_1d, synth_layer)
+        assert out["feats_synth"].shape == feats.shape
+    return out
 
 
-def build_pool(sd_w, cfg, wavs, f0s, duration_limit=None, n_layers: int = 6) -> dict:
+def build_pool(sd_w, cfg, wavs, f0s, duration_limit=None, n_layers: int = 6, synth_layer=None) -> dict:
     """Concatenated pool over utterances with the overshooting duration limit
     (ddsp_prematch_dataset.py:408-411, 1152-1168)."""
     parts, dur = [], 0.0
     for w, f in zip(wavs, f0s):
-        u = utterance_features(sd_w, cfg, w, f, n_layers)
+        u = utterance_features(sd_w, cfg, w, f, n_layers, synth_layer)
         parts.append(u)
         dur += len(u["spec"]) * 320 / 16000
         if duration_limit is not None and dur >= duration_limit:
@@ -40,15 +45,16 @@ def match(query: dict, pool: dict, ckpt_type: str = "mix", post_opt: str = "no_p
           return_debug: bool = False):
     """The per-query body of match_at_inference_time (ddsp_prematch_dataset.py:1189-1450)."""
     q, P = query["feats"], pool["feats"]
+    Ps = pool.get("feats_synth", P)      # synth_list (:1157, 1260, 1347): what is gathered and smoothed; the search runs on matching_list
     nn32, _ = knn_ref.knn_topk(q, P, k=32)
     f0s = select_ref.shift_query_f0(query["f0"], pool["f0"])
     cw, run_adam = select_ref.parse_post_opt(post_opt)
     idx = nn32[:, :4].clone()
     if cw != -1:
         idx = select_ref.concat_reselect(idx, q, P, concat_weight=cw)
-    gathered = P[idx.reshape(-1)].reshape(idx.shape[0], 4, P.shape[-1])
+    gathered = Ps[idx.reshape(-1)].reshape(idx.shape[0], 4, Ps.shape[-1])
     if run_adam:
-        w = smooth_ref.smooth_weights(idx, P, 0.1)
+        w = smooth_ref.smooth_weights(idx, Ps, 0.1)
     else:
         w = torch.softmax(torch.ones(idx.shape), dim=1)
     out_feats = torch.sum(gathered * w[..., None], dim=1).float()
@@ -72,11 +78,11 @@ def match(query: dict, pool: dict, ckpt_type: str = "mix", post_opt: str = "no_p
 
 
 def convert(sd_w, cfg_w, sd_g, h, kind, src_wav, src_f0, pool_wavs, pool_f0s, ckpt_type="mix",
-            post_opt="no_post_opt", duration_limit=None, n_layers: int = 6) -> torch.Tensor:
+            post_opt="no_post_opt", duration_limit=None, n_layers: int = 6, synth_layer=None) -> torch.Tensor:
     """special_match minus file I/O (ddsp_matcher.py:937-995).  special_match does not forward
     post_opt for wavlm_only / no_harm_no_amp checkpoints (ddsp_matcher.py:970)."""
     query = utterance_features(sd_w, cfg_w, src_wav, src_f0, n_layers)
-    pool = build_pool(sd_w, cfg_w, pool_wavs, pool_f0s, duration_limit, n_layers)
+    pool = build_pool(sd_w, cfg_w, pool_wavs, pool_f0s, duration_limit, n_layers, synth_layer)
     f0only = "wavlm_only" in ckpt_type or "no_harm_no_amp" in ckpt_type
     out_feats, harm_w, f0s = match(query, pool, ckpt_type, "no_post_opt" if f0only else post_opt)
     y = vocoder_ref.synthesizer(sd_g, h, kind, out_feats[None], f0s[None, :, None],

@@ -391,8 +391,9 @@ def gen_e2e():
     onehot = torch.zeros(cfg["encoder_layers"] + 1); onehot[2] = 1      # "layer 6" of the tiny model
     weights = onehot[:, None]
     res = {}
-    for kind, ckpt, post_opt, seed in (("mix", "mix", "post_opt_0.2", 63), ("mix", "mix", "no_post_opt", 63),
-                                       ("f0", "wavlm_only", "no_post_opt", 64)):
+    synth1 = torch.zeros(cfg["encoder_layers"] + 1); synth1[1] = 1      # a DIFFERENT synthesis weighting: the one-hot on layer 1
+    for kind, ckpt, post_opt, seed, sw in (("mix", "mix", "post_opt_0.2", 63, None), ("mix", "mix", "no_post_opt", 63, None),
+                                           ("f0", "wavlm_only", "no_post_opt", 64, None), ("mix", "mix", "post_opt_0.2", 63, synth1[:, None])):
         sdg = S.seeded_state(S.generator_param_spec(h, kind), seed)
         gen = ref_generator(h, kind, sdg)
         knn = R_m.KNeighborsVC(m, gen, AttrDict(dict(h)), "cpu")
@@ -400,7 +401,7 @@ def gen_e2e():
         srcp = str(tmp / "a" / "src.wav")
         with quiet():
             if kind == "mix":
-                of, hf, _, sf0 = R_dp.match_at_inference_time(Path(srcp), tmp / "b", m, weights, weights, device="cpu",
+                of, hf, _, sf0 = R_dp.match_at_inference_time(Path(srcp), tmp / "b", m, weights, weights if sw is None else sw, device="cpu",
                                                                prioritize_f0=True, ckpt_type=ckpt, post_opt=post_opt,
                                                                tgt_dataset_path=tmp, duration_limit=7)
                 y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None], hf[srcp][None]).squeeze()
@@ -410,9 +411,9 @@ def gen_e2e():
                                                           tgt_dataset_path=tmp, duration_limit=7)
                 y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None]).squeeze()
         mine = pipeline_ref.convert(sdw, cfg, sdg, h, kind, src_w, src_f, pool_w, pool_f, ckpt, post_opt,
-                                    duration_limit=7, n_layers=2)
-        eq(y, mine, f"e2e {ckpt} {post_opt}", tol=2e-5)
-        res[f"{ckpt}__{post_opt}"] = y.numpy()
+                                    duration_limit=7, n_layers=2, synth_layer=None if sw is None else 1)
+        eq(y, mine, f"e2e {ckpt} {post_opt}" + ("" if sw is None else " synth layer 1"), tol=2e-5)
+        res[f"{ckpt}__{post_opt}" + ("" if sw is None else "__synth_layer1")] = y.numpy()
         print(f"     {ckpt} {post_opt}: {tuple(y.shape)} rms {y.pow(2).mean().sqrt():.4f}")
     save("g11_e2e", src_seed=81, pool_seed0=82, f0_scale=1.25, duration_limit=7, **res)
 

@@ -185,6 +185,18 @@ def test_e2e_tiny_golden(golden, tmp_path):
         print(f"e2e {ckpt} {post_opt}: waveform rms error {r:.2e} (signal rms {float(np.sqrt((ref ** 2).mean())):.3f})")
         assert y.shape[0] == ref.shape[0]
         assert r < 1e-4, (ckpt, post_opt, r)      # north-star tolerance: waveform within 1e-4 RMS
+    # different matching and synthesis layer weightings (ddsp_prematch_dataset.py:349-350: two feature sets per target file — the
+    # search runs on the matching features, the smoothness weights and the weighted sums on the synthesis features)
+    sdg = S.seeded_state(S.generator_param_spec(h, "mix"), 63)
+    knn = KNeighborsVC(enc, Vocoder(sdg, h, "mix", DEV), h, DEV)
+    synth1 = torch.zeros_like(knn.weighting); synth1[1] = 1.0
+    of, hw, _a, sf0 = match_at_inference_time(srcp, poolp, enc, knn.weighting, synth1, prioritize_f0=True, ckpt_type="mix",
+                                              post_opt="post_opt_0.2", tgt_dataset_path=tmp_path, duration_limit=int(g["duration_limit"]))
+    y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None], hw[srcp][None]).squeeze()
+    r = _rms(y, g["mix__post_opt_0.2__synth_layer1"])
+    print(f"e2e mix post_opt_0.2, synthesis weighting on layer 1: waveform rms error {r:.2e}")
+    assert r < 1e-4 and _rms(y, g["mix__post_opt_0.2"]) > 1e-3            # ... and it is not the equal-weighting result
+    assert enc.layer_mix is None                                           # the shared encoder is back on the matching weighting
 
 
 def test_special_match_writes_reference_named_file(golden, tmp_path):
