@@ -381,9 +381,11 @@ class WavLMEncoder:
                 sub = grp[i:i + n]
                 i += n
                 buf = torch.zeros(len(sub), Lb, device=self.device, dtype=torch.float32)
+                dsts, srcs = [], []
                 for r, (u, s_, l, _t) in enumerate(sub):
                     k = min(l, Lb)
-                    buf[r, :k] = wavs[u][s_:s_ + k]
+                    dsts.append(buf[r, :k]); srcs.append(wavs[u][s_:s_ + k])
+                torch._foreach_copy_(dsts, srcs)             # one multi-tensor launch instead of one copy kernel per chunk
                 exact = all(t == Tb for (_u, _s, _l, t) in sub)
                 lens = None if exact else torch.tensor([t for (_u, _s, _l, t) in sub], dtype=torch.int32).to(self.device, non_blocking=True)
                 out = self.encode_batch(buf, lens)

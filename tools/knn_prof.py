@@ -62,8 +62,11 @@ for e, t in enumerate(calls):
     if e == 0:
         c = t[t[:, 7] > t[:, 1]]
         if len(c):
-            print(f" cold tiles ({len(c)}): local bound {np.mean(c[:, 7] - c[:, 1]) * 0.01:.1f} us, publish + wait {np.mean(c[:, 5] - c[:, 7]) * 0.01:.1f}, "
-                  f"read + select {np.mean(c[:, 6] - c[:, 5]) * 0.01:.1f}, set_row + atomics + barrier {np.mean(c[:, 2] - c[:, 6]) * 0.01:.1f}, "
+            xch = bool((c[:, 5] > c[:, 7]).all())          # slots 5 / 6 are only stamped by tiles that exchange bounds
+            mid = (f"publish + wait {np.mean(c[:, 5] - c[:, 7]) * 0.01:.1f}, read + select {np.mean(c[:, 6] - c[:, 5]) * 0.01:.1f}, "
+                   f"set_row + atomics + barrier {np.mean(c[:, 2] - c[:, 6]) * 0.01:.1f}, " if xch else
+                   f"(no exchange: fewer than 20 column tiles) set_row + barrier {np.mean(c[:, 2] - c[:, 7]) * 0.01:.1f}, ")
+            print(f" cold tiles ({len(c)}): local bound {np.mean(c[:, 7] - c[:, 1]) * 0.01:.1f} us, " + mid +
                   f"coarse + drains {np.mean(c[:, 3] - c[:, 2]) * 0.01:.1f} (p90 {np.percentile(c[:, 3] - c[:, 2], 90) * 0.01:.1f}), last drain "
                   f"{np.mean(c[:, 4] - c[:, 3]) * 0.01:.1f}, main loop {np.mean(c[:, 1] - c[:, 0]) * 0.01:.1f}, tile {np.mean(c[:, 4] - c[:, 0]) * 0.01:.1f} "
                   f"(max {np.max(c[:, 4] - c[:, 0]) * 0.01:.1f}), kernel span {(c[:, 4].max() - c[:, 0].min()) * 0.01:.1f} us")
