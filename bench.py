@@ -174,7 +174,9 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
     # The encoder is enqueued first (its first kernels are long, so the host runs ahead); STFT / harmonic
     # amplitudes only need the raw audio and run on a second stream next to it.
     main = torch.cuda.current_stream()
-    side = _FRONT_SIDE.setdefault(src.device, torch.cuda.Stream(device=src.device))
+    if src.device not in _FRONT_SIDE:                    # (created once: `setdefault(..., Stream())` took a pool stream per step)
+        _FRONT_SIDE[src.device] = torch.cuda.Stream(device=src.device)
+    side = _FRONT_SIDE[src.device]
     side.wait_stream(main)
     with stage("wavlm"):
         feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
@@ -211,15 +213,23 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
         if rank != owner:
             return None
         return dict(qf=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, nn32=nn32)
-    # the pool all-gather (123 MB per rank) starts now and travels under the local kNN search; waited for below
+    # The pool all-gathers start now and travel under the local kNN search; waited for below.  Two collectives, not three: f0 and
+    # harmonics go as one [Np, 1 + 49] message — every collective the searching stream has to WAIT for costs the scheduling latency of
+    # a kernel on RCCL's stream next to a busy chip (tools/bench_1rank_ab.sh), and these two are off the critical path altogether.
     P, wait_P = kdist.all_gather_rows_async(P_loc)
+    side_loc = torch.cat([Pf0_loc[:, None], Ph_loc], 1) if dist.is_initialized() else None
+    if side_loc is not None:
+        side_all, wait_side = kdist.all_gather_rows_async(side_loc)
     with stage("knn"):
         # equal shards by construction: pass the sizes instead of letting sharded_knn read them back (a host sync)
         nn32, _ = kdist.sharded_knn(qf, P_loc, C.KNN_K, counts=[P_loc.shape[0]] * kdist.world()[1])
     with stage("gather"):
         wait_P()
-        Pf0 = kdist.all_gather_rows(Pf0_loc)
-        Ph = kdist.all_gather_rows(Ph_loc)
+        if side_loc is not None:
+            wait_side()
+            Pf0, Ph = side_all[:, 0].contiguous(), side_all[:, 1:].contiguous()
+        else:
+            Pf0, Ph = Pf0_loc, Ph_loc
     return dict(qf=qf, qf0=qf0, P=P, Pf0=Pf0, Ph=Ph, nn32=nn32)
 
 

@@ -792,6 +792,9 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         e[0] = ((unsigned)row << 8) | (unsigned)col;                 // comes within one column's 32 elements of the depth
         e[1] = __float_as_uint(accv * out_scale);                    // the dot product (out_scale is a power of two: exact)
         ++qcnt;
+#ifdef KN_KNN_PROF
+        ++kp_pushed;
+#endif
     };
 #pragma unroll
     for (int j = 0; j < QG::TN; ++j) {
@@ -823,7 +826,6 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         continue;
 #endif
 #ifdef KN_KNN_PROF
-        kp_pushed += qcnt;
         if (__builtin_expect(__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR), 0)) { ++kp_drains; drain_and_flush(); }
 #else
         if (__builtin_expect(__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR), 0)) drain_and_flush();      // (unlikely: laid out behind the hot path)

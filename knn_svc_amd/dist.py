@@ -197,11 +197,19 @@ def sharded_knn_owned(q_all: torch.Tensor, owner_rows, pool_local: torch.Tensor,
     idx, dst = local_topk(q_all, pool_local, k, sum(counts[:rank]))            # every row vs my shard, global ids
     mine = owner_rows[rank]
     recv = [mine] * ws                                                         # my rows' lists, one block per shard
-    d_parts = all_to_all_rows(dst, owner_rows, recv).view(ws, mine, k)
-    i_parts = all_to_all_rows(idx, owner_rows, recv).view(ws, mine, k)
+    # ONE exchange for both halves of the lists: (distance bits, index) packed as three 32-bit words per entry.  Every collective
+    # is a point where the searching stream waits for a kernel on RCCL's stream to be scheduled — next to a chip full of
+    # another conversion's generator that costs a few hundred microseconds each, whatever the message size
+    # (tools/bench_1rank_ab.sh: a one-rank group alone cost the stream pipeline 7 % of its throughput).
+    packed = torch.empty(idx.shape + (3,), dtype=torch.int32, device=idx.device)
+    packed[..., 0] = dst.view(torch.int32)
+    packed[..., 1:] = idx.view(torch.int32).view(idx.shape + (2,))
+    got = all_to_all_rows(packed, owner_rows, recv).view(ws, mine, k, 3)
     if mine == 0:
         return idx[:0], dst[:0]
-    return merge(d_parts.contiguous(), i_parts.contiguous())
+    d_parts = got[..., 0].contiguous().view(torch.float32)
+    i_parts = got[..., 1:].contiguous().view(torch.int64).view(ws, mine, k)
+    return merge(d_parts, i_parts)
 
 
 def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, local_topk=None,
@@ -228,7 +236,11 @@ def sharded_knn(q_local: torch.Tensor, pool_local: torch.Tensor, k: int = 32, lo
     assert len(counts) == ws and counts[rank] == pool_local.shape[0], (counts, rank, pool_local.shape)
     if replicated:
         idx, dst = local_topk(q_local, pool_local, k, sum(counts[:rank]))
-        return merge(all_gather_rows(dst[None]).contiguous(), all_gather_rows(idx[None]).contiguous())
+        packed = torch.empty((1,) + idx.shape + (3,), dtype=torch.int32, device=idx.device)      # one all-gather for both halves
+        packed[0, ..., 0] = dst.view(torch.int32)
+        packed[0, ..., 1:] = idx.view(torch.int32).view(idx.shape + (2,))
+        got = all_gather_rows(packed)
+        return merge(got[..., 0].contiguous().view(torch.float32), got[..., 1:].contiguous().view(torch.int64).view((ws,) + idx.shape))
     q_all = all_gather_rows(q_local)                                           # [ws*nq, D], rank-major
     return sharded_knn_owned(q_all, [nq] * ws, pool_local, k, local_topk, merge, counts)
 
