@@ -495,9 +495,9 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
             nn.update(g_nn); nn_ready.update(g_ready)
         def body(item):
             wait_for_neighbours(nn.get(item), nn_ready.get(item), matching_list.device)      # a group search on the kNN stream
+            extra = dict(synth_list=synth_list) if synth_list is not None else {}
             return match_features(query_pool[item], query_f0_pool[item], matching_list, matching_f0,
-                                  harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item),
-                                  synth_list=synth_list)
+                                  harmonics_list, ckpt_type, post_opt, nan_flags=flags, pool_prep=prep, nn32=nn.get(item), **extra)
         # match bodies in flight at once (each is a chain of single-workgroup recurrences: more lanes = more of them side by side)
         lanes = min(int(os.environ.get("KNNSVC_MATCH_LANES", "3")), len(items)) if matching_list.is_cuda else 1   # (CPU tensors: injected kernels in the gloo tests)
         if vocode_fn is not None and len(items) > 0:
