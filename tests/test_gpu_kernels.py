@@ -742,6 +742,32 @@ def test_knn_fused_epochs_equal_dot_matrix_route_at_small_sizes(nq, npool, dim, 
     assert len(ops.knn_epochs(nq, npool)) >= 1
 
 
+@pytest.mark.parametrize("k", [1, 5, 31])
+def test_knn_fused_route_small_k_and_masks_that_leave_few_rows(k, monkeypatch):
+    """The fused route for k < 32 (its first epoch always bounds a row by 32 of a tile's columns, whatever k), for a mask that
+    swallows almost the whole pool (most candidates compete at exactly 1: a 9000-way tie cut by index) and for a mask that starts
+    inside one epoch and ends inside the next — against the dot-matrix route, bit for bit."""
+    from knn_svc_amd import ops
+    q = S.clustered_features(300, 512, 61, n_centres=12).to(DEV)
+    p = S.clustered_features(9000 + 13, 512, 62, n_centres=12).to(DEV)
+    for mask in (None, (40, 9000), (2000, 6100), (0, 9013)):
+        outs = []
+        for fused in ("0", "1"):
+            monkeypatch.setenv("KNNSVC_KNN_FUSED", fused)
+            c0 = ops.KNN_ROUTE_COUNTS["fused"]
+            i, d, f = ops.knn_topk(q, p, k, mask=mask, idx_offset=7, check_nan=False, return_flag=True)
+            assert (ops.KNN_ROUTE_COUNTS["fused"] > c0) == (fused == "1")
+            fl = int(f.item())
+            if fl & ops.KNN_OVERFLOW:            # (a whole-pool tie may overflow the candidate buffer: flagged, the retry is exact)
+                assert fused == "1" and mask is not None
+                i, d = ops.knn_topk(q, p, k, mask=mask, idx_offset=7)
+            outs.append((i.cpu(), d.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (k, mask)
+        assert outs[0][0].shape == (300, k) and int(outs[0][0].min()) >= 7 and int(outs[0][0].max()) < 9013 + 7
+        if mask == (0, 9013):                    # everything competes at 1: the k lowest indices, in order
+            assert bool((outs[1][1] == 1.0).all()) and bool((outs[1][0] == torch.arange(7, 7 + k)[None, :]).all())
+
+
 def test_knn_fused_route_survives_thousands_of_identical_pool_rows_and_silence(monkeypatch):
     """with many bit-identical pool rows (digital silence) every tied row shares one dot product.  The
     thresholds of the fused route are KEYS (distance bits, pool index) over rows already searched with the SAME operand split
