@@ -615,8 +615,9 @@ def main():
                            "frac_fp32_mfma_peak_157.3": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),
                            "t_mfma_floor_ms": round(flop / (F16X2_PEAK_TFLOPS * 1e12) * 1e3, 4),
                            "t_hbm_floor_ms": round(min_bytes / 8e12 * 1e3, 4),
-                           "note": "whole stage incl. norms, operand splits, top-32 selection and the RCCL all-gather merge; "
-                                   "query_frames_per_s counts every rank's frames resolved against the whole pool"}
+                           "route": "fused (epochs of knn_screen + knn_refine on the Gemm2QuadS loop): no [Nq, Np] distance or dot matrix in HBM",
+                           "note": "whole stage incl. row norms, operand splits, both epochs' screening GEMMs and top-32 refinement, and the "
+                                   "RCCL list exchange + merge; query_frames_per_s counts every rank's frames resolved against the whole pool"}
         # measured offline with rocprofv3 --pmc (tools/pmc_traffic.py, tools/refresh_profiles.sh); bench.py cannot read PMCs itself.
         # Newest round's file whose kernel is the one reported above.
         import glob
@@ -649,8 +650,8 @@ if __name__ == "__main__":
     try:
         main()
     except ops.KnnOverflow:
-        # a row of some search had more than 4096 pool rows ahead of its threshold sample's 32nd best (adversarial data; never
-        # seen on the synthetic clips): the searches of this run are void.  Once more, every search on the dot-matrix route.
+        # a row of some search had more than 4096 survivors in one epoch (thousands of bit-identical pool rows inside the first epoch:
+        # adversarial data, never seen on the synthetic clips): the searches of this run are void.  Once more, on the dot-matrix route.
         print("bench.py: fused kNN route overflowed its candidate buffer; re-running on the dot-matrix route", file=sys.stderr)
         if dist.is_initialized():
             dist.destroy_process_group()
