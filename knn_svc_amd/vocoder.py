@@ -108,7 +108,14 @@ class Vocoder:
         self._branch = {}
 
     def _par(self) -> bool:
-        return self.parallel_resblocks and not getattr(_SERIAL, "on", False)
+        # (under an RCCL process group the branches run in series: with the communicator's streams on the card the parallel form
+        #  is the slower one — bench.py, one rank: 38.2 ms per step against 37.4; profiles/r04_rank1_rccl_ab.txt)
+        if not self.parallel_resblocks or getattr(_SERIAL, "on", False):
+            return False
+        if os.environ.get("KNNSVC_PAR_RESBLOCKS") == "1":
+            return True
+        from .pipeline import rccl_streams
+        return rccl_streams()[0] == 0
 
     def _branch_streams(self, dev):
         """Two side streams per (device, current stream) for the ResBlock branches (the generator may run on several streams)."""
