@@ -802,8 +802,10 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         const long p = pc0 + col;
         const bool pv = (long)n0 + col < np;
         const float v_pn = s_pn[col];
-        const float v_nb2 = pv ? -(a2max + EPS * s_psq[col] * inv_os) : __builtin_inff();   // columns past np: the bound becomes +inf
         const bool in_mask = masked && pv && p >= mask_lo && p < mask_hi;
+        // columns past np: the bound becomes +inf (nothing passes); a masked column: NaN (every row passes: it competes at exactly 1
+        // whatever its dot product) — both without a term in the per-element test
+        const float v_nb2 = !pv ? __builtin_inff() : in_mask ? __builtin_nanf("") : -(a2max + EPS * s_psq[col] * inv_os);
 #pragma unroll
         for (int i = 0; i < QG::TM; ++i) {
             // (NaN anywhere: the comparison fails and the pair goes to the exact test, which keeps NaN distances; a masked pool row
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
             //  four compare masks are OR-ed on the scalar unit — a survivor is rare, the exec-mask round trip per element was not
             bool c[QG::NR];
 #pragma unroll
-            for (int r = 0; r < QG::NR; ++r) c[r] = !(acc[i][j][r] <= fmaf(ra1[i][r], v_pn, v_nb2)) || in_mask;
+            for (int r = 0; r < QG::NR; ++r) c[r] = !(acc[i][j][r] <= fmaf(ra1[i][r], v_pn, v_nb2));
             if ((c[0] || c[1] || c[2] || c[3]) && pv) {
 #pragma unroll
                 for (int r = 0; r < QG::NR; ++r) {
