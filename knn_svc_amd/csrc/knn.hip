@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
         const bool v = r < nq;
         s_qn[tid] = v ? qn[r] : 0.f; s_qsq[tid] = v ? qsq[r] : 0.f;
         s_cnt[tid] = 0;
-        if (tid == 0) s_n[0] = 0;
+        if (tid == 0) { s_n[0] = 0; s_n[1] = 0; }
         const long pc = (long)n0 + tid;
         s_pn[tid] = pc < np ? pn[pc] : 0.f;
         s_psq[tid] = pc < np ? psq[pc] : 0.f;
@@ -769,6 +769,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
                 if (have && !stalled) ++e;
             }
             __syncthreads();
+            if (tid == 0) s_n[1] = 0;                                // (everybody has read the drain request by now)
             { const int c = s_cnt[tid]; s_base[tid] = c ? atomicAdd(&cand_count[m0 + tid], c) : 0; }
             __syncthreads();
             const int n = s_n[0] < SCR_LIST ? s_n[0] : SCR_LIST;
@@ -827,11 +828,17 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
 #ifdef KN_WHATIF_NOCHECK
         continue;
 #endif
+        // "does any lane's queue come within one column group of its depth?" with ONE barrier: a wave that needs the drain raises a
+        // flag in LDS (plain store, rare), everybody reads it behind the barrier; drain_and_flush lowers it again behind its own first
+        // barrier.  (__syncthreads_or is three barriers and an LDS atomic: 24 barriers per tile for a question whose answer is no.)
+        if (__ballot(qcnt > SCR_QD - QG::TM * QG::NR) != 0ull && lane == 0) s_n[1] = 1;
+        __syncthreads();
+        if (__builtin_expect(s_n[1] != 0, 0)) {                     // (unlikely: laid out behind the hot path)
 #ifdef KN_KNN_PROF
-        if (__builtin_expect(__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR), 0)) { ++kp_drains; drain_and_flush(); }
-#else
-        if (__builtin_expect(__syncthreads_or(qcnt > SCR_QD - QG::TM * QG::NR), 0)) drain_and_flush();      // (unlikely: laid out behind the hot path)
+            ++kp_drains;
 #endif
+            drain_and_flush();
+        }
     }
     KN_KP_T(3)
     drain_and_flush();
