@@ -225,16 +225,6 @@ __global__ __launch_bounds__(256) void concat_reselect_kernel(
 
 
 
-// ---------------------------------------------------------------------------------------------
-// Pipelined variant (feature dim <= 1024): 8 waves, one per candidate.  Everything frame i needs is
-// already in LDS when the frame starts: its 4 kNN rows and q[i] were prefetched during frame i-1,
-// and the "previous selection + 1" rows come from a speculative prefetch of the successors of ALL
-// eight candidates of frame i-1 (4 of them are used).  The global loads of frame i+1 are issued
-// at the top of frame i and land behind the distance reductions, so no frame waits on HBM/L2.
-//   LDS rows: A[2][4] kNN rows | S[2][8] successor rows | P[4] previous selection | Q[2] queries.
-// ---------------------------------------------------------------------------------------------
-constexpr int CT = 512;
-
 // buffer resource over a whole array (< 4 GiB: the dispatcher sends larger pools to the generic kernel)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sel_rsrc(const void* p, unsigned long long bytes) {
     const unsigned long long u = (unsigned long long)p;
@@ -243,70 +233,114 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sel_rsrc(const void* p, unsign
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)nb, 0x00020000);
 }
 
-__global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
+// ---------------------------------------------------------------------------------------------
+// Pipelined walk (feature dim <= 1024).  Everything frame i needs is in LDS when the frame starts: its 4 kNN rows and q[i] were
+// fetched during frame i-1, and the "previous selection + 1" rows come from a speculative fetch of the successors of ALL eight
+// candidates of frame i-1 (4 of them are used).  Round 3's version of this walk (8 waves, one candidate each) took 10 900 cycles
+// per frame; its cycle counters (tools/concat_prof.py) said where they went: 4 500 in the distances (one candidate per wave re-read the query and the four
+// previous rows: 196 KB of LDS reads per frame; 3 VALU per element and 12 per wave-wide sum, two waves per SIMD; then ONE lane
+// worked six sqrt / divide chains), 1 600 issuing the prefetch, 1 700 + 1 500 in the per-lane bookkeeping and the selection on
+// wave 0 (everyone else at the barrier, or running the same selection on the same SIMD), 1 200 copying rows between LDS regions.
+//   * nine waves.  Waves 0-7 compute distances; waves 0-3 fetch and stage the eight speculative successor rows and run the
+//     selection (one copy per SIMD), waves 4-7 fetch and stage the rows that do not depend on it (next kNN rows, next query);
+//     the ninth wave keeps the books (norm / f0 / id prefetch of the 13 new rows, log2 f0, next frame's tables and load
+//     offsets, idx_out) — nothing scalar is left on a wave the others wait for;
+//   * distances: wave (p, h) owns candidates 2p, 2p + 1 over column half h — seven rows of half length per wave (112 KB per
+//     frame), fused multiply-adds, and ONE transposed fold for its twelve sums (two select-and-add DPP steps leave value
+//     4 m + (lane & 3) in register m, two row rotations finish the 16 lanes of a row: 33 VALU instead of 132); the 2 x 4
+//     partial sums per distance (column half x row of lanes) meet in LDS and are added in a fixed order;
+//   * after the barrier lane ref * 8 + cand of waves 0-3 evaluates one cos_from_cd, four ds_bpermutes bring a candidate's
+//     concat costs to its lane; wave 0 publishes the kept slots and ranks, the book-keeper polls an LDS word for them
+//     and writes next frame's tables beside the staging (two barriers per frame);
+//   * the previous selection is not copied: its rows stay where they are (A[prv] / S[prv]) and are addressed through the kept
+//     slot numbers; of the eight speculative successor rows only the four kept ones are written to LDS (S[nxt][rank]), so
+//     candidate c always sits at a fixed offset;
+//   * tables (id, norm, log2 f0 per candidate; norms of the reference rows; byte offsets of the rows to prefetch; kept slots)
+//     are READ only before the first barrier of a frame and WRITTEN only after it, each by the book-keeping lane that already
+//     holds the value (a DPP row shift hands the rank of candidate c to the lane holding its successor).
+//   LDS rows: A[2][4] kNN rows | S[2][4] successors of the kept rows | Q[2] queries  (18 rows, 72 KB at D = 1024).
+// Candidate order, tie rule, sticky weight and NaN handling are those of concat_reselect_kernel above; sums of squares are
+// taken in a different order than there and with fused multiply-adds (equal up to fp32 rounding of the accumulation).
+// ---------------------------------------------------------------------------------------------
+constexpr int LT = 576;        // 8 distance waves + the book-keeper
+
+#define KN_DPPF(V, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (V)), (CTRL), 0xF, 0xF, true))
+
+template <bool use_f0>
+__global__ __launch_bounds__(LT) void concat_reselect_pipe_kernel(
     const long* __restrict__ idx_in, const float* __restrict__ q, const float* __restrict__ qn, long nq,
     const float* __restrict__ pool, const float* __restrict__ pn, long np, int dim,
-    const float* __restrict__ sf0, const float* __restrict__ pf0, int use_f0, float concat_weight,
-    long* __restrict__ idx_out) {
+    const float* __restrict__ sf0, const float* __restrict__ pf0, float concat_weight, long* __restrict__ idx_out) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     typedef __attribute__((address_space(3))) float lf;
     typedef __attribute__((address_space(3))) f32x4 lf4;
     lf* L = (lf*)sm;
     const int D = dim;
-    const int offA = 0, offS = 8 * D, offP = 24 * D, offQ = 28 * D;      // floats
-    __shared__ long s_idA[2][4], s_idS[2][8], s_idP[4];
-    __shared__ float s_pnA[2][4], s_pnS[2][8], s_pnP[4], s_qn[2], s_f0A[2][4], s_f0S[2][8], s_sf0[2];
-    __shared__ long s_idNext[2][4];        // kNN ids of frame f live in s_idNext[f & 1], loaded two frames ahead
-    __shared__ int s_slot[2][4];           // slots (0..7) of the kept candidates of frame i, i&1
-    __shared__ float s_match[NC], s_cc[KC][NC], s_base, s_wv[2];
-    // candidate table, double buffered by frame parity: frame i reads [i&1] while wave 0 fills [(i+1)&1]
-    __shared__ long s_candT[2][NC];
-    __shared__ float s_cpnT[2][NC], s_cf0T[2][NC];
-    __shared__ int s_coffT[2][NC];         // LDS float offset of each candidate row
+    const int offA = 0, offS = 8 * D, offQ = 24 * D;                       // floats: A[2][4] | S[2][8] | Q[2]
+    __shared__ int s_id[2][NC];                                            // candidate tables by frame parity
+    __shared__ float s_pn[2][NC], s_lf0[2][NC];
+    __shared__ float s_ref[2][8];          // [parity][0] |q|, [1..4] norms of the previous selection (by rank), [5] log2 source f0
+    __shared__ unsigned s_off[2][16];      // byte offsets of the 13 rows fetched DURING a frame of this parity (for the next frame)
+    __shared__ int s_rank[NC];             // last selection: rank by candidate slot (-1: dropped)
+    __shared__ int s_poff[KC], s_soff[KC]; // LDS offsets (floats) of the rows kept last (by rank) and of their successors
+    __shared__ int s_done;                 // frame whose selection wave 0 has published (the book-keeper polls it)
+    __shared__ __attribute__((aligned(16))) float s_part[48][8];   // [ref * 8 + cand][column half * 4 + row of 16 lanes]; [40] = |q[i-1] - q[i]|^2, [41..47] unused
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = (tid & 255) * 4;       // 256 threads cover one 1024-float row with float4
-    const int half = tid >> 8;             // two rows per pass
-    const bool colok = col < D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool bk = wave == 8;             // the book-keeper: no rows, no distances
+    const bool sel = wave < 4;             // runs the selection, stages the successor rows
+    const int col = (tid & 255) * 4;       // 256 threads (waves 0-3, waves 4-7) cover one 1024-float row with float4
+    const bool colok = col < D && !bk;
+    const unsigned row_bytes = (unsigned)D * 4u;
 
-    // ---- frame 0 ---------------------------------------------------------------------------------
+    // ---- frame 0 keeps its neighbours; tables, load offsets and rows of frame 1 ------------------------
     if (tid < 4) {
-        const long id = idx_in[tid];
-        idx_out[tid] = id;
-        s_idP[tid] = id; s_pnP[tid] = pn[id];
-        long sid = id + 1; if (sid >= np) sid = np - 1;
-        s_idS[0][tid] = sid; s_pnS[0][tid] = pn[sid]; s_f0S[0][tid] = use_f0 ? log2_rn(pf0[sid] + 1e-5f) : 0.f;
-        s_slot[0][tid] = tid;
-        if (nq > 2) s_idNext[0][tid] = idx_in[8 + tid];
-        if (nq > 1) { const long a = idx_in[4 + tid]; s_idA[1][tid] = a; s_pnA[1][tid] = pn[a]; s_f0A[1][tid] = use_f0 ? log2_rn(pf0[a] + 1e-5f) : 0.f; }
+        const long id0 = idx_in[tid];
+        idx_out[tid] = id0;
+        s_id[0][tid] = (int)id0;
+        s_ref[1][1 + tid] = pn[id0];
+        s_poff[tid] = offA + tid * D; s_soff[tid] = offS + (NC + tid) * D;
+        if (tid == 0) s_done = 0;
+        if (nq > 1) {
+            long sid = id0 + 1; if (sid >= np) sid = np - 1;
+            s_id[1][KC + tid] = (int)sid; s_pn[1][KC + tid] = pn[sid]; s_lf0[1][KC + tid] = use_f0 ? log2_rn(pf0[sid] + 1e-5f) : 0.f;
+            const long a = idx_in[KC + tid];
+            s_id[1][tid] = (int)a; s_pn[1][tid] = pn[a]; s_lf0[1][tid] = use_f0 ? log2_rn(pf0[a] + 1e-5f) : 0.f;
+            long sa = a + 1; if (sa >= np) sa = np - 1;
+            long ss = sid + 1; if (ss >= np) ss = np - 1;
+            s_off[1][5 + tid] = (unsigned)sa * row_bytes; s_off[1][5 + KC + tid] = (unsigned)ss * row_bytes;
+            s_off[1][tid] = nq > 2 ? (unsigned)idx_in[2 * KC + tid] * row_bytes : 0u;
+        }
     }
     if (tid == 0) {
-        s_wv[1] = concat_weight; s_qn[0] = qn[0];
-        if (nq > 1) { s_qn[1] = qn[1]; s_sf0[1] = use_f0 ? log2_rn(sf0[1] + 1e-5f) : 0.f; }
+        s_ref[0][0] = qn[0];
+        if (nq > 1) { s_ref[1][0] = qn[1]; s_ref[1][5] = use_f0 ? log2_rn(sf0[1] + 1e-5f) : 0.f; s_off[1][4] = nq > 2 ? 2u * row_bytes : 0u; }
     }
     __syncthreads();
-    if (tid < NC && nq > 1) {                // candidate table of frame 1
-        if (tid < KC) { s_candT[1][tid] = s_idA[1][tid]; s_cpnT[1][tid] = s_pnA[1][tid]; s_cf0T[1][tid] = s_f0A[1][tid]; s_coffT[1][tid] = offA + (4 + tid) * D; }
-        else { const int sl = tid - KC; s_candT[1][tid] = s_idS[0][sl]; s_cpnT[1][tid] = s_pnS[0][sl]; s_cf0T[1][tid] = s_f0S[0][sl]; s_coffT[1][tid] = offS + sl * D; }
-    }
     if (colok) {
+        const int half = tid >> 8;
         for (int r = half; r < 4; r += 2) {
-            *(lf4*)&L[offP + r * D + col] = *(const f32x4*)(pool + s_idP[r] * (long)D + col);
-            *(lf4*)&L[offS + r * D + col] = *(const f32x4*)(pool + s_idS[0][r] * (long)D + col);
-            if (nq > 1) *(lf4*)&L[offA + (4 + r) * D + col] = *(const f32x4*)(pool + s_idA[1][r] * (long)D + col);
+            *(lf4*)&L[offA + r * D + col] = *(const f32x4*)(pool + (long)s_id[0][r] * D + col);
+            if (nq > 1) {
+                *(lf4*)&L[offA + (4 + r) * D + col] = *(const f32x4*)(pool + (long)s_id[1][r] * D + col);
+                *(lf4*)&L[offS + (NC + r) * D + col] = *(const f32x4*)(pool + (long)s_id[1][KC + r] * D + col);
+            }
         }
         if (half == 0) *(lf4*)&L[offQ + col] = *(const f32x4*)(q + col);
         else if (nq > 1) *(lf4*)&L[offQ + D + col] = *(const f32x4*)(q + (long)D + col);
     }
+    // book-keeper lanes 0..3: ids of the kNN rows of frame i + 1, carried from frame to frame (loaded two frames ahead)
+    long id_a = (bk && lane < 4 && nq > 2) ? idx_in[2 * KC + lane] : 0;
     __syncthreads();
 
-    typedef unsigned g2u4 __attribute__((ext_vector_type(4)));
-    const unsigned row_bytes = (unsigned)D * 4u;
-    const int whalf = __builtin_amdgcn_readfirstlane(half);                    // waves 0-3: 0, waves 4-7: 1
     const __amdgpu_buffer_rsrc_t p_rsrc = sel_rsrc(pool, (unsigned long long)np * row_bytes), q_rsrc = sel_rsrc(q, (unsigned long long)nq * row_bytes);
+    const int dp = (wave >> 1) & 3, dh = wave & 1;         // distance work: candidate pair, column half
+    const int hcols = ((D / 4 + 1) / 2) * 4;               // columns per half (float4 granules, first half takes the odd one)
+    const bool odd1 = lane & 1, odd2 = lane & 2;
+    float w = concat_weight;                               // sticky: once 0 (f0 variant) it stays 0
 #ifdef KN_CONCAT_PROF
-    unsigned long long pf[7] = {0, 0, 0, 0, 0, 0, 0}, tq = 0;
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
 #define KN_TICK(K) { const unsigned long long now = __builtin_readcyclecounter(); pf[K] += now - tq; tq = now; }
 #else
 #define KN_TICK(K)
@@ -315,113 +349,148 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
 #ifdef KN_CONCAT_PROF
         tq = __builtin_readcyclecounter();
 #endif
-        const int cur = (int)(i & 1), prv = cur ^ 1;
-        const long* s_cand = s_candT[cur]; const float* s_cpn = s_cpnT[cur]; const float* s_cf0 = s_cf0T[cur];
-        const int* s_coff = s_coffT[cur];
-        // ---- (a) prefetch for frame i+1 into registers: 4 kNN rows, q[i+1], 8 successor rows --------
+        const int cur = (int)(i & 1), nxt = cur ^ 1;
         const bool more = (i + 1 < nq);
-        f32x4 pre[7];
-        long my_id = 0, nn_id = 0; float my_pn = 0.f, my_f0 = 0.f; int my_kind = -1;   // per-thread scalar prefetch (tid < 13)
-        {
-            // row list r = 2 t + half: 0-3 -> A[i+1], 4 -> q[i+1], 5-12 -> successors of cand[0..7], 13 -> nothing.
-            // Every load is UNCONDITIONAL (rows that are not needed read a harmless row and are dropped in (d)): with the loads
-            // inside branches each one sat in its own basic block and waited for its predecessor — 3700 cycles per frame just to
-            // issue seven loads (in-kernel cycle counters, tools/concat_prof.py), the largest single item of a 12 500-cycle frame.
-            // Addresses cost no vector work either: lane r of every wave turns row r's id into a 32-bit byte offset once, the
-            // offset travels to an SGPR (v_readlane) and the load is buffer_load_dwordx4 v, col * 4, rsrc, soffset.
-            unsigned my_off = 0;
-            if (lane < 4) my_off = more ? (unsigned)s_idNext[prv][lane] * row_bytes : 0u;
-            else if (lane == 4) my_off = more ? (unsigned)(i + 1) * row_bytes : 0u;
-            else if (lane < 13) { long sid = s_cand[lane - 5] + 1; sid = sid >= np ? np - 1 : sid; my_off = (unsigned)sid * row_bytes; }
-            const int voff = (colok ? col : 0) * 4;
-#pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const int r0 = 2 * t, r1 = 2 * t + 1 < 13 ? 2 * t + 1 : 12;             // this wave's row is r0 (half 0) or r1 (half 1)
-                const unsigned o0 = __builtin_amdgcn_readlane(my_off, r0), o1 = __builtin_amdgcn_readlane(my_off, r1);
-                const unsigned so = whalf ? o1 : o0;
-#ifdef KN_CONCAT_NOLOAD        // what-if: no row loads at all (results are garbage)
-                pre[t] = (f32x4){(float)so, 0.f, 0.f, 0.f};
-                continue;
+        f32x4 pre[8];
+        int rid = 0; long my_id = 0, nn_id = 0; float my_pn = 0.f, my_f0 = 0.f; int my_kind = -1;
+        float rpn = 0.f, rlf0 = 0.f, xref = 0.f, qn_prv = 0.f, qn_cur = 0.f, lsf0 = 0.f;
+        const int c8 = lane & 7, refi = lane >> 3;
+        int oP[KC] = {0, 0, 0, 0}, oS[KC] = {0, 0, 0, 0};      // LDS offsets of the previous selection / of candidates 4..7 (wave-uniform)
+        if (bk) {
+            // ---- book-keeper: norm / f0 of the 13 rows being fetched, the kNN ids two frames ahead; lanes 0-3 kNN rows of
+            //      frame i + 1, lane 4 its query, lanes 5-12 successors of this frame's candidates --------------------
+            rid = s_id[cur][c8]; rpn = s_pn[cur][c8];
+            const int l = lane < 13 ? lane : 12;
+            long sid = (long)s_id[cur][l >= 5 ? l - 5 : 0] + 1; sid = sid >= np ? np - 1 : sid;
+            const long row = l < 4 ? (more ? id_a : 0) : (l == 4 ? (more ? i + 1 : 0) : sid);
+            const float* pnp = l == 4 ? qn : pn;
+            const float* pfp = use_f0 ? (l == 4 ? sf0 : pf0) : pnp;                         // any valid address when f0 is off
+            my_pn = pnp[row]; my_f0 = pfp[row];
+            nn_id = idx_in[(i + 2 < nq ? (i + 2) * KC : 0) + (l & 3)];
+            my_kind = lane < 13 ? (l < 4 ? (more ? 0 : -1) : (l == 4 ? (more ? 1 : -1) : 2)) : -1;
+            my_id = (my_kind == 0 || my_kind == 2) ? row : 0;
+            if (use_f0 && my_kind >= 0) my_f0 = log2_rn(my_f0 + 1e-5f);      // one evaluation per new row, behind the others' distances
+            else my_f0 = 0.f;
+            KN_TICK(0)
+            KN_TICK(1)
+        } else {
+            // ---- row prefetch for frame i+1: waves 0-3 the 4 kNN rows and q[i+1] (rows 0-4 of the offset list) before their
+            //      distances, waves 4-7 the successors of all 8 candidates (rows 5-12) in the middle of theirs.  Every load is
+            //      unconditional (rows that are not needed read a harmless row); the byte offset of row r travels from lane r to
+            //      an SGPR: buffer_load_dwordx4 v, col * 4, rsrc, soffset.
+#ifdef KN_CONCAT_WHATIF_L2      // timing aid: every fetch hits the same 16 rows (cache hits); results are garbage
+            const unsigned my_off = (unsigned)(lane & 15) * row_bytes + 0u * s_off[cur][lane & 15];
+#else
+            const unsigned my_off = s_off[cur][lane & 15];
 #endif
-                if (t == 2) {                            // r0 = 4 is the query row (its own resource), r1 = 5 a pool row
-                    const g2u4 vq = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, voff, o0, 0);
-                    const g2u4 vp = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, voff, o1, 0);
-                    pre[t] = __builtin_bit_cast(f32x4, whalf ? vp : vq);
-                } else {
-                    pre[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, voff, so, 0));
-                }
-            }
-            // The per-row scalars (norm, f0, the kNN ids two frames ahead) of lanes 0..12 of wave 0, branch-free for the same
-            // reason: inside `if (tid < 4) .. else if ..` the compiler put s_waitcnt vmcnt(0) at the joins, and wave 0 sat out
-            // the full latency of the row loads it had just issued — with every other wave waiting for it at the barrier.
-            if (wave == 0) {                         // wave-uniform: only wave 0 keeps these values
-                const int l = tid < 13 ? tid : 12;
-                const long kid = more ? s_idNext[prv][l & 3] : 0;                              // kind 0: a kNN row of frame i + 1
-                long sid = s_cand[l >= 5 ? l - 5 : 0] + 1; sid = sid >= np ? np - 1 : sid;      // kind 2: a successor row
-                const long row = l < 4 ? kid : (l == 4 ? (more ? i + 1 : 0) : sid);
-                const float* pnp = l == 4 ? qn : pn;
-                const float* pfp = use_f0 ? (l == 4 ? sf0 : pf0) : pnp;                         // any valid address when f0 is off
-                // issued here, first touched at the end of the frame: any use of the loaded values up here (even a select) makes
-                // the compiler wait for them on the spot — behind the eight row loads, which return in order
-                my_pn = pnp[row]; my_f0 = pfp[row];
-                nn_id = idx_in[(i + 2 < nq ? (i + 2) * KC : 0) + (l & 3)];
-                my_kind = tid < 13 ? (l < 4 ? (more ? 0 : -1) : (l == 4 ? (more ? 1 : -1) : 2)) : -1;
-                my_id = (my_kind == 0 || my_kind == 2) ? row : 0;
-            }
-        }
-        KN_TICK(0)
-        // ---- (b) distances: wave b owns candidate b ---------------------------------------------------
-        {
-            const int coff = s_coff[wave];
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
-            for (int c = lane * 4; c < D; c += 256) {
-                const f32x4 cv = *(const lf4*)&L[coff + c];
-                const f32x4 qv = *(const lf4*)&L[offQ + cur * D + c];
-                const f32x4 p0 = *(const lf4*)&L[offP + c], p1 = *(const lf4*)&L[offP + D + c];
-                const f32x4 p2 = *(const lf4*)&L[offP + 2 * D + c], p3 = *(const lf4*)&L[offP + 3 * D + c];
+            const int voff = (colok ? col : 0) * 4;
+            if (sel) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float d;
-                    d = qv[e] - cv[e]; a0 += d * d;
-                    d = p0[e] - cv[e]; a1 += d * d;
-                    d = p1[e] - cv[e]; a2 += d * d;
-                    d = p2[e] - cv[e]; a3 += d * d;
-                    d = p3[e] - cv[e]; a4 += d * d;
-                }
-                if (wave == 0) {
-                    const f32x4 qp = *(const lf4*)&L[offQ + prv * D + c];
+                for (int t = 0; t < 5; ++t)
+                    pre[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(t == 4 ? q_rsrc : p_rsrc, voff, __builtin_amdgcn_readlane(my_off, t), 0));
+            }
+            // ---- table reads of this frame (tables are only written between the barriers) ------------------------
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = qp[e] - qv[e]; a5 += d * d; }
+            for (int a = 0; a < KC; ++a) { oP[a] = __builtin_amdgcn_readfirstlane(s_poff[a]); oS[a] = __builtin_amdgcn_readfirstlane(s_soff[a]); }
+            if (sel) {
+                rpn = s_pn[cur][c8]; rlf0 = s_lf0[cur][c8];
+                xref = s_ref[cur][refi < 5 ? refi : 0];
+                qn_prv = s_ref[nxt][0]; qn_cur = s_ref[cur][0]; lsf0 = s_ref[cur][5];
+            }
+            KN_TICK(0)
+            // ---- (b) squared distances: wave (dp, dh) = candidates 2 dp, 2 dp + 1 against q and the four previous rows,
+            //      column half dh; the waves of pair 0 add |q[i-1] - q[i]|^2 -----------------------------------------
+            const int oC0 = dp < 2 ? offA + (cur * 4 + 2 * dp) * D : oS[dp == 2 ? 0 : 2];
+            const int oC1 = dp < 2 ? oC0 + D : oS[dp == 2 ? 1 : 3];
+            const int oQ = offQ + cur * D, oQp = offQ + nxt * D;
+            float v[12];                        // v[2 ref + cc]: candidate 2 dp + cc against reference ref; v[10] the baseline
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && !sel) {           // waves 4-7 fetch between their column steps: the texture path takes ~16 cycles per
+#pragma unroll                                  // 1 KB request, and eight waves asking at once only wait for each other
+                    for (int t = 0; t < NC; ++t)
+                        pre[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, voff, __builtin_amdgcn_readlane(my_off, 5 + t), 0));
+                }
+                const int cl = lane * 4 + 256 * k, c = dh * hcols + cl;
+                if (cl < hcols && c < D) {
+                    const f32x4 x0 = *(const lf4*)&L[oC0 + c], x1 = *(const lf4*)&L[oC1 + c];
+                    const f32x4 qv = *(const lf4*)&L[oQ + c];
+                    const f32x4 p0 = *(const lf4*)&L[oP[0] + c], p1 = *(const lf4*)&L[oP[1] + c];
+                    const f32x4 p2 = *(const lf4*)&L[oP[2] + c], p3 = *(const lf4*)&L[oP[3] + c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float d;
+                        d = qv[e] - x0[e]; v[0] = fmaf(d, d, v[0]);
+                        d = qv[e] - x1[e]; v[1] = fmaf(d, d, v[1]);
+                        d = p0[e] - x0[e]; v[2] = fmaf(d, d, v[2]);
+                        d = p0[e] - x1[e]; v[3] = fmaf(d, d, v[3]);
+                        d = p1[e] - x0[e]; v[4] = fmaf(d, d, v[4]);
+                        d = p1[e] - x1[e]; v[5] = fmaf(d, d, v[5]);
+                        d = p2[e] - x0[e]; v[6] = fmaf(d, d, v[6]);
+                        d = p2[e] - x1[e]; v[7] = fmaf(d, d, v[7]);
+                        d = p3[e] - x0[e]; v[8] = fmaf(d, d, v[8]);
+                        d = p3[e] - x1[e]; v[9] = fmaf(d, d, v[9]);
+                    }
+                    if (dp == 0) {
+                        const f32x4 qp = *(const lf4*)&L[oQp + c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float d = qp[e] - qv[e]; v[10] = fmaf(d, d, v[10]); }
+                    }
                 }
             }
-            a0 = wave_sum_dpp(a0); a1 = wave_sum_dpp(a1); a2 = wave_sum_dpp(a2); a3 = wave_sum_dpp(a3); a4 = wave_sum_dpp(a4);
-            if (wave == 0) a5 = wave_sum_dpp(a5);
-            if (lane == 0) {
-                const float cn = s_cpn[wave];
-                s_match[wave] = cos_from_cd(a0, s_qn[cur], cn);
-                s_cc[0][wave] = cos_from_cd(a1, s_pnP[0], cn);
-                s_cc[1][wave] = cos_from_cd(a2, s_pnP[1], cn);
-                s_cc[2][wave] = cos_from_cd(a3, s_pnP[2], cn);
-                s_cc[3][wave] = cos_from_cd(a4, s_pnP[3], cn);
-                if (wave == 0) s_base = cos_from_cd(a5, s_qn[prv], s_qn[cur]) * 2.0f;
+            // transposed fold: after step 1 even lanes hold v[2j], odd lanes v[2j+1] (summed over lane pairs); after step 2
+            // register m holds v[4m + (lane & 3)] summed over the quad; two rotations by 4 and 8 lanes finish the row of 16
+            float r1[6], r2[3];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float keep = odd1 ? v[2 * j + 1] : v[2 * j], send = odd1 ? v[2 * j] : v[2 * j + 1];
+                r1[j] = keep + KN_DPPF(send, 0xB1);                       // quad_perm [1,0,3,2]
             }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float keep = odd2 ? r1[2 * m + 1] : r1[2 * m], send = odd2 ? r1[2 * m] : r1[2 * m + 1];
+                r2[m] = keep + KN_DPPF(send, 0x4E);                       // quad_perm [2,3,0,1]
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                r2[m] += KN_DPPF(r2[m], 0x124);                           // row_ror:4
+                r2[m] += KN_DPPF(r2[m], 0x128);                           // row_ror:8
+            }
+            if ((lane & 15) < 4) {
+                const int j = lane & 3, rowq = lane >> 4;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int idx = 4 * m + j;                            // = 2 ref + cc; 10: baseline; 11: nothing
+                    const int e = idx < 10 ? (idx >> 1) * 8 + 2 * dp + (idx & 1) : (idx == 10 && dp == 0 ? 40 : 41 + dp);
+                    s_part[e][dh * 4 + rowq] = r2[m];
+                }
+            }
+            KN_TICK(1)
         }
-        KN_TICK(1)
         __syncthreads();
         KN_TICK(2)
-        // ---- (c) costs, lower median over the previous selection, 4 smallest.  Every wave evaluates the
-        // same 8-lane decision redundantly (it only reads LDS), so no barrier is needed before (d). ------
+        // ---- (c) waves 0-3 (one per SIMD): lane ref * 8 + cand evaluates one distance (lane 40: the baseline), candidates'
+        //      lanes collect their costs, lower median over the previous selection, 4 smallest; wave 0 publishes ----------
         int my_slot = -1;                       // lane < 8: rank of candidate `lane` if kept
-        {
-            float total = __builtin_inff();
-            const float base = s_base;
-            float w = s_wv[cur];
+        if (sel) {
+            const int pl = lane < 41 ? lane : 40;
+            const f32x4 pa = *(const f32x4*)&s_part[pl][0], pb = *(const f32x4*)&s_part[pl][4];
+            const float h0 = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            const float h1 = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+            const float ss = h0 + h1;
+            const float val = cos_from_cd(ss, lane < 40 ? xref : qn_prv, lane < 40 ? rpn : qn_cur);
+            const float base = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), 40)) * 2.0f;
+            float c4[KC];
+#pragma unroll
+            for (int a = 0; a < KC; ++a) c4[a] = __shfl(val, 8 * (a + 1) + c8, 64);
             if (use_f0 && !(base < 0.08f)) w = 0.f;
+            float total = __builtin_inff();
             if (lane < NC) {
-                float c4[KC];
 #pragma unroll
                 for (int a = 0; a < KC; ++a) {
-                    float c = s_cc[a][lane];
+                    float c = c4[a];
                     if (use_f0) { if (base < 0.08f && c < 5.0f * base) c = 0.f; }
                     else if (c > base) c = 1.5f * c - base;
                     c4[a] = c;
@@ -429,86 +498,80 @@ __global__ __launch_bounds__(CT) void concat_reselect_pipe_kernel(
                 const float lo01 = fminf(c4[0], c4[1]), hi01 = fmaxf(c4[0], c4[1]);
                 const float lo23 = fminf(c4[2], c4[3]), hi23 = fmaxf(c4[2], c4[3]);
                 const float med = fminf(fmaxf(lo01, lo23), fminf(hi01, hi23));
-                total = w * med + s_match[lane];
-                if (use_f0) total = total + fabsf(s_cf0[lane] - s_sf0[cur]);      // both already log2(f0 + 1e-5)
+                total = w * med + val;
+                if (use_f0) total = total + fabsf(rlf0 - lsf0);            // both already log2(f0 + 1e-5)
             }
             if (!(total == total)) total = __builtin_inff();       // NaN costs rank as +inf, ties by candidate number (see above)
             int rank = 0;
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {          // v_readlane (an SGPR broadcast), not a ds_bpermute round trip per candidate
+            for (int j = 0; j < NC; ++j) {
                 const float tj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), j));
                 rank += (tj < total || (tj == total && j < lane)) ? 1 : 0;
             }
             if (lane < NC && rank < KC) my_slot = rank;
             if (wave == 0) {
-                if (my_slot >= 0) { s_slot[cur][my_slot] = lane; idx_out[i * KC + my_slot] = s_cand[lane]; }
-                if (lane == 0) s_wv[prv] = w;
+                if (lane < NC) {
+                    s_rank[lane] = my_slot;
+                    if (my_slot >= 0) {             // where the kept row lives now, where its successor is being staged
+                        const int o_mine = lane < KC ? offA + (cur * 4 + lane) * D : (lane == 4 ? oS[0] : (lane == 5 ? oS[1] : (lane == 6 ? oS[2] : oS[3])));
+                        s_poff[my_slot] = o_mine; s_soff[my_slot] = offS + (nxt * NC + lane) * D;
+                    }
+                }
+                if (lane == 0) __hip_atomic_store(&s_done, (int)i, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS ops of a wave execute in order
             }
         }
-        // slot kept at rank r, broadcast inside the wave: lane holding rank r
-        int kept[KC];
-#pragma unroll
-        for (int r = 0; r < KC; ++r) {
-            const unsigned long long bal = __ballot(my_slot == r);
-            kept[r] = (int)__builtin_ctzll(bal);
-        }
         KN_TICK(3)
-        // ---- (d) kept rows -> P, prefetched registers -> A[next], Q[next], S[cur] -----------------------
-        f32x4 keep[2];
-        if (colok) {
+        // ---- (d) prefetched rows -> LDS: waves 4-7 beside the selection S[nxt][c] = successor of candidate c (all eight: which
+        //      four are used is settled by the offsets wave 0 publishes), waves 0-3 after it A[nxt], Q[nxt] (beside the book-keeper)
+        if (more && colok) {
+            if (sel) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) keep[t] = *(const lf4*)&L[s_coff[kept[2 * t + half]] + col];
-        }
-        if (colok) {                        // P is only read in (b); kept rows live in A[cur] / S[prv], not written here
+                for (int t = 0; t < 4; ++t) *(lf4*)&L[offA + (nxt * 4 + t) * D + col] = pre[t];
+                *(lf4*)&L[offQ + nxt * D + col] = pre[4];
+            } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) *(lf4*)&L[offP + (2 * t + half) * D + col] = keep[t];
-#pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const int r = 2 * t + half;
-                if (r < 4) { if (more) *(lf4*)&L[offA + (prv * 4 + r) * D + col] = pre[t]; }
-                else if (r == 4) { if (more) *(lf4*)&L[offQ + prv * D + col] = pre[t]; }
-                else if (r < 13) *(lf4*)&L[offS + (cur * 8 + (r - 5)) * D + col] = pre[t];
+                for (int t = 0; t < NC; ++t) *(lf4*)&L[offS + (nxt * NC + t) * D + col] = pre[t];
             }
         }
         KN_TICK(4)
-        if (my_kind < 0) { my_pn = 0.f; my_f0 = 0.f; }                   // lanes / rows without a row this frame: as if never loaded
-        if (!use_f0) my_f0 = 0.f;
-        if (use_f0 && my_kind >= 0) my_f0 = log2_rn(my_f0 + 1e-5f);      // one evaluation per new row, 13 lanes of wave 0
-        // next frame's candidate table, straight from the prefetch registers of wave 0 (lanes 0..12):
-        // slots 0-3 = its kNN rows, slots 4-7 = successors of the rows kept now
-        {
-            long nid = my_id; float npn = my_pn, nf0 = my_f0;
-            int ksl = 0;
-            if (tid >= KC && tid < NC) {
-#pragma unroll
-                for (int r = 0; r < KC; ++r) if (tid - KC == r) ksl = kept[r];
+        // ---- the book-keeper writes next frame's tables as soon as wave 0 has published the selection (beside the staging) ----
+        if (bk) {
+            long nx = my_id + 1; if (nx >= np) nx = np - 1;                  // successor of a candidate of frame i + 1
+            const bool more2 = i + 2 < nq;
+            if (more) {                          // what does not depend on the selection goes first
+                if (my_kind == 0) {
+                    s_id[nxt][lane] = (int)my_id; s_pn[nxt][lane] = my_pn; s_lf0[nxt][lane] = my_f0;
+                    s_off[nxt][5 + lane] = (unsigned)nx * row_bytes;
+                    s_off[nxt][lane] = more2 ? (unsigned)nn_id * row_bytes : 0u;
+                } else if (my_kind == 1) {
+                    s_ref[nxt][0] = my_pn; s_ref[nxt][5] = my_f0;
+                    s_off[nxt][4] = more2 ? (unsigned)(i + 2) * row_bytes : 0u;
+                }
+                if (lane < 4) id_a = nn_id;
             }
-            const int src = 5 + ksl;
-            const long sid = __shfl(my_id, src, 64); const float spn = __shfl(my_pn, src, 64), sf = __shfl(my_f0, src, 64);
-            long pid = 0; float ppn = 0.f;
-            if (tid < KC) {
-#pragma unroll
-                for (int r = 0; r < KC; ++r) if (tid == r) { pid = s_cand[kept[r]]; ppn = s_cpn[kept[r]]; }
-            }
-            if (wave == 0) {
-                // every lane of wave 0 has read the old table above; LDS ops of one wave execute in order
-                if (tid < KC) { s_idP[tid] = pid; s_pnP[tid] = ppn; }
-                if (tid < KC) { s_candT[prv][tid] = nid; s_cpnT[prv][tid] = npn; s_cf0T[prv][tid] = nf0; s_coffT[prv][tid] = offA + (prv * 4 + tid) * D; }
-                else if (tid < NC) { s_candT[prv][tid] = sid; s_cpnT[prv][tid] = spn; s_cf0T[prv][tid] = sf; s_coffT[prv][tid] = offS + (cur * 8 + ksl) * D; }
+            while (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)i) __builtin_amdgcn_s_sleep(1);
+            my_slot = lane < NC ? s_rank[lane] : -1;
+            if (my_slot >= 0) idx_out[i * KC + my_slot] = (long)rid;
+            if (more) {
+                // rank of candidate c, handed to lane 5 + c (row_shr:5 inside the first row of 16 lanes)
+                const int rk_succ = __builtin_amdgcn_update_dpp(-1, my_slot, 0x115, 0xF, 0xF, false);
+                if (my_kind == 2 && rk_succ >= 0) {
+                    s_id[nxt][KC + rk_succ] = (int)my_id; s_pn[nxt][KC + rk_succ] = my_pn; s_lf0[nxt][KC + rk_succ] = my_f0;
+                    s_off[nxt][5 + KC + rk_succ] = (unsigned)nx * row_bytes;
+                }
+                if (my_slot >= 0) s_ref[nxt][1 + my_slot] = rpn;                 // norms of the rows kept now
             }
         }
-        if (tid < 4 && i + 2 < nq) s_idNext[cur][tid] = nn_id;
-        if (my_kind == 0) { s_idA[prv][tid] = my_id; s_pnA[prv][tid] = my_pn; s_f0A[prv][tid] = my_f0; }
-        else if (my_kind == 1) { s_qn[prv] = my_pn; s_sf0[prv] = my_f0; }
-        else if (my_kind == 2) { s_idS[cur][tid - 5] = my_id; s_pnS[cur][tid - 5] = my_pn; s_f0S[cur][tid - 5] = my_f0; }
         KN_TICK(5)
         __syncthreads();
         KN_TICK(6)
     }
 #ifdef KN_CONCAT_PROF
-    if (tid == 0) printf("concat prof (cycles/frame, wave 0): prefetch-issue %.0f  distances %.0f  barrier1 %.0f  select %.0f  stage(wait loads) %.0f  table %.0f  barrier2 %.0f\n",
-                         (double)pf[0] / nq, (double)pf[1] / nq, (double)pf[2] / nq, (double)pf[3] / nq, (double)pf[4] / nq, (double)pf[5] / nq, (double)pf[6] / nq);
+    if (lane == 0 && (wave == 0 || wave == 3 || wave == 5 || wave == 8))
+        printf("concat prof (cycles/frame, wave %d): loads + tables | books %.0f  distances %.0f  barrier1 %.0f  select %.0f  stage %.0f  tables (book-keeper: wait + write) %.0f  barrier2 %.0f\n",
+               wave, (double)pf[0] / nq, (double)pf[1] / nq, (double)pf[2] / nq, (double)pf[3] / nq, (double)pf[4] / nq, (double)pf[5] / nq, (double)pf[6] / nq);
 #endif
+#undef KN_TICK
 }
 
 }  // namespace
@@ -549,18 +612,21 @@ extern "C" int knnsvc_concat_reselect(const int64_t* idx_in, const float* q, con
         // one.  Debugging aid from round 3's determinism hunt (see the Makefile's note on -fno-slp-vectorize: with compiler-made
         // packed-fp32 math this kernel's sums were perturbed by MFMA-issuing neighbours on its CU; isolation removed the symptom
         // before the cause was found).
-        size_t pl = (size_t)30 * dim * 4;
+        size_t pl = (size_t)26 * dim * 4;
         { const char* e = getenv("KNNSVC_CONCAT_OWN_CU"); if (e && e[0] == '1' && pl < (size_t)158 * 1024) pl = (size_t)158 * 1024; }
-        static size_t pattr = 0;
-        if (pl > pattr) {
-            if (hipFuncSetAttribute((const void*)concat_reselect_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)pl) != hipSuccess)
+        static size_t pattr[2] = {0, 0};
+        if (pl > pattr[use_f0 ? 1 : 0]) {
+            const void* fn = use_f0 ? (const void*)concat_reselect_pipe_kernel<true> : (const void*)concat_reselect_pipe_kernel<false>;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl) != hipSuccess)
                 return knnsvc_fail(KNNSVC_EHIP, "concat_reselect: hipFuncSetAttribute failed");
-            pattr = pl;
+            pattr[use_f0 ? 1 : 0] = pl;
         }
-        hipLaunchKernelGGL(concat_reselect_pipe_kernel, dim3(1), dim3(CT), pl, (hipStream_t)stream, (const long*)idx_in, q,
-                           q_norm, (long)nq, pool, p_norm, (long)np, dim, shifted_f0, pool_f0, use_f0, concat_weight,
-                           (long*)idx_out);
+        if (use_f0)
+            hipLaunchKernelGGL(concat_reselect_pipe_kernel<true>, dim3(1), dim3(LT), pl, (hipStream_t)stream, (const long*)idx_in, q, q_norm,
+                               (long)nq, pool, p_norm, (long)np, dim, shifted_f0, pool_f0, concat_weight, (long*)idx_out);
+        else
+            hipLaunchKernelGGL(concat_reselect_pipe_kernel<false>, dim3(1), dim3(LT), pl, (hipStream_t)stream, (const long*)idx_in, q, q_norm,
+                               (long)nq, pool, p_norm, (long)np, dim, shifted_f0, pool_f0, concat_weight, (long*)idx_out);
         return knnsvc_check_launch("concat_reselect_pipe");
     }
     const size_t lds = (size_t)(2 * NC + 2) * dim * 4;
