@@ -877,6 +877,264 @@ __global__ __launch_bounds__(256, 2) void attention2q_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// attention2q_kernel with EIGHT waves per workgroup (512 queries, one workgroup per CU) and the two waves of a SIMD out of
+// phase.  Round 3's phase counters: a wave spends ~11 000 cycles per 64-key tile — 3 072 of MFMA, ~3 700 of VALU (softmax,
+// split of P), 2 000-3 500 around the staging and its two barriers — and the two waves of a SIMD, released by the same
+// barriers, want the matrix pipe at the same time and the VALU at the same time: the sum, not the maximum.
+//   * K / V tiles in THREE LDS buffers (3 x 37 KB + the bias table: one workgroup per CU), staged two tiles ahead by all
+//     512 threads (two float4 of K and of V each: a staged tile serves eight waves); ONE barrier per tile.
+//   * every wave walks  softmax(g) -> PV(g) -> S(g + 1)  (the S of step 0 up front); waves 0-3 arrive at the tile's barrier
+//     BEFORE the S that opens the next tile, waves 4-7 (their SIMD neighbours) BEHIND it: when the barrier opens one group
+//     starts on the matrix pipe and the other on the VALU.  That S may read the first half of the NEXT tile before this
+//     tile's barrier, which is why tiles are staged two ahead (that tile was published by the previous barrier).
+// Per query the same operations in the same order as attention2q_kernel / attention2_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int QB>
+__global__ __launch_bounds__(512, 1) void attention2w_kernel(const float* __restrict__ qkv, const float* __restrict__ gate,
+                                                            const float* __restrict__ table, const int* __restrict__ kv_len, int T, int heads,
+                                                            float* __restrict__ out, int out_split, int kv_split) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) char lc;
+    typedef __attribute__((address_space(3))) au32x4 l_u4;
+    typedef __attribute__((address_space(3))) au32x2 l_u2;
+    typedef __attribute__((address_space(3))) float l_f;
+    constexpr int NT = 512, NJ = KT * 16 / NT;        // 16 threads per key row: 32 rows per pass, two passes
+    constexpr int KVB = KT * KP2 + KT * VP2;          // bytes of one K + V tile
+    lc* Ks = (lc*)lds;
+    lc* Vs = Ks + KT * KP2;
+    l_f* tb = (l_f*)(Ks + 3 * KVB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= 4;                      // the group that starts a step with the softmax
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int E = heads * HD;
+    const long ld = 3L * E;
+    const float* base = qkv + (long)b * T * ld;
+    int Tk = T;
+    if (kv_len) { Tk = kv_len[b]; Tk = Tk < 1 ? 1 : (Tk > T ? T : Tk); }
+
+    for (int i = tid; i < 2 * T - 1 + 64; i += NT) tb[i] = i < 2 * T - 1 ? table[(long)head * (2 * T - 1) + i] : 0.f;
+
+    const float L2E = 1.44269504088896341f;
+    const float qscale = 0.125f * L2E * 16.0f;
+    int qi[QB]; bool qvalid[QB];
+    au32x4 qf[QB][4][2];
+    float g_i[QB];
+    const l_f* tbq[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        qi[u] = blockIdx.x * (8 * 32 * QB) + wave * (32 * QB) + u * 32 + li;
+        qvalid[u] = qi[u] < T;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (qvalid[u]) {
+                const float* p = base + (long)qi[u] * ld + head * HD + s4 * 16 + lh * 8;
+                v0 = *(const f32x4*)p; v1 = *(const f32x4*)(p + 4);
+            }
+            g2_u32x2 h0, l0, h1, l1;
+            f16x2_split4(v0, qscale, h0, l0); f16x2_split4(v1, qscale, h1, l1);
+            qf[u][s4][0] = (au32x4){h0[0], h0[1], h1[0], h1[1]};
+            qf[u][s4][1] = (au32x4){l0[0], l0[1], l1[0], l1[1]};
+        }
+        g_i[u] = qvalid[u] ? gate[((long)b * T + qi[u]) * heads + head] * (L2E * 256.0f) : 0.f;
+        tbq[u] = tb + (T - 1 - (qvalid[u] ? qi[u] : T - 1)) + 4 * lh;
+    }
+    const lc* v_tr = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * VP2 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    f32x16 o[QB][2];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        m_run[u] = -__builtin_inff(); l_run[u] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[u][d][r] = 0.f;
+    }
+
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    f32x4 rk[NJ], rv[NJ];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int key = k0 + srow + (NT / 16) * j;
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < T) {
+                const float* p = base + (long)key * ld + head * HD + scol;
+                kk = *(const f32x4*)(p + E);
+                vv = *(const f32x4*)(p + 2 * E);
+            }
+            rk[j] = kk; rv[j] = vv;
+        }
+    };
+    auto stage_tile = [&](int boff) {             // the tile in rk / rv -> LDS at byte offset boff
+        if (kv_split) {
+            const int pc = tid & 15, plane = (pc >> 2) & 1, d0 = (pc >> 3) * 32 + (pc & 3) * 8;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int key = srow + (NT / 16) * j;
+                *(l_u4*)(Ks + boff + key * KP2 + plane * 128 + d0 * 2) = __builtin_bit_cast(au32x4, rk[j]);
+                *(l_u4*)(Vs + boff + key * VP2 + plane * 128 + d0 * 2) = __builtin_bit_cast(au32x4, rv[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int key = srow + (NT / 16) * j;
+                g2_u32x2 hi, lo;
+                f16x2_split4(rk[j], 16.0f, hi, lo);
+                lc* kd = Ks + boff + key * KP2 + scol * 2;
+                *(l_u2*)(kd) = hi;
+                *(l_u2*)(kd + 128) = lo;
+                f16x2_split4(rv[j], 16.0f, hi, lo);
+                lc* vd = Vs + boff + key * VP2 + scol * 2;
+                *(l_u2*)(vd) = hi;
+                *(l_u2*)(vd + 128) = lo;
+            }
+        }
+    };
+    const int ntiles = (Tk + KT - 1) / KT;
+    const int nsteps = (Tk + 31) / 32;            // 32-key steps g; step g lives in tile g >> 1, buffer (g >> 1) % 3
+
+    f32x16 s[QB];
+    // ---- S^T = K . Q^T for the QB query blocks: every K fragment pair is read once --------------
+    auto do_S = [&](int boff, int sub) {
+#pragma unroll
+        for (int u = 0; u < QB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+        const lc* kp = Ks + boff + (sub * 32 + li) * KP2 + lh * 16;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const f16x8 k0 = __builtin_bit_cast(f16x8, *(const l_u4*)(kp + st * 32));
+            const f16x8 k1 = __builtin_bit_cast(f16x8, *(const l_u4*)(kp + 128 + st * 32));
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const f16x8 q0 = __builtin_bit_cast(f16x8, qf[u][st][0]), q1 = __builtin_bit_cast(f16x8, qf[u][st][1]);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q0, s[u], 0, 0, 0);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q1, s[u], 0, 0, 0);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q0, s[u], 0, 0, 0);
+            }
+        }
+    };
+    // ---- online softmax per query block (lane-local + one exchange with lane ^ 32) ----------------
+    auto do_softmax = [&](int g) {
+        const int kbase = g * 32;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const l_f* tp = tbq[u] + kbase;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][r] = fmaf(g_i[u], tp[(r & 3) + 8 * (r >> 2)], s[u][r]);
+            if (kbase + 32 > Tk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) s[u][r] = -__builtin_inff();
+            }
+            float mx = fmaxf(fmaxf(s[u][0], s[u][1]), fmaxf(s[u][2], s[u][3]));
+#pragma unroll
+            for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[u][r], s[u][r + 1]), fmaxf(s[u][r + 2], s[u][r + 3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[u], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * (1.0f / 256.0f));
+            const float mneg = fmaf(m_new, -1.0f / 256.0f, 14.0f);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[u][r] = __builtin_amdgcn_exp2f(fmaf(s[u][r], 1.0f / 256.0f, mneg)); ps += s[u][r]; }
+            ps += __shfl_xor(ps, 32, 64);
+            l_run[u] = l_run[u] * alpha + ps;
+            m_run[u] = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[u][d][r] *= alpha;
+            }
+        }
+    };
+    // ---- O^T += V^T . P^T: every transposed V fragment is read once -------------------------------
+    auto do_PV = [&](int boff, int sub) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 b0[QB], b1[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                g2_u32x2 h0, l0, h1, l1;
+                f16x2_split4((f32x4){s[u][8 * st + 0], s[u][8 * st + 1], s[u][8 * st + 2], s[u][8 * st + 3]}, 1.0f, h0, l0);
+                f16x2_split4((f32x4){s[u][8 * st + 4], s[u][8 * st + 5], s[u][8 * st + 6], s[u][8 * st + 7]}, 1.0f, h1, l1);
+                b0[u] = __builtin_bit_cast(f16x8, (au32x4){h0[0], h0[1], h1[0], h1[1]});
+                b1[u] = __builtin_bit_cast(f16x8, (au32x4){l0[0], l0[1], l1[0], l1[1]});
+            }
+            const lc* vrow = v_tr + boff + (sub * 32 + 16 * st) * VP2;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                typedef __attribute__((address_space(3))) short4v l_s4;
+                const lc* vp = vrow + dt * 64;
+                const au32x2 x0 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp)));
+                const au32x2 x1 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp + 8 * VP2)));
+                const au32x2 y0 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp + 128)));
+                const au32x2 y1 = __builtin_bit_cast(au32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((l_s4*)(vp + 8 * VP2 + 128)));
+                const f16x8 v0 = __builtin_bit_cast(f16x8, (au32x4){x0[0], x0[1], x1[0], x1[1]});
+                const f16x8 v1 = __builtin_bit_cast(f16x8, (au32x4){y0[0], y0[1], y1[0], y1[1]});
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    f32x16 c = o[u][dt];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, b0[u], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b1[u], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b0[u], c, 0, 0, 0);
+                    o[u][dt] = c;
+                }
+            }
+        }
+    };
+
+    // tiles 0 and 1 staged, tile 2 on its way in registers; every wave opens with the S of step 0
+    gload(0);
+    stage_tile(0);
+    if (ntiles > 1) { gload(KT); stage_tile(KVB); }
+    if (ntiles > 2) gload(2 * KT);
+    __syncthreads();
+    do_S(0, 0);
+    int bc = 0;                                   // byte offset of tile t's buffer (t % 3)
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t + 2 goes into the buffer whose last readers (tile t - 1) passed the previous barrier; its global loads were issued
+        // an iteration ago, those of tile t + 3 start now
+        const int bn = bc == 2 * KVB ? 0 : bc + KVB, bp = bc == 0 ? 2 * KVB : bc - KVB;       // tile t + 1, tile t + 2 (= t - 1)
+        if (t + 2 < ntiles) stage_tile(bp);
+        if (t + 3 < ntiles) gload((t + 3) * KT);
+        do_softmax(2 * t); do_PV(bc, 0);
+        if (2 * t + 1 < nsteps) { do_S(bc, 1); do_softmax(2 * t + 1); do_PV(bc, 1); }
+        // the barrier sits BEFORE the next step's S for waves 0-3 and BEHIND it for waves 4-7 (one arrival per wave and tile either way)
+        if (!late) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+        if (2 * t + 2 < nsteps) do_S(bn, 0);
+        if (late) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+        bc = bn;
+    }
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        if (!qvalid[u]) continue;
+        const float inv = 0.0625f / l_run[u];
+        float* op = out + ((long)b * T + qi[u]) * E + head * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {o[u][d][r4 * 4 + 0] * inv, o[u][d][r4 * 4 + 1] * inv, o[u][d][r4 * 4 + 2] * inv, o[u][d][r4 * 4 + 3] * inv};
+                if (out_split) {
+                    g2_u32x2 hi, lo;
+                    f16x2_split4(v, KN_F16X2_A_SCALE, hi, lo);
+                    const int c = head * HD + d * 32 + r4 * 8 + lh * 4;
+                    char* ob = (char*)(out + ((long)b * T + qi[u]) * E) + (c >> 5) * 128 + (c & 31) * 2;
+                    *(g2_u32x2*)ob = hi;
+                    *(g2_u32x2*)(ob + 64) = lo;
+                } else
+                    *(f32x4*)(op + d * 32 + r4 * 8 + lh * 4) = v;
+            }
+    }
+}
+
+
 }  // namespace
 
 extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* table, int32_t batches,
@@ -909,6 +1167,22 @@ extern "C" int knnsvc_wavlm_attention(const float* qkv, const float* gate, const
         const int qb = !eq ? 0 : (eq[0] == '1' ? 1 : 2);
         const long blocks128 = (long)((T + 127) / 128) * heads * batches;
         if ((qb == 2 || (qb == 0 && blocks128 >= 1536)) && T > 128) {
+            // eight waves per workgroup (three K / V buffers, one barrier per tile, SIMD neighbours out of phase) once the 512-query
+            // grid is at least two rounds of one workgroup per CU; KNNSVC_ATT_NW=4 / 8 forces one.  Same results, bit for bit.
+            const char* ew = getenv("KNNSVC_ATT_NW");
+            const long blocks512 = (long)((T + 511) / 512) * heads * batches;
+            const size_t l2w = (size_t)3 * (KT * KP2 + KT * VP2) + (size_t)(2 * T - 1 + 64) * 4;
+            if ((ew ? ew[0] == '8' : blocks512 >= 512) && l2w <= 160 * 1024) {
+                static size_t attr2w = 0;
+                if (l2w > attr2w) {
+                    if (hipFuncSetAttribute((const void*)attention2w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2w) != hipSuccess)
+                        return knnsvc_fail(KNNSVC_EHIP, "wavlm_attention: hipFuncSetAttribute failed");
+                    attr2w = l2w;
+                }
+                dim3 gridw((unsigned)((T + 511) / 512), (unsigned)heads, (unsigned)batches);
+                hipLaunchKernelGGL(attention2w_kernel<2>, gridw, dim3(512), l2w, (hipStream_t)stream, qkv, gate, table, kv_len, T, heads, out, out_f16x2, kv_f16x2);
+                return knnsvc_check_launch("wavlm_attention2w");
+            }
             static size_t attr2q = 0;
             if (l2 > attr2q) {
                 if (hipFuncSetAttribute((const void*)attention2q_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)

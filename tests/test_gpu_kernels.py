@@ -364,6 +364,32 @@ def test_attention_64_queries_per_wave_equals_32(B, T, split, monkeypatch):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+@pytest.mark.parametrize("B,T,split", [(2, 333, False), (3, 700, True), (1, 1500, True), (2, 1061, True)])
+def test_attention_eight_waves_per_workgroup_equals_four(B, T, split, monkeypatch):
+    """attention2w_kernel (512 queries per workgroup, K / V tiles in three LDS buffers staged two ahead, one barrier per tile at a
+    different point of the step for the two waves of a SIMD — the large-batch dispatch) against attention2q_kernel: per query the
+    same operations in the same order, so bit-identical — with an odd number of 32-key steps (T = 333, 1061: the last tile has one
+    step), fewer than three tiles after key padding, ragged last query blocks, pre-split K / V and split output."""
+    ops = _ops()
+    H, E = 16, 1024
+    g = torch.Generator().manual_seed(B * 1000 + T + 1)
+    qkv = (torch.randn(B * T, 3 * E, generator=g) * 0.5).to(DEV)
+    gate = torch.rand(B * T, H, generator=g).to(DEV)
+    table = (torch.randn(H, 2 * T - 1, generator=g) * 0.1).to(DEV)
+    lens = torch.tensor([max(T - 237 * b, 70) for b in range(B)], dtype=torch.int32, device=DEV)
+    short = torch.tensor([70 + 31 * b for b in range(B)], dtype=torch.int32, device=DEV)       # two or three tiles only
+    if split:
+        qkv = qkv.clone(); qkv[:, E:] = ops.split_pack(qkv[:, E:].contiguous())
+    monkeypatch.setenv("KNNSVC_ATT_QB", "2")
+    res = {}
+    for nw in ("4", "8"):
+        monkeypatch.setenv("KNNSVC_ATT_NW", nw)
+        res[nw] = [ops.wavlm_attention(qkv, gate, table, B, T, H, kv_split=split, out_split=split, kv_len=kl).clone()
+                   for kl in (None, lens, short)]
+    for a, b in zip(res["4"], res["8"]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 # ------------------------------------------------------------------ kNN
 def test_knn_golden(golden):
     from oracle import knn_ref
