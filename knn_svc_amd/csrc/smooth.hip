@@ -78,6 +78,29 @@ __global__ __launch_bounds__(256) void gram_kernel(const long* __restrict__ idx,
 
 struct LoopState { double min_loss, conv_min; int since; };
 
+// The two per-element pieces of an iteration that were IEEE divides, square roots and expf: 250 of the 410 VALU instructions a
+// frame costs per iteration (one CU runs the whole loop).  Inside the loop they run on the hardware's 1-ulp v_exp_f32 / v_rcp_f32 /
+// v_sqrt_f32: 4.67 -> 2.65 us per iteration.  The optimiser's trajectory is only defined up to such roundings anyway (a different
+// summation order of the loss already moves the weights by 2e-4), and measured against the reference-generated fixtures the two
+// forms are level: weights max|d| 3.5e-4 / 2.4e-4 (IEEE) vs 2.9e-4 / 2.8e-4 (WavLM / harmonics, g5), 1.1e-6 vs 1.2e-6
+// (amplitude-scaled), the same iteration counts (201 / 201 / 401), file-level waveform rms 5.4e-7 vs 1.2e-6 on the post_opt
+// fixture (bar 1e-4), everything else unchanged.  The FINAL weights (softmax of the best iterate) keep expf and the IEEE divide.
+__device__ __forceinline__ f32x4 loop_softmax4(f32x4 th, float mx) {
+#pragma clang fp contract(off)
+    f32x4 e;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f((th[k] - mx) * 1.44269504088896341f);
+    const float den = (e[0] + e[1]) + (e[2] + e[3]);       // >= 1: the maximum contributes exp2(0)
+    return e * __builtin_amdgcn_rcpf(den);
+}
+// theta + step_size * m / (sqrt(vmax) / sqrt(1 - b2^t) + eps); rbc2 = 1 / sqrt(1 - b2^t), one IEEE divide per iteration
+__device__ __forceinline__ float loop_step(float th, float m, float vmax, float rbc2, float eps, float step_size) {
+#pragma clang fp contract(off)
+    const float denom = __builtin_amdgcn_sqrtf(vmax) * rbc2 + eps;
+    return th + step_size * (m * __builtin_amdgcn_rcpf(denom));
+}
+
+
 __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scale, int max_iter,
                                                    const float* __restrict__ gram, float* __restrict__ state,
                                                    float* __restrict__ xch_global, int use_lds,
@@ -106,9 +129,7 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
         for (long t = tid; t < nq; t += 1024) {
             const f32x4 th = theta[t];
             const float mx = fmaxf(fmaxf(th[0], th[1]), fmaxf(th[2], th[3]));
-            f32x4 e = {expf(th[0] - mx), expf(th[1] - mx), expf(th[2] - mx), expf(th[3] - mx)};
-            const float den = (e[0] + e[1]) + (e[2] + e[3]);
-            *(f32x4*)&xw[t * KW] = e / den;
+            *(f32x4*)&xw[t * KW] = loop_softmax4(th, mx);
         }
         __syncthreads();
         // ---- phase 2: per pair quadratic forms, gradient w.r.t. the weights ---------------------
@@ -158,6 +179,7 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
         pb1 *= 0.9; pb2 *= 0.999;
         const float step_size = (float)(-(0.1 / (1.0 - pb1)));
         const float bc2_sqrt = (float)sqrt(1.0 - pb2);
+        const float rbc2 = 1.0f / bc2_sqrt;
         for (long t = tid; t < nq; t += 1024) {
             const f32x4 w = *(const f32x4*)&xw[t * KW];
             f32x4 g = zero;
@@ -173,8 +195,7 @@ __global__ __launch_bounds__(1024) void adam_kernel(long nq, int dim, float scal
                 mm[k] = mm[k] + (gt[k] - mm[k]) * omb1;
                 vv[k] = vv[k] * b2 + (omb2 * gt[k]) * gt[k];
                 vm[k] = fmaxf(vm[k], vv[k]);
-                const float denom = sqrtf(vm[k]) / bc2_sqrt + eps;
-                th[k] = th[k] + step_size * (mm[k] / denom);
+                th[k] = loop_step(th[k], mm[k], vm[k], rbc2, eps, step_size);
             }
             theta[t] = th; m1[t] = mm; v2[t] = vv; vmax[t] = vm;
         }
@@ -228,9 +249,7 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
             const long t = tid + 512L * f;
             if (t < nq) {
                 const float mx = fmaxf(fmaxf(th[f][0], th[f][1]), fmaxf(th[f][2], th[f][3]));
-                f32x4 e = {expf(th[f][0] - mx), expf(th[f][1] - mx), expf(th[f][2] - mx), expf(th[f][3] - mx)};
-                const float den = (e[0] + e[1]) + (e[2] + e[3]);
-                *(f32x4*)&xw[t * KW] = e / den;
+                *(f32x4*)&xw[t * KW] = loop_softmax4(th[f], mx);
             }
         }
         __syncthreads();
@@ -284,6 +303,7 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
         pb1 *= 0.9; pb2 *= 0.999;
         const float step_size = (float)(-(0.1 / (1.0 - pb1)));
         const float bc2_sqrt = (float)sqrt(1.0 - pb2);
+        const float rbc2 = 1.0f / bc2_sqrt;
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
             const long t = tid + 512L * f;
@@ -300,8 +320,7 @@ __global__ __launch_bounds__(512) void adam_reg_kernel(long nq, int dim, float s
                     mm[f][k] = mm[f][k] + (gt[k] - mm[f][k]) * omb1;
                     vv[f][k] = vv[f][k] * b2 + (omb2 * gt[k]) * gt[k];
                     vm[f][k] = fmaxf(vm[f][k], vv[f][k]);
-                    const float denom = sqrtf(vm[f][k]) / bc2_sqrt + eps;
-                    th[f][k] = th[f][k] + step_size * (mm[f][k] / denom);
+                    th[f][k] = loop_step(th[f][k], mm[f][k], vm[f][k], rbc2, eps, step_size);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
