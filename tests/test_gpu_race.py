@@ -32,5 +32,6 @@ def test_concat_reselect_is_bit_stable_beside_mfma_workgroups():
     pr = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     print("SLP probe (select.hip with packed-fp32 math):", pr)
     assert pr["lib"] == "libknnsvc_slpprobe.so" and pr["quiet_repeat_equal"]
-    # no assertion on pr["differ"]: > 0 reproduces round 3's finding (the fence is what keeps the product stable), 0 means the
-    # hazard does not show with these co-runners on this box — recorded in DESIGN.md either way
+    # no assertion on pr["differ"]: > 0 reproduces round 3's finding (the fence is what keeps the product stable).  Since the walk
+    # was rebuilt in round 4 (nine waves: three on SIMD 0) these co-runners cannot share its CU any more and the probe reads 0;
+    # round 3's walk rebuilt from history still reads 26-33 of 40 (profiles/r04_concat_race_bisect.txt)
