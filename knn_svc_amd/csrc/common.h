@@ -57,6 +57,34 @@ __device__ __forceinline__ float kn_gelu(float x) {
 #endif
 }
 
+// Two activations per instruction where the ISA has a packed fp32 form (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32; the two
+// reciprocals and the two exponentials stay scalar): every component goes through exactly the roundings of kn_gelu, so the result
+// is bit-identical to it — a change of instruction selection only (the conv stack's first layer evaluates 1e9 of these per step
+// and is VALU-bound).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 kn_gelu2(f32x2 x) {
+#ifdef KN_GELU_ERFF
+    return (f32x2){kn_gelu(x[0]), kn_gelu(x[1])};
+#else
+#pragma clang fp contract(off)
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752440f;
+    const f32x2 u = __builtin_elementwise_fma((f32x2)(0.39f), z, (f32x2)(1.0f));
+    const f32x2 t = {__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+    f32x2 p = (f32x2)(-0.1137684788031453f);
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.4433318425354039f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(-0.3176995829519751f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.32477925011974735f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.045694387408764885f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.11766258084307574f));
+    p = p * t;
+    const f32x2 ea = (-(z * z)) * 1.4426950408889634f;
+    const f32x2 h = p * (f32x2){__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};      // Phi(-|x|)
+    const f32x2 omh = 1.0f - h;
+    return x * (f32x2){x[0] >= 0.f ? omh[0] : h[0], x[1] >= 0.f ? omh[1] : h[1]};
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

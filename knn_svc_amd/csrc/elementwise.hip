@@ -116,13 +116,17 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
         const long p = m0 * stride + i;
         xs[i] = p < L ? xb[p] : 0.f;
     }
-    float wr[CPL][KMAXT], g[CPL], be[CPL];
+    constexpr int NP = (CPL + 1) / 2;      // channel pairs (CPL = 1: the second half of the one pair repeats the channel and is dropped)
+    // channels in PAIRS: the taps, the affine and the GELU run on v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 — per channel the
+    // same operations in the same order as one at a time (bit-identical), at half the issue slots; the LayerNorm sums stay scalar
+    // chains in channel order
+    f32x2 wr[NP][KMAXT], g[NP], be[NP];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int ch = lane * CPL + c;
-        g[c] = gamma[ch]; be[c] = beta[ch];
+    for (int c = 0; c < NP; ++c) {
+        const int ch = lane * CPL + 2 * c, ch1 = CPL > 1 ? ch + 1 : ch;
+        g[c] = (f32x2){gamma[ch], gamma[ch1]}; be[c] = (f32x2){beta[ch], beta[ch1]};
 #pragma unroll
-        for (int t = 0; t < KMAXT; ++t) wr[c][t] = t < k ? w[ch * k + t] : 0.f;
+        for (int t = 0; t < KMAXT; ++t) wr[c][t] = t < k ? (f32x2){w[ch * k + t], w[ch1 * k + t]} : (f32x2){0.f, 0.f};
     }
     __syncthreads();
     // RP rows per pass: independent chains (LDS reads, the two reductions, the GELU's rcp / exp2, the stores) interleave, and the
@@ -130,7 +134,8 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
     // is VALU work (80 FMAs, 8 GELUs per lane and row) that sat half idle behind those latencies (RP = 1 with shuffles: 2.04 ms
     // for 21 x 96 015 rows, the VALU floor is ~1.1).
     for (int r = 0; r < 16; r += RP) {
-        float y[RP][CPL], s[RP], mean[RP], q[RP], rstd[RP];
+        f32x2 y[RP][NP];
+        float s[RP], mean[RP], q[RP], rstd[RP];
 #pragma unroll
         for (int u = 0; u < RP; ++u) {
             const int lm = wave * 16 + r + u;          // rows past T read zeros / stale LDS: finite, never stored
@@ -139,11 +144,11 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             for (int t = 0; t < KMAXT; ++t) xv[t] = t < k ? xs[lm * stride + t] : 0.f;
             s[u] = 0.f;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                float a = 0.f;
+            for (int c = 0; c < NP; ++c) {
+                f32x2 a = {0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < KMAXT; ++t) a += wr[c][t] * xv[t];
-                y[u][c] = a; s[u] += a;
+                for (int t = 0; t < KMAXT; ++t) a = __builtin_elementwise_fma(wr[c][t], (f32x2)(xv[t]), a);
+                y[u][c] = a; s[u] += a[0]; if (CPL > 1) s[u] += a[1];
             }
         }
 #pragma unroll
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
         for (int u = 0; u < RP; ++u) {
             q[u] = 0.f;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) { const float d = y[u][c] - mean[u]; q[u] += d * d; }
+            for (int c = 0; c < CPL; ++c) { const float d = y[u][c >> 1][c & 1] - mean[u]; q[u] += d * d; }
         }
 #pragma unroll
         for (int u = 0; u < RP; ++u) rstd[u] = 1.0f / sqrtf((RP > 1 ? wave_sum_dpp(q[u]) : wave_sum(q[u])) / (float)C + 1e-5f);
@@ -162,19 +167,19 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             if (m >= T) break;
             float* o = out + (b * T + m) * C + lane * CPL;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) y[u][c] = gelu_erf((y[u][c] - mean[u]) * rstd[u] * g[c] + be[c]);
+            for (int c = 0; c < NP; ++c) y[u][c] = kn_gelu2(__builtin_elementwise_fma((y[u][c] - mean[u]) * rstd[u], g[c], be[c]));
             if (CPL % 4 == 0) {
                 if (split) {
                     float* orow = out + (b * T + m) * C;
 #pragma unroll
-                    for (int c = 0; c < CPL; c += 4) store_split4(orow, lane * CPL + c, (f32x4){y[u][c], y[u][c + 1], y[u][c + 2], y[u][c + 3]});
+                    for (int c = 0; c < CPL; c += 4) store_split4(orow, lane * CPL + c, (f32x4){y[u][c / 2][0], y[u][c / 2][1], y[u][c / 2 + 1][0], y[u][c / 2 + 1][1]});
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CPL; c += 4) *(f32x4*)(o + c) = (f32x4){y[u][c], y[u][c + 1], y[u][c + 2], y[u][c + 3]};
+                    for (int c = 0; c < CPL; c += 4) *(f32x4*)(o + c) = (f32x4){y[u][c / 2][0], y[u][c / 2][1], y[u][c / 2 + 1][0], y[u][c / 2 + 1][1]};
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) o[c] = y[u][c];
+                for (int c = 0; c < CPL; ++c) o[c] = y[u][c >> 1][c & 1];
             }
         }
     }

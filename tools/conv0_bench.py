@@ -14,4 +14,4 @@ for split in (False, True):
     for _ in range(10): y = ops.wavlm_conv0(x, w, ga, be, k, st, out_split=split)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print(f"split={split}: {ms:.3f} ms  {y.numel() * 4 / ms / 1e9:.2f} TB/s written  checksum {float(y.double().abs().sum()):.6e}")
+    print(f"split={split}: {ms:.3f} ms  {y.numel() * 4 / ms / 1e9:.2f} TB/s written  checksum {float(y.double().abs().sum()):.9e} bits {int(y.view(torch.int32).to(torch.int64).sum())}")
