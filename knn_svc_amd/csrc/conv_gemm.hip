@@ -534,7 +534,7 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvArgs& a, typename G
             }
             if (act == KNNSVC_ACT_GELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
+                for (int e = 0; e < 4; e += 2) { const f32x2 gv = kn_gelu2((f32x2){v[e], v[e + 1]}); v[e] = gv[0]; v[e + 1] = gv[1]; }     // pairs on packed fp32: bit-identical to kn_gelu
             } else if (act == KNNSVC_ACT_LRELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.act_slope);
@@ -646,7 +646,7 @@ __device__ __forceinline__ void conv_epilogue_wide_fast(const ConvArgs& a, typen
                 f32x4 v = *(const lds_f4*)(prow + it * RSTEP * PITCH) + bias4;
                 if constexpr (ACT == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
+                    for (int e = 0; e < 4; e += 2) { const f32x2 gv = kn_gelu2((f32x2){v[e], v[e + 1]}); v[e] = gv[0]; v[e + 1] = gv[1]; }     // pairs on packed fp32: bit-identical to kn_gelu
                 }
                 g2_u32x2 hi, lo;
                 f16x2_split4(v, sscale, hi, lo);
@@ -671,7 +671,7 @@ __device__ __forceinline__ void conv_epilogue_wide_fast(const ConvArgs& a, typen
                     f32x4 v = *(const lds_f4*)(prow + it * RSTEP * PITCH) + bias4;
                     if constexpr (ACT == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = kn_gelu(v[e]);
+                        for (int e = 0; e < 4; e += 2) { const f32x2 gv = kn_gelu2((f32x2){v[e], v[e + 1]}); v[e] = gv[0]; v[e + 1] = gv[1]; }     // pairs on packed fp32: bit-identical to kn_gelu
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, off, 0, 0);
                     if (nv) off += row_pitch_o;
