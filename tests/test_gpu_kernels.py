@@ -378,6 +378,7 @@ def test_attention_eight_waves_per_workgroup_equals_four(B, T, split, monkeypatc
     table = (torch.randn(H, 2 * T - 1, generator=g) * 0.1).to(DEV)
     lens = torch.tensor([max(T - 237 * b, 70) for b in range(B)], dtype=torch.int32, device=DEV)
     short = torch.tensor([70 + 31 * b for b in range(B)], dtype=torch.int32, device=DEV)       # two or three tiles only
+    one = torch.tensor([(5, 64, 33)[b % 3] for b in range(B)], dtype=torch.int32, device=DEV)    # a single tile (one or two 32-key steps)
     if split:
         qkv = qkv.clone(); qkv[:, E:] = ops.split_pack(qkv[:, E:].contiguous())
     monkeypatch.setenv("KNNSVC_ATT_QB", "2")
@@ -385,7 +386,7 @@ def test_attention_eight_waves_per_workgroup_equals_four(B, T, split, monkeypatc
     for nw in ("4", "8"):
         monkeypatch.setenv("KNNSVC_ATT_NW", nw)
         res[nw] = [ops.wavlm_attention(qkv, gate, table, B, T, H, kv_split=split, out_split=split, kv_len=kl).clone()
-                   for kl in (None, lens, short)]
+                   for kl in (None, lens, short, one)]
     for a, b in zip(res["4"], res["8"]):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
