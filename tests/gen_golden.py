@@ -208,6 +208,23 @@ def gen_knn():
          small=small.numpy())
 
 
+def gen_knn_ns():
+    """G3c: the search at the NORTH-STAR size (1500 query frames against a 10-minute pool of 30 000 frames) from the reference's own
+    distance function and torch.topk — the fixture the fused route (no [Nq, Np] matrix) is read against at the size it was built for."""
+    print("G3c kNN top-32 at the north-star size (1500 x 30 000)")
+    q = S.clustered_features(1500, 1024, seed=41)
+    p = S.clustered_features(30000, 1024, seed=42)
+    idxs, vals = [], []
+    for s in range(0, len(q), 20):
+        d = R_lo.fast_cosine_dist(q[s:s + 20], p)
+        t = d.topk(k=32, dim=-1, largest=False)
+        idxs.append(t.indices); vals.append(t.values)
+    idx, val = torch.cat(idxs), torch.cat(vals)
+    mi, mv = knn_ref.knn_topk(q, p, 32)
+    eq(idx, mi, "knn idx (north-star size)"); eq(val, mv, "knn dist (north-star size)")
+    save("g3c_knn_north_star", q_seed=41, p_seed=42, nq=1500, np_=30000, idx=idx.numpy().astype(np.int32), dist=val.numpy())
+
+
 def knn_ties_inputs():
     """Inputs of fixture G3b (shared with the tests): exact ties of every kind the path can meet — duplicated pool rows, a block
     of 400 bit-identical "silence" rows, queries that ARE pool rows, queries that are the silence row."""
@@ -534,7 +551,7 @@ def gen_sample():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "select", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
+    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")
