@@ -301,6 +301,34 @@ def gen_select():
         assert select_ref.parse_post_opt(po) == want
 
 
+from tests.gen_golden_inputs import north_star_inputs   # noqa: E402  (seeded inputs shared with the tests)
+
+
+def gen_select_ns():
+    """G4c: the selection chain at the NORTH-STAR size from the reference itself — top-32, f0 shift, stable f0 re-rank and both
+    frame-sequential concat re-selections over all 1500 frames of a 30 000-frame pool."""
+    print("G4c selection chain at the north-star size (1500 x 30 000)")
+    import copy
+    q, p, qf0, pf0 = north_star_inputs()
+    idxs = []
+    for s in range(0, len(q), 20):
+        idxs.append(R_lo.fast_cosine_dist(q[s:s + 20], p).topk(k=32, dim=-1, largest=False).indices)
+    nn32 = torch.cat(idxs)
+    eq(nn32, knn_ref.knn_topk(q, p, 32)[0], "knn idx (north-star, smooth)")
+    qm = torch.median(torch.log(qf0[qf0 != 0])); pm = torch.median(torch.log(pf0[pf0 != 0]))
+    shifted = copy.deepcopy(qf0); shifted[qf0 != 0] = torch.exp(torch.log(qf0[qf0 != 0]) + pm - qm)
+    eq(shifted, select_ref.shift_query_f0(qf0, pf0), "shifted f0 (north-star)")
+    ranked = R_dp.sort_by_f0_compatibility(shifted, pf0, nn32)
+    eq(ranked, select_ref.rerank_by_f0(shifted, pf0, nn32), "f0 rerank (north-star)")
+    with quiet():
+        sel_a = R_lo.knn_with_concat_cost(copy.deepcopy(nn32[:, :4]), q, p, concat_weight=0.2)
+        sel_b = R_lo.knn_with_concat_cost(copy.deepcopy(ranked[:, :4]), q, p, shifted, pf0, concat_weight=0.2)
+    eq(sel_a, select_ref.concat_reselect(nn32[:, :4].clone(), q, p, concat_weight=0.2), "concat (no f0, north-star)")
+    eq(sel_b, select_ref.concat_reselect(ranked[:, :4].clone(), q, p, shifted, pf0, concat_weight=0.2), "concat (f0, north-star)")
+    save("g4c_select_north_star", shifted=shifted.numpy(), nn32=nn32.numpy().astype(np.int32), ranked4=ranked[:, :4].numpy().astype(np.int32),
+         sel_plain=sel_a.numpy().astype(np.int32), sel_f0=sel_b.numpy().astype(np.int32))
+
+
 # ---------------------------------------------------------------- G5: Adam weights
 def gen_smooth():
     print("G5 smoothness weights (Adam loops)")
@@ -551,7 +579,7 @@ def gen_sample():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
+    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

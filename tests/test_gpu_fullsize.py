@@ -57,6 +57,34 @@ def test_knn_north_star_size_against_the_reference_fixture(golden):
     assert bool((dist[:, 1:] >= dist[:, :-1]).all())
 
 
+def test_selection_chain_north_star_size_against_the_reference_fixture(golden):
+    """Fixture G4c (the reference itself at 1500 x 30 000, tests/gen_golden.py select_ns): given the reference's neighbour lists,
+    the f0 shift, the stable f0 re-rank and BOTH frame-sequential concat re-selections reproduce the reference's output on every
+    one of the 1500 frames; the search on these (temporally smooth) features agrees with the reference's lists up to fp32
+    rounding gaps (see test_knn_north_star_size_against_the_reference_fixture)."""
+    from knn_svc_amd import ops
+    from tests.gen_golden_inputs import north_star_inputs
+    g = golden("g4c_select_north_star")
+    q, p, qf0, pf0 = north_star_inputs()
+    qd, pd, qf0d, pf0d = q.to(DEV), p.to(DEV), qf0.to(DEV), pf0.to(DEV)
+    nn32 = torch.from_numpy(g["nn32"]).long().to(DEV)
+    sh = ops.shift_f0(qf0d, ops.log_f0_median(qf0d), ops.log_f0_median(pf0d))
+    assert float((sh.cpu() - torch.from_numpy(g["shifted"])).abs().max() / torch.from_numpy(g["shifted"]).abs().max()) < 5e-6
+    shifted = torch.from_numpy(g["shifted"]).to(DEV)                  # from here on the reference's own values
+    rk = ops.f0_rerank(nn32, shifted, pf0d)
+    assert float((rk[:, :4].cpu() == torch.from_numpy(g["ranked4"]).long()).all(1).float().mean()) == 1.0
+    qn, _ = ops.row_norms(qd); pn, _ = ops.row_norms(pd)
+    a = ops.concat_reselect(nn32[:, :4].contiguous(), qd, qn, pd, pn, concat_weight=0.2)
+    b = ops.concat_reselect(torch.from_numpy(g["ranked4"]).long().to(DEV), qd, qn, pd, pn, shifted, pf0d, concat_weight=0.2)
+    ma = float((a.cpu() == torch.from_numpy(g["sel_plain"]).long()).all(1).float().mean())
+    mb = float((b.cpu() == torch.from_numpy(g["sel_f0"]).long()).all(1).float().mean())
+    idx, _ = ops.knn_topk(qd, pd, 32)
+    top4 = float((idx[:, :4].cpu() == torch.from_numpy(g["nn32"]).long()[:, :4]).all(1).float().mean())
+    print(f"north-star selection chain vs the reference: concat plain {ma:.4f}, pitched {mb:.4f} of 1500 frames; search top-4 rows equal {top4:.4f}")
+    assert ma == 1.0 and mb == 1.0
+    assert top4 >= 0.995
+
+
 def test_knn_full_size_properties(north_star_features):
     from knn_svc_amd import ops
     from oracle import knn_ref
