@@ -351,6 +351,25 @@ def gen_smooth():
          w_wavlm=w_ref.detach().numpy(), iters_wavlm=it, w_harm=wh_ref.detach().numpy(), iters_harm=ith)
 
 
+def gen_smooth_ns():
+    """G5c: both Adam loops at the NORTH-STAR size from the reference — 1500 frames, the reference's own re-selected neighbours
+    (fixture G4c) in a 30 000-frame pool."""
+    print("G5c smoothness weights at the north-star size (1500 frames, 30 000-row pools)")
+    q, p, qf0, pf0 = north_star_inputs()
+    g4 = np.load(OUT / "g4c_select_north_star.npz")
+    idx_a, idx_b = torch.from_numpy(g4["sel_plain"]).long(), torch.from_numpy(g4["sel_f0"]).long()
+    with quiet():
+        w_ref = R_dp.compute_wavlm_weight(idx_a.clone(), p)
+    w_mine, it = smooth_ref.smooth_weights(idx_a, p, 0.1, return_iters=True)
+    eq(w_ref, w_mine, "wavlm weights (north-star)", tol=0.0)
+    ph = torch.rand(30000, 49, generator=torch.Generator().manual_seed(5)) * 0.05
+    with quiet():
+        wh_ref = R_dp.compute_extended_weight(idx_b.clone(), ph, "sum_to_1_geq", [1])
+    wh_mine, ith = smooth_ref.smooth_weights(idx_b, ph, 1000.0, return_iters=True)
+    eq(wh_ref.detach(), wh_mine, "harmonic weights (north-star)", tol=0.0)
+    save("g5c_smooth_north_star", harm_seed=5, w_wavlm=w_ref.detach().numpy(), iters_wavlm=it, w_harm=wh_ref.detach().numpy(), iters_harm=ith)
+
+
 # ---------------------------------------------------------------- G6/G8: synth + harmonics
 def gen_synth():
     print("G6 additive synth / G8 harmonic amplitudes")
@@ -579,7 +598,7 @@ def gen_sample():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "synth", "vocoder", "e2e", "prematch", "sample"]
+    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "smooth_ns", "synth", "vocoder", "e2e", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

@@ -85,6 +85,24 @@ def test_selection_chain_north_star_size_against_the_reference_fixture(golden):
     assert top4 >= 0.995
 
 
+def test_smooth_weights_north_star_size_against_the_reference_fixture(golden):
+    """Fixture G5c: the reference's compute_wavlm_weight / compute_extended_weight on 1500 frames (its own re-selected neighbours,
+    30 000-row pools).  Same iteration counts; weights within the bar of the small fixture (g5)."""
+    from knn_svc_amd import ops
+    from tests.gen_golden_inputs import north_star_inputs
+    g, g4 = golden("g5c_smooth_north_star"), golden("g4c_select_north_star")
+    _q, p, _qf0, _pf0 = north_star_inputs()
+    w, it = ops.smooth_weights(torch.from_numpy(g4["sel_plain"]).long().to(DEV), p.to(DEV), 0.1, return_iters=True)
+    e = float((w.cpu() - torch.from_numpy(g["w_wavlm"])).abs().max())
+    ph = torch.rand(30000, 49, generator=torch.Generator().manual_seed(int(g["harm_seed"]))) * 0.05
+    wh, ith = ops.smooth_weights(torch.from_numpy(g4["sel_f0"]).long().to(DEV), ph.to(DEV), 1000.0, return_iters=True)
+    eh = float((wh.cpu() - torch.from_numpy(g["w_harm"])).abs().max())
+    print(f"Adam loops at the north-star size vs the reference: WavLM weights max|d| {e:.2e}, iterations {int(it)} (reference {int(g['iters_wavlm'])}); "
+          f"harmonics max|d| {eh:.2e}, iterations {int(ith)} (reference {int(g['iters_harm'])})")
+    assert int(it) == int(g["iters_wavlm"]) and int(ith) == int(g["iters_harm"])
+    assert e < 4e-4 and eh < 4e-4
+
+
 def test_knn_full_size_properties(north_star_features):
     from knn_svc_amd import ops
     from oracle import knn_ref
