@@ -422,6 +422,28 @@ def gen_vocoder():
     save("g7_vocoder", n=n, seed_in=61, f0=f0[0, :, 0].numpy(), harm=harm[0].numpy(), c=c[0].numpy(), **out)
 
 
+from tests.gen_golden_inputs import vocoder_full_inputs   # noqa: E402
+
+
+def gen_vocoder_full():
+    """G7c: the reference's FULL-SIZE generators (HiFi-GAN V1 configuration of the released checkpoints: mix and f0 kinds) on
+    seeded weights, 60 frames."""
+    print("G7c full-size generators (mix, f0), 60 frames")
+    h = C.HIFIGAN_V1
+    c, f0, harm = vocoder_full_inputs()
+    out = {}
+    for kind, seed in (("mix", 2), ("f0", 3)):
+        sd = S.seeded_state(S.generator_param_spec(h, kind), seed)
+        gen = ref_generator(h, kind, sd)
+        with torch.inference_mode():
+            y = gen(c, f0, harm) if kind == "mix" else gen(c, f0)
+        mine = vocoder_ref.synthesizer(sd, h, kind, c, f0, harm if kind == "mix" else None)
+        eq(y, mine, f"full-size generator {kind}", tol=1e-6)
+        out["wave_" + kind] = y[0, 0].numpy()
+        out["checksum_" + kind] = S.state_checksum(sd)
+    save("g7c_vocoder_full", n=60, **out)
+
+
 # ---------------------------------------------------------------- G10/G11: save_audio + end to end
 def gen_e2e():
     print("G10 save_audio scaling")
@@ -598,7 +620,7 @@ def gen_sample():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "smooth_ns", "synth", "vocoder", "e2e", "prematch", "sample"]
+    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "smooth_ns", "synth", "vocoder", "vocoder_full", "e2e", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

@@ -143,6 +143,24 @@ def test_vocoder_full_vs_oracle():
     assert r < 1e-4
 
 
+def test_vocoder_full_size_golden(golden):
+    """Fixture G7c: the reference's own full-size generators (22.9 M parameters; 'mix' with the additive synthesiser and 'f0'),
+    60 frames — the GPU waveform against the reference's, not only against the oracle."""
+    from knn_svc_amd.vocoder import Vocoder
+    from tests.gen_golden_inputs import vocoder_full_inputs
+    g = golden("g7c_vocoder_full")
+    h = C.HIFIGAN_V1
+    c, f0, harm = vocoder_full_inputs(int(g["n"]))
+    for kind, seed in (("mix", 2), ("f0", 3)):
+        sd = S.seeded_state(S.generator_param_spec(h, kind), seed)
+        voc = Vocoder(sd, h, kind, DEV)
+        y = voc.forward(c[0].to(DEV), f0[0, :, 0].to(DEV), harm[0].to(DEV)) if kind == "mix" else voc.forward(c[0].to(DEV), f0[0, :, 0].to(DEV))
+        ref = torch.from_numpy(g["wave_" + kind])
+        r = float((y.cpu().reshape(-1) - ref).pow(2).mean().sqrt())
+        print(f"full-size generator ({kind}) vs the reference's waveform: rms {r:.2e} (signal rms {float(ref.pow(2).mean().sqrt()):.3f})")
+        assert y.numel() == ref.numel() and r < 1e-5
+
+
 def _write_tiny_dataset(tmp_path, g):
     (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
     src_wav, src_f0 = S.synth_clip(3 * 16000 + 77, seed=int(g["src_seed"]))
