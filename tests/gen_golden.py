@@ -188,6 +188,25 @@ def gen_wavlm():
     save("g9_frame_law", lengths=np.array(lens), frames=np.array(counts))
 
 
+def gen_wavlm_full():
+    """G1d: the reference's WavLM-Large (first six layers: the exit layer of the live path) on ONE full 30 s chunk (T = 1500) with
+    seeded weights — every 25th frame of the layer-6 output and every frame's norm."""
+    print("G1d WavLM-Large, 6 layers, one full 30 s chunk (T = 1500)")
+    cfg6 = dict(C.WAVLM_LARGE, encoder_layers=6)
+    sd = S.seeded_state(S.wavlm_param_spec(C.WAVLM_LARGE, 6), seed=1)
+    m = ref_wavlm(cfg6, sd)
+    w, _ = S.synth_clip(30 * 16000, 31)
+    x = torch.from_numpy(np.pad(w, (0, 320)))[None]
+    with torch.inference_mode():
+        (rep, lr), _ = m.extract_features(x, output_layer=6, ret_layer_results=True)
+    l6 = lr[6][0][:, 0]
+    assert l6.shape == (1500, 1024)
+    mine = wavlm_ref.extract_layer(sd, C.WAVLM_LARGE, x, 6)
+    eq(l6, mine[0], "large layer 6, T = 1500", tol=5e-5)
+    save("g1d_wavlm_large6_full_chunk", seed=1, clip_seed=31, checksum=S.state_checksum(sd), rows=l6[::25].numpy(),
+         norms=l6.norm(dim=1).numpy())
+
+
 # ---------------------------------------------------------------- G3: kNN
 def gen_knn():
     print("G3 kNN top-32 on clustered features")
@@ -620,7 +639,7 @@ def gen_sample():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "smooth_ns", "synth", "vocoder", "vocoder_full", "e2e", "prematch", "sample"]
+    which = sys.argv[1:] or ["wavlm", "wavlm_full", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "smooth_ns", "synth", "vocoder", "vocoder_full", "e2e", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

@@ -47,6 +47,26 @@ def test_wavlm_large_six_layers_one_full_chunk_vs_oracle():
     assert float((1 - cos).max()) < 1e-10
 
 
+def test_wavlm_large_six_layers_one_full_chunk_golden(golden):
+    """Fixture G1d: the REFERENCE's WavLM-Large (six layers, seeded weights) on one full 30 s chunk — every 25th frame of the exit
+    layer and all 1500 frame norms, against the GPU encoder."""
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g1d_wavlm_large6_full_chunk")
+    sd = S.seeded_state(S.wavlm_param_spec(C.WAVLM_LARGE, 6), int(g["seed"]))
+    w, _ = S.synth_clip(30 * 16000, int(g["clip_seed"]))
+    x = torch.from_numpy(np.pad(w, (0, 320)))[None]
+    out = WavLMEncoder(sd, C.WAVLM_LARGE, DEV, n_layers=6).encode_batch(x.to(DEV))[0].cpu()
+    assert out.shape == (1500, 1024)
+    ref = torch.from_numpy(g["rows"])
+    mx, rms, rmax, rrms = _stats(out[::25], ref)
+    nd = float((out.norm(dim=1) - torch.from_numpy(g["norms"])).abs().max())
+    cos = F.cosine_similarity(out[::25].double(), ref.double(), dim=1)
+    print(f"WavLM-Large 6 layers, T=1500 vs the reference's rows: max|d| {mx:.2e} rms {rms:.2e} (ref max {rmax:.2f} rms {rrms:.3f}); "
+          f"largest frame-norm difference {nd:.2e}; min per-frame cosine {float(cos.min()):.12f}")
+    assert mx < 5e-5 * max(1.0, rmax) and rms < 2.5e-6 * max(1.0, rrms)
+    assert nd < 2e-4 and float((1 - cos).max()) < 1e-10
+
+
 def test_attention_full_length_vs_oracle():
     """attention2_kernel at E=1024 / H=16 / T=1500 (12 query blocks x many key tiles per head, distances beyond the
     last log bucket, ragged last tile since 1500 % 128 != 0) vs F.scaled_dot_product_attention with the gated bias."""
