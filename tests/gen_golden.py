@@ -523,6 +523,44 @@ def gen_e2e():
     save("g11_e2e", src_seed=81, pool_seed0=82, f0_scale=1.25, duration_limit=7, **res)
 
 
+def gen_e2e_full():
+    """G11c: files in -> waveform out through the REFERENCE's match_at_inference_time + vocode with the full architecture —
+    WavLM-Large (first six layers, the live path's exit layer) and the full-size 'mix' generator, seeded weights, mix,
+    post_opt_0.2 — on a 3 s source against three 5 s target files."""
+    print("G11c end-to-end with the full architecture (WavLM-Large x 6 layers, HiFi-GAN V1 'mix'), post_opt_0.2")
+    cfg6, h = dict(C.WAVLM_LARGE, encoder_layers=6), C.HIFIGAN_V1
+    sdw = S.seeded_state(S.wavlm_param_spec(C.WAVLM_LARGE, 6), seed=1)
+    m = ref_wavlm(cfg6, sdw)
+    tmp = Path(tempfile.mkdtemp())
+    (tmp / "a").mkdir(); (tmp / "b").mkdir()
+    src_wav, src_f0 = S.synth_clip(3 * 16000 + 40, seed=91)
+    pool = [S.synth_clip(5 * 16000 + 7 * i, seed=92 + i) for i in range(3)]
+    audio_io.write_wav_pcm16(str(tmp / "a" / "src.wav"), src_wav, 16000)
+    np.save(tmp / "a" / "src_f0.npy", (src_f0 * 1.2).astype(np.float32))
+    for i, (w, f) in enumerate(pool):
+        audio_io.write_wav_pcm16(str(tmp / "b" / f"u{i}.wav"), w, 16000)
+        np.save(tmp / "b" / f"u{i}_f0.npy", f.astype(np.float32))
+    src_w = torch.from_numpy(audio_io.read_wav(str(tmp / "a" / "src.wav"))[0][0])
+    pool_w = [torch.from_numpy(audio_io.read_wav(str(tmp / "b" / f"u{i}.wav"))[0][0]) for i in range(3)]
+    src_f = torch.from_numpy((src_f0 * 1.2).astype(np.float32))
+    pool_f = [torch.from_numpy(f.astype(np.float32)) for _, f in pool]
+    onehot = torch.zeros(7); onehot[6] = 1
+    weights = onehot[:, None]
+    sdg = S.seeded_state(S.generator_param_spec(h, "mix"), 2)
+    gen = ref_generator(h, "mix", sdg)
+    knn = R_m.KNeighborsVC(m, gen, AttrDict(dict(h)), "cpu")
+    knn.weighting = weights
+    srcp = str(tmp / "a" / "src.wav")
+    with quiet():
+        of, hf, _, sf0 = R_dp.match_at_inference_time(Path(srcp), tmp / "b", m, weights, weights, device="cpu", prioritize_f0=True,
+                                                       ckpt_type="mix", post_opt="post_opt_0.2", tgt_dataset_path=tmp)
+        y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None], hf[srcp][None]).squeeze()
+    mine = pipeline_ref.convert(sdw, C.WAVLM_LARGE, sdg, h, "mix", src_w, src_f, pool_w, pool_f, "mix", "post_opt_0.2", n_layers=6)
+    eq(y, mine, "e2e full architecture mix post_opt_0.2", tol=2e-5)
+    print(f"     {tuple(y.shape)} rms {y.pow(2).mean().sqrt():.4f}")
+    save("g11c_e2e_full", src_seed=91, pool_seed0=92, f0_scale=1.2, wave=y.numpy())
+
+
 def gen_prematch():
     """G12: the reference's per_spk_extract on a two-speaker toy dataset (tiny WavLM).  As committed the function
     hands (ls_path, device) to get_complete_spk_pool's (device, duration_limit) parameters
@@ -639,7 +677,7 @@ def gen_sample():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["wavlm", "wavlm_full", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "smooth_ns", "synth", "vocoder", "vocoder_full", "e2e", "prematch", "sample"]
+    which = sys.argv[1:] or ["wavlm", "wavlm_full", "knn", "knn_ties", "knn_ns", "select", "select_ns", "smooth", "smooth_ns", "synth", "vocoder", "vocoder_full", "e2e", "e2e_full", "prematch", "sample"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

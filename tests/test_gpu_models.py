@@ -217,6 +217,34 @@ def test_e2e_tiny_golden(golden, tmp_path):
     assert enc.layer_mix is None                                           # the shared encoder is back on the matching weighting
 
 
+def test_e2e_full_architecture_golden(golden, tmp_path):
+    """Fixture G11c: the REFERENCE's waveform for files -> match_at_inference_time -> vocode with the full architecture (WavLM-Large
+    x six layers, full-size 'mix' generator, seeded weights, post_opt_0.2): the product's waveform against it, north-star bar."""
+    from knn_svc_amd.matcher import KNeighborsVC
+    from knn_svc_amd.matching import match_at_inference_time
+    from knn_svc_amd.vocoder import Vocoder
+    from knn_svc_amd.wavlm import WavLMEncoder
+    g = golden("g11c_e2e_full")
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    src_wav, src_f0 = S.synth_clip(3 * 16000 + 40, seed=int(g["src_seed"]))
+    audio_io.write_wav_pcm16(str(tmp_path / "a" / "src.wav"), src_wav, 16000)
+    np.save(tmp_path / "a" / "src_f0.npy", (src_f0 * float(g["f0_scale"])).astype(np.float32))
+    for i in range(3):
+        w, f = S.synth_clip(5 * 16000 + 7 * i, seed=int(g["pool_seed0"]) + i)
+        audio_io.write_wav_pcm16(str(tmp_path / "b" / f"u{i}.wav"), w, 16000)
+        np.save(tmp_path / "b" / f"u{i}_f0.npy", f.astype(np.float32))
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(C.WAVLM_LARGE, 6), seed=1), C.WAVLM_LARGE, DEV, n_layers=6)
+    knn = KNeighborsVC(enc, Vocoder(S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, "mix"), 2), C.HIFIGAN_V1, "mix", DEV), C.HIFIGAN_V1, DEV)
+    srcp = str(tmp_path / "a" / "src.wav")
+    of, hw, _a, sf0 = match_at_inference_time(srcp, tmp_path / "b", enc, knn.weighting, knn.weighting, prioritize_f0=True,
+                                              ckpt_type="mix", post_opt="post_opt_0.2", tgt_dataset_path=tmp_path)
+    y = knn.vocode(of[srcp][None], sf0[srcp][None, :, None], hw[srcp][None]).squeeze()
+    ref = g["wave"]
+    r = _rms(y, ref)
+    print(f"e2e full architecture, mix post_opt_0.2: waveform rms error vs the reference {r:.2e} (signal rms {float(np.sqrt((ref ** 2).mean())):.3f})")
+    assert y.shape[0] == ref.shape[0] and r < 1e-4
+
+
 def test_special_match_writes_reference_named_file(golden, tmp_path):
     from knn_svc_amd.matcher import KNeighborsVC
     from knn_svc_amd.vocoder import Vocoder
