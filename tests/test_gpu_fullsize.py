@@ -38,13 +38,20 @@ def test_knn_north_star_size_against_the_reference_fixture(golden):
     idx, dist = ops.knn_topk(q.to(DEV), p.to(DEV), 32)
     assert ops.KNN_ROUTE_COUNTS["fused"] > fused0 and ops.KNN_ROUTE_COUNTS["dot"] == dot0      # the route under test
     idx, dist = idx.cpu(), dist.cpu()
-    d64 = knn_ref.cosine_dist_f64(q, p)
     ref_idx = torch.from_numpy(g["idx"]).long()
+
+    def exact(ix):            # fp64 cosine distances of the listed pairs only (the full 1500 x 30 000 fp64 matrix costs a minute of CPU)
+        qd, pr = q.double(), p.double()[ix]                                      # [nq, 32, 1024]
+        return (1.0 - torch.einsum("qd,qkd->qk", qd, pr) / (qd.norm(dim=1)[:, None] * pr.norm(dim=2))).numpy()
+    da, db = exact(ref_idx), exact(idx)
     # how far each side's fp32 distances sit from the exact ones (on its own list): the reference's formula (cdist through a
     # matrix product, clamp, sqrt, ...) is only defined up to that, and so is the ORDER of neighbours closer together than it
-    err_ref = float(np.abs(np.take_along_axis(d64, ref_idx.numpy(), 1) - g["dist"].astype(np.float64)).max())
-    err_gpu = float(np.abs(np.take_along_axis(d64, idx.numpy(), 1) - dist.numpy().astype(np.float64)).max())
-    st = knn_ref.topk_agreement(ref_idx, idx, d64, tau=err_ref + err_gpu)
+    err_ref = float(np.abs(da - g["dist"].astype(np.float64)).max())
+    err_gpu = float(np.abs(db - dist.numpy().astype(np.float64)).max())
+    a_, b_ = ref_idx.numpy(), idx.numpy()
+    st = dict(top4=float(np.mean(np.all(a_[:, :4] == b_[:, :4], axis=1))), allk=float(np.mean(np.all(a_ == b_, axis=1))),
+              sets=float(np.mean([set(a_[i]) == set(b_[i]) for i in range(len(a_))])), max_gap=float(np.abs(da - db).max()),
+              unexplained=int(np.sum(np.abs(da - db) > err_ref + err_gpu)))          # knn_ref.topk_agreement on the listed pairs
     print(f"kNN at the north-star size vs the reference fixture: {st}; largest |fp32 - exact| distance: reference {err_ref:.2e}, here {err_gpu:.2e}")
     # measured (r04, deterministic): the reference's distances are up to 6.8e-7 off the exact ones, this path's up to 1.22e-6 (the
     # emulated product drops lo x lo: 2^-22 per term); the ordered lists differ in 5.6 % of the rows, the sets in 1 row of 1500,
