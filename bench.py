@@ -12,11 +12,13 @@ architectures (no network for the released checkpoints).  value = source seconds
 ranks / wall time of the slowest rank.
 
 Extra objects on the JSON line:
-  roofline     — the dominant kernel (implicit GEMM, 128x128 tile, fp32 emulated as three fp16 MFMAs per
-                 product): algorithmic fp32 FLOP (2*M*N*K per launch) / HIP-event time of those launches,
-                 against the dense fp16 matrix peak / 3 (and, for reference, the 157.3 TFLOP/s fp32 peak);
+  roofline     — the dominant kernel (conv_gemm2quad_kernel<Gemm2QuadS>: implicit GEMM, 256x256 block tiles of
+                 v_mfma_f32_16x16x32_f16, fp32 emulated as three fp16 MFMAs per product): algorithmic fp32 FLOP
+                 (2*M*N*K per launch) / HIP-event time of those launches, against the dense fp16 matrix peak / 3
+                 (and, for reference, the 157.3 TFLOP/s fp32 peak);
   cpu_baseline — the CPU oracle (a port of the reference's --device cpu path) timed on this box's
-                 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                 host cores on a bounded sample of the same workload (rank 0, N = 1 only); the sample is
+                 scaled to the full step, so the object carries "extrapolated": true and the per-stage seconds.
 """
 import argparse
 import json
@@ -76,15 +78,16 @@ POOL_CLIPS = 20                        # x 30 s = 10 minutes per rank
 
 
 class GemmTimer:
-    """HIP-event timing of every launch of conv_gemm_kernel<GemmTile<128,128,2,2,2,2>, 4> (the
-    dominant kernel) on the stream it is launched on, plus its algorithmic FLOP."""
+    """HIP-event timing of every conv_gemm launch that can reach a candidate for "the dominant kernel" (the library
+    reports which kernel it dispatched: Q256S = conv_gemm2quad_kernel<Gemm2QuadS>, the dominant one since round 2;
+    F128 / F128a2 = conv_gemm2_kernel<Gemm2Tile<128,128,..>>), on the stream it is launched on, plus its algorithmic FLOP."""
 
     def __init__(self):
         self.records = []
         self.enabled = False
         self.all_variants = False
         # candidates for "the dominant kernel": both instantiations of conv_gemm2_kernel<Gemm2Tile<128,128,...>> (A fp32 / A
-        # pre-split) count as one kernel, conv_gemm2quad_kernel<Gemm2QuadR> (long-K launches) as another; summary() reports the
+        # pre-split) count as one kernel, conv_gemm2quad_kernel<Gemm2QuadS> (long-K launches) as another; summary() reports the
         # one with more time in the step and carries the other along as `secondary`
         self.families = {"f16x2": (("F128", "F128a2"), ("Q256S",), ("Q256",)), "bf16x3": (("H128",),), "fp32": (("G128v8",),)}[ops.gemm_mode()]
         self.dominant = tuple(t for fam in self.families for t in fam)
@@ -299,7 +302,7 @@ def cpu_baseline(snap):
     cfg, h = C.WAVLM_LARGE, C.HIFIGAN_V1
     sdw = S.seeded_state(S.wavlm_param_spec(cfg, 6), seed=1)
     sdg = S.seeded_state(S.generator_param_spec(h, "mix"), seed=2)
-    t, spread = {}, {}
+    t, spread, sampled = {}, {}, [0.0]
 
     def timed(name, scale, fn, reps=3):
         fn()                                                   # warm-up, untimed
@@ -308,6 +311,7 @@ def cpu_baseline(snap):
             t0 = time.perf_counter(); fn(); xs.append(time.perf_counter() - t0)
         t[name] = statistics.median(xs) * scale
         spread[name] = (min(xs) * scale, max(xs) * scale)
+        sampled[0] += sum(xs)                                  # host seconds actually spent in timed calls
     wav = snap["src"]
     timed("wavlm", 21.0, lambda: wavlm_ref.full_features(sdw, cfg, wav, 6))
     # the reference itself runs all 24 layers and keeps layer 6 (ddsp_prematch_dataset.py:289): one more
@@ -334,6 +338,9 @@ def cpu_baseline(snap):
     total = sum(t.values())
     lo, hi = sum(v[0] for v in spread.values()), sum(v[1] for v in spread.values())
     return dict(value=round(SRC_SECONDS / total, 4), unit="x real-time", cores=cores, kind="port",
+                extrapolated=True,          # every stage is timed on a bounded sample and scaled to the full step (see `sample`)
+                stage_seconds={k: round(v, 2) for k, v in t.items()}, full_step_seconds=round(total, 1),
+                sampled_seconds=round(sampled[0], 1),
                 value_range=[round(SRC_SECONDS / hi, 4), round(SRC_SECONDS / lo, 4)],
                 reference_equiv_24_layers=round(SRC_SECONDS / (total + t_extra), 4),
                 torch_threads=torch.get_num_threads(), timing="1 warm-up + median of 3 per stage",
@@ -569,7 +576,9 @@ def main():
                        "nq": 1500, "np_per_rank": (30000 // ws if STRONG else 30000),
                        "pool_sharding": (f"one pool, rows over {ws} rank(s) in file order, replicated queries, RCCL all-gather merge of the top-32 lists; "
                                          f"match + generator of conversion i on rank i mod {ws} only, pool rows to that rank point-to-point"
-                                         if STRONG else f"rows over {ws} rank(s), RCCL all-to-all merge"),
+                                         if STRONG else ("none: one rank searches its whole 30 000-row pool (no process group, no collective)" if ws == 1 else
+                                                         f"weak: every rank holds its own 30 000-row shard and searches all {ws} x 1500 query frames in it; "
+                                                         "top-32 lists exchanged with one RCCL all-to-all and merged (lower index first on ties)")),
                        "wavlm_batch_chunks": a.max_batch,
                        "pipeline_depth": a.pipeline_depth,
                        "pipeline": ("match + vocoder of conversion i run on a second stream under the encoder of conversion i+1"

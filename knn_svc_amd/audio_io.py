@@ -5,8 +5,8 @@ The reference goes through ``torchaudio.load`` (ddsp_prematch_dataset.py:332) an
 library is in this image, so WAV is handled here with numpy and FLAC (what the
 reference's prematch builder globs next to .wav: LibriSpeech) by the library's own
 RFC 9639 decoder / encoder (csrc/flac.hip, host code: frame CRCs and the stream MD5 are
-verified on every read).  .mp3 is delegated to torchaudio/soundfile when importable and
-refused otherwise.  Sample values follow torchaudio's convention: integer PCM is scaled
+verified on every read).  .mp3 is delegated to soundfile when importable and refused otherwise — at LISTING
+time (matching.list_audio), before anything is encoded.  Sample values follow torchaudio's convention: integer PCM is scaled
 by 2**-(bits-1) to float32 in [-1, 1).
 """
 from __future__ import annotations
@@ -118,6 +118,18 @@ def write_flac(path: str, pcm: np.ndarray, sr: int, bits: int = 24) -> None:
         f.write(bytes(out[:size.value]) if size.value < (1 << 20) else memoryview(out)[:size.value])
 
 
+def can_decode(ext: str) -> bool:
+    """Whether ``load_audio`` has a decoder for this extension HERE: .wav / .flac natively, anything else only through an
+    importable soundfile (absent in this image — the reference reads .mp3 through torchaudio/ffmpeg)."""
+    if ext.lower() in (".wav", ".flac"):
+        return True
+    try:
+        import soundfile  # noqa: F401
+        return True
+    except ImportError:
+        return False
+
+
 def load_audio(path: str):
     """torchaudio.load stand-in: -> (float32 ndarray [channels, samples], sr)."""
     ext = os.path.splitext(path)[-1].lower()
@@ -131,7 +143,7 @@ def load_audio(path: str):
         return np.ascontiguousarray(x.T), sr
     except ImportError:
         pass
-    raise RuntimeError(f"{path}: only .wav can be decoded without soundfile/torchaudio installed")
+    raise RuntimeError(f"{path}: only .wav and .flac can be decoded without soundfile installed")
 
 
 def to_pcm32(wave: np.ndarray) -> np.ndarray:

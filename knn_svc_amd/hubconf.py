@@ -89,9 +89,11 @@ def wavlm_large(pretrained=True, progress=True, device="cuda", weights="auto", c
 def knn_vc(pretrained=True, progress=True, prematched=True, ckpt_type="mix", device="cuda",
            local_ckpt_dir=DEFAULT_CKPT_DIR, weights="auto") -> KNeighborsVC:
     """Load kNN-SVC (WavLM encoder + conditioned HiFi-GAN) — ddsp_hubconf.py:17-25."""
-    if str(device) == "cpu":
-        logging.warning("device='cpu' requested: this build only runs on the GPU; using 'cuda'")
-        device = "cuda"
+    if str(device).startswith("cpu"):
+        # ddsp_inference.py:39 offers --device cpu; this build has NO CPU path (the oracle under oracle/ is test infrastructure and
+        # must never serve a conversion).  Fail once and clearly instead of remapping to 'cuda' and dying later elsewhere.
+        raise RuntimeError("device='cpu' requested: knn_svc_amd only runs on a ROCm GPU (MI355X, gfx950) — there is no CPU path; "
+                           "pass --device cuda")
     hifigan, h = hifigan_wavlm(pretrained, progress, prematched, ckpt_type, device, local_ckpt_dir, weights)
     wavlm = wavlm_large(pretrained, progress, device, weights)
     return KNeighborsVC(wavlm, hifigan, h, device)

@@ -38,9 +38,18 @@ def list_audio(path) -> list:
     """A single audio file, or every audio file under a folder in sorted rglob order (:313-319)."""
     path = Path(path)
     if os.path.isfile(path) and os.path.splitext(path)[-1] in AUDIO_EXT:
-        return [path]
-    files = sorted([p for p in path.rglob("**/*") if p.suffix.lower() in AUDIO_EXT])
-    assert len(files) != 0, [f"directory not containing any audio {path}"]
+        files = [path]
+    else:
+        files = sorted([p for p in path.rglob("**/*") if p.suffix.lower() in AUDIO_EXT])
+        assert len(files) != 0, [f"directory not containing any audio {path}"]
+    # The reference decodes every listed container through torchaudio (:332).  Here .wav and .flac are decoded natively and
+    # .mp3 only when soundfile is importable: a pool that holds a file nobody can decode is refused NOW, by name, not in the
+    # middle of a run after the other files have been encoded.
+    bad = [str(p) for p in files if not audio_io.can_decode(p.suffix)]
+    if bad:
+        raise RuntimeError(f"{len(bad)} audio file(s) under {path} are in a container this build cannot decode without the "
+                           f"'soundfile' package (.wav and .flac are native): {bad[:5]}{' ...' if len(bad) > 5 else ''} — "
+                           "transcode them to .wav / .flac or install soundfile")
     return files
 
 
@@ -100,6 +109,13 @@ def side_features_many(wavs_gpu, f0s_host, Ts):
     return [(f0, harm, spec) for f0, (spec, harm) in zip(f0s, res)]
 
 
+def disk_identity(wavlm) -> tuple:
+    """What an on-disk pool-store entry belongs to besides its audio file: the encoder's WEIGHTS, its exit layer and the layer
+    weighting the features were mixed under (set_layer_mix bumps ``uid`` for the in-memory tier; the disk tier outlives the
+    process, so it needs the weighting itself — without it a second weighting read back the first one's features)."""
+    return (wavlm.weights_fingerprint(), wavlm.n_layers, getattr(wavlm, "layer_mix", None))
+
+
 def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_weights=None, device="cuda",
                           duration_limit=None, vad_trigger_level=0, shard_files=False, gather=False):
     """Per-file dicts (matching_pool, synth_pool, audio_synth_pool, spec_synth_pool, f0_pool, harmonics_pool),
@@ -116,7 +132,7 @@ def get_complete_spk_pool(path, wavlm: WavLMEncoder, match_weights=None, synth_w
     files = list_audio(path)
     cache = _pool_cache()
     tag = (wavlm.uid, wavlm.n_layers)
-    dtag = (wavlm.weights_fingerprint(), wavlm.n_layers) if cache.disk_dir else None     # on-disk tier: content identity
+    dtag = disk_identity(wavlm) if cache.disk_dir else None     # on-disk tier: content identity
     dkeys = {}
     kept, keys, Ts = [], [], []
     loaded = {}                       # index -> (wav host, f0 host) for files that miss the cache

@@ -93,7 +93,7 @@ class BatchConverter:
         self.lanes = lanes if lanes is not None else int(os.environ.get("KNNSVC_MATCH_LANES", "3"))
         self.max_encode_batch = max_encode_batch
 
-    def _load(self, src):
+    def _load(self, src, check=False):
         """A request is a path, or (wav [L] float32 16 kHz mono as array / tensor, f0 [L // 320 + 1] or None).
         -> (wav on the device, f0 host array or device tensor)."""
         dev = self.vc.device
@@ -101,7 +101,16 @@ class BatchConverter:
             w, f0 = M.load_utterance(src)                    # resamples, reads or computes + caches <stem>_f0.npy
             return torch.from_numpy(w).to(dev), f0
         w, f0 = src
-        w = (w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))).to(dev).float().reshape(-1)
+        w = w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+        # checked on the RAW input, before anything flattens it or runs on it: a [2, L] stereo array would otherwise be converted
+        # as one 2L-sample mono clip, and Harvest would run on NaN samples before the finiteness check
+        if w.dim() == 2 and 1 in w.shape:
+            w = w.reshape(-1)                                # [1, L] / [L, 1]: mono with a channel axis (torchaudio.load's shape)
+        if w.dim() != 1:
+            raise ValueError(f"request: expected a mono waveform [L], got shape {tuple(w.shape)}")
+        w = w.to(dev).float()
+        if check and not bool(torch.isfinite(w).all()):      # (one small host read per request: a server checks its inputs at the door)
+            raise ValueError("request: the waveform contains NaN or infinite samples")
         if f0 is None:
             f0 = ops.f0_harvest(w)                           # Harvest on the GPU (csrc/harvest.hip), as load_utterance does
         elif not isinstance(f0, torch.Tensor):
@@ -111,10 +120,8 @@ class BatchConverter:
     def load_checked(self, src):
         """_load + the checks that do not need the encoder: a request that fails them fails alone (RequestQueue), before it can
         take a batch down with it.  -> (wav, f0)."""
-        w, f0 = self._load(src)
-        if w.dim() != 1:
-            raise ValueError(f"request: expected a mono waveform [L], got shape {tuple(w.shape)}")
-        if not bool(torch.isfinite(w).all()):          # (one small host read per request: a server checks its inputs at the door)
+        w, f0 = self._load(src, check=True)          # shape and finiteness are checked on the raw input, before Harvest runs on it
+        if isinstance(src, (str, os.PathLike)) and not bool(torch.isfinite(w).all()):
             raise ValueError("request: the waveform contains NaN or infinite samples")
         T = M.frames_of(int(w.shape[0]), self.vc.wavlm)
         if T < 1:

@@ -171,7 +171,7 @@ class Vocoder:
                 self._graph_pools[slot] = torch.cuda.graph_pool_handle()
             g, out = ops.capture_graph(lambda: self._forward(sc, sf, sh, n_dyn=nd), self.device, self._graph_pools[slot])
             ent = self._graphs[key] = (g, sc, sf, sh, nd, out, [None])
-            self._evict(slot)
+            self._evict(slot, keep=key)
         else:
             self._graphs[key] = self._graphs.pop(key)                 # most recently used
         g, sc, sf, sh, nd, out, last = ent
@@ -184,22 +184,29 @@ class Vocoder:
         last[0] = torch.cuda.current_stream(c.device)       # the entry may be destroyed once this stream has drained (a stream
         return y                                            # object, not an event: events held at interpreter exit crash in hipEventDestroy)
 
-    def _evict(self, slot) -> None:
+    def _evict(self, slot, keep=None) -> None:
         """LRU per tail stream (``max_graphs`` instances EACH: the key space is buckets x tails, and the tails replay
         independently).  An evicted key is forgotten altogether — its next sight is an eager pass again, not an immediate
         re-capture, so a length distribution wider than the cache degrades to eager passes instead of a capture per call — and
-        only an entry whose last replay has finished is destroyed (its static buffers go back to the tail's pool)."""
-        mine = [k for k in self._graphs if (k[1] if isinstance(k, tuple) and not isinstance(k[1], str) else 0) == slot]
-        extra = len(mine) - self.max_graphs
+        only an entry whose last replay has finished is destroyed (its static buffers go back to the tail's pool).  The entry
+        just captured (``keep``) is never a victim.  Under a steady pipeline the tails are never idle, so "skip the busy ones"
+        alone would let the cache grow without bound: beyond twice the budget the oldest entry's stream is waited for once
+        (a host wait on work that is already queued: it ends) and the entry goes."""
+        mine = [k for k in self._graphs if k != keep and (k[1] if isinstance(k, tuple) and not isinstance(k[1], str) else 0) == slot]
+        extra = len(mine) + (1 if keep is not None else 0) - self.max_graphs
+        hard = len(mine) + (1 if keep is not None else 0) - 2 * self.max_graphs
         for k in mine:                                                    # insertion order = least recently used first
             if extra <= 0:
                 break
             st = self._graphs[k][6][0]
             if st is not None and not st.query():
-                continue                                                  # its stream is still busy: try the next oldest
+                if hard <= 0:
+                    continue                                              # its stream is still busy: try the next oldest
+                st.synchronize()                                          # bounded overshoot: this one has to go
             self._graphs.pop(k)
             self._seen.discard(k)
             extra -= 1
+            hard -= 1
 
     def _forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None, n_dyn: torch.Tensor | None = None) -> torch.Tensor:
         """``n_dyn`` (device int32 [1], <= N): the valid frame count of a forward laid out for N = a bucket's frames."""

@@ -122,13 +122,21 @@ def test_request_queue_a_bad_request_fails_alone_and_one_deadline_per_batch(tmp_
     bad_f0 = (reqs[1][0], reqs[1][1][:-7])
     nan_w = reqs[2][0].copy(); nan_w[5000:5100] = np.nan
     rq = serving.RequestQueue(conv, max_batch=8, max_wait_ms=400.0)
-    futs = [rq.submit(r) for r in (reqs[0], bad_f0, (nan_w, reqs[2][1]), reqs[3])]
+    # a stereo [2, L] array must not be flattened into one 2L-sample mono clip, and a NaN waveform WITHOUT an f0 track
+    # must be refused before Harvest runs on it — both are checked on the raw input
+    stereo = (np.stack([reqs[0][0], reqs[0][0]]), reqs[0][1])
+    futs = [rq.submit(r) for r in (reqs[0], bad_f0, (nan_w, reqs[2][1]), reqs[3], stereo, (nan_w, None))]
     with pytest.raises(ValueError):
         futs[1].result(timeout=60)
     with pytest.raises(ValueError):
         futs[2].result(timeout=60)
+    with pytest.raises(ValueError, match="mono"):
+        futs[4].result(timeout=60)
+    with pytest.raises(ValueError, match="NaN"):
+        futs[5].result(timeout=60)
     assert torch.equal(futs[0].result(timeout=60), alone[0]) and torch.equal(futs[3].result(timeout=60), alone[3])
-    assert rq.batches == [4] and rq.isolated == 0, (rq.batches, rq.isolated)
+    assert rq.batches == [6] and rq.isolated == 0, (rq.batches, rq.isolated)
+    assert torch.equal(conv.convert([(reqs[0][0][None], reqs[0][1])])[0].cpu(), alone[0])       # [1, L]: mono with a channel axis
     rq.close()
     with pytest.raises(ops.KnnSvcError):                 # not through the queue: the whole batch is enqueued, then the flag raises
         conv.convert([reqs[0], (nan_w, reqs[2][1]), reqs[3]])

@@ -35,3 +35,15 @@ def test_concat_reselect_is_bit_stable_beside_mfma_workgroups():
     # no assertion on pr["differ"]: > 0 reproduces round 3's finding (the fence is what keeps the product stable).  Since the walk
     # was rebuilt in round 4 (nine waves: three on SIMD 0) these co-runners cannot share its CU any more and the probe reads 0;
     # round 3's walk rebuilt from history still reads 26-33 of 40 (profiles/r04_concat_race_bisect.txt)
+
+
+def test_hand_packed_fp32_kernels_are_bit_stable_beside_mfma_workgroups():
+    """kn_gelu2 (csrc/common.h), conv0_ln_gelu_kernel's channel pairs and the GEMMs' GELU epilogues hand-emit packed
+    fp32 (v_pk_fma / mul / add_f32) although the library is built with -fno-slp-vectorize.  They run in the stream pipeline beside
+    the generator's MFMA kernels (and the epilogue is inside one): every launch beside the co-runners must equal the quiet one."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import packed_race
+    res = packed_race.run(runs=20)
+    print("hand-packed fp32 beside MFMA co-runners:", res)
+    assert all(v == 0 for v in res["differ"].values()), res
+    assert any(k.startswith("W128") for k in res["co_runners"]), res
