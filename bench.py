@@ -551,6 +551,7 @@ def main():
             print(f"[stage] {k:14s} {sum(ms) / max(1, len(ms)):9.3f} ms/step", file=sys.stderr)
 
     if rank == 0:
+        import glob
         ms_step = dt / a.steps * 1e3
         value = (1 if STRONG else ws) * SRC_SECONDS * a.steps / dt      # strong: ONE conversion per step, all ranks on it
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -624,12 +625,22 @@ def main():
                            "frac_fp32_mfma_peak_157.3": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),
                            "t_mfma_floor_ms": round(flop / (F16X2_PEAK_TFLOPS * 1e12) * 1e3, 4),
                            "t_hbm_floor_ms": round(min_bytes / 8e12 * 1e3, 4),
-                           "route": "fused (epochs of knn_screen + knn_refine on the Gemm2QuadS loop): no [Nq, Np] distance or dot matrix in HBM",
-                           "note": "whole stage incl. row norms, operand splits, both epochs' screening GEMMs and top-32 refinement, and the "
+                           "route": "fused (epochs of knn_screen + knn_refine on the Gemm2QuadS loop: no [Nq, Np] distance or dot matrix in HBM), then "
+                                    "knn_rescore: the listed pairs re-scored from exact (fp64-accumulated) dot products",
+                           "note": "whole stage incl. row norms, operand splits, both epochs' screening GEMMs, top-32 refinement, the exact re-score, and the "
                                    "RCCL list exchange + merge; query_frames_per_s counts every rank's frames resolved against the whole pool"}
+        # counted (not inferred) MFMA utilisation of the search's kernels: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over
+        # the same search size (tools/pmc_knn.sh -> profiles/rNN_pmc_knn.json; bench.py cannot read PMCs itself)
+        if "knn" in line:
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_knn.json")), reverse=True):
+                t = json.load(open(pmc))
+                if t.get("nq") == 1500 and t.get("np") == 30000 and "screen_mfma_util" in t:
+                    line["knn"]["mfma_util_counted"] = {"knn_screen_kernel": round(t["screen_mfma_util"], 4), "whole_search": round(t["search_mfma_util"], 4),
+                                                        "source": f"profiles/{os.path.basename(pmc)}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), "
+                                                                  "one rocprofv3 --pmc pass over tools/knn_prof_one.py 1500 30000"}
+                    break
         # measured offline with rocprofv3 --pmc (tools/pmc_traffic.py, tools/refresh_profiles.sh); bench.py cannot read PMCs itself.
         # Newest round's file whose kernel is the one reported above.
-        import glob
         want = {"Q256S": "Gemm2QuadS", "Q256": "Gemm2QuadR"}.get(dom_tags[0], "Gemm2Tile<128, 128" if dom_tags[0].startswith("F128") else None)
         for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             t = json.load(open(pmc))

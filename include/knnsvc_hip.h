@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 11
+#define KNNSVC_ABI_VERSION 12
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -240,8 +240,24 @@ int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32_t ldx, flo
 
 size_t knnsvc_knn_workspace_bytes(int64_t nq, int64_t np, int32_t k);
 
+/* Wide lists and the exact re-score (round 5).  "Bit-exact top-k indices" is defined against the reference's fp32 formula
+ * (lib_ongaku_test.py:162-165) evaluated on ITS matrix product; whatever product a GPU kernel forms (here: fp16-split MFMAs with 96
+ * fp32 roundings along K, or fp32 MFMAs) differs from it in the last bits, and neighbours closer together than those bits swap.
+ * The selection kernels below therefore only PICK candidates: each keeps, per query row, a WIDE list of up to 64 keys
+ * (uint64: order-preserving bits of the screening distance << 32 | pool row) — the k best and every pair within 4e-6 of the
+ * k-th — and knnsvc_knn_rescore recomputes q.p for exactly those pairs in fp64 from the fp32 operands, rounds once to fp32,
+ * replays the reference's formula and sorts by (distance bits, lower index first).  What is left between this order and the
+ * reference's is the reference's own BLAS rounding.  exact = 0 passes the screening order through (A/B aid).
+ * wide: [nq][64] keys ascending, unused places 0xFFFF...F; out_idx / out_dist: [nq][k], indices + idx_offset; a row with fewer
+ * than k finite distances (a NaN row) is filled with VALID row indices and NaN distances.  [mask_lo, mask_hi) as below. */
+int knnsvc_knn_rescore(const void* wide, int64_t nq, int32_t k, const float* q, const float* q_norm, const float* q_sq,
+                       const float* pool, const float* p_norm, const float* p_sq, int64_t np, int32_t dim,
+                       int64_t idx_offset, int64_t mask_lo, int64_t mask_hi, int32_t exact,
+                       int64_t* out_idx, float* out_dist, void* stream);
+
 /* Ascending top-k of d(q_i, p_j) per query row, d evaluated with the reference's operation
- * sequence on top of an MFMA dot product.  Ties: lower pool index first.  Indices are written
+ * sequence on top of an fp32-MFMA dot product (candidates), then re-scored exactly (rescore != 0: knnsvc_knn_rescore).
+ * Ties: lower pool index first.  Indices are written
  * as idx_offset + j (so that a pool shard reports global rows).  k <= 32.
  * [mask_lo, mask_hi): local pool rows whose distance is replaced by exactly 1 before selection — the
  * self-matching rule of per_spk_extract (ddsp_prematch_dataset.py:1606-1607, `dists[:, start:end] = 1`);
@@ -250,16 +266,17 @@ int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int6
                     const float* pool, const float* p_norm, const float* p_sq, int64_t np,
                     int32_t dim, int32_t k, int64_t idx_offset, int64_t mask_lo, int64_t mask_hi,
                     int64_t* out_idx, float* out_dist, void* workspace, size_t workspace_bytes,
-                    int32_t* nan_flag, void* stream);
+                    int32_t* nan_flag, int32_t rescore, void* stream);
 
 /* Second half of the two-kernel kNN route: `dots`[nq, np] (row pitch ld) holds q.p^T computed by knnsvc_conv_gemm
  * on the emulated-fp32 matrix-core path (q as the A operand, the pool rows as pre-split "weights"); this replays the
- * reference's distance formula (lib_ongaku_test.py:148-175) on every entry and selects each row's ascending top-k with
- * the same (distance, lower index) order, NaN flag and idx_offset semantics as knnsvc_knn_topk. */
+ * reference's distance formula (lib_ongaku_test.py:148-175) on every entry and keeps each row's WIDE list (wide_out [nq][64],
+ * see knnsvc_knn_rescore, which turns it into the top-k) with the same (distance, lower index) order and NaN flag
+ * semantics as knnsvc_knn_topk. */
 int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const float* q_sq, int64_t nq,
-                      const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                      const float* p_norm, const float* p_sq, int64_t np, int32_t k,
                       int64_t mask_lo, int64_t mask_hi,
-                      int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream);
+                      void* wide_out, int32_t* nan_flag, void* stream);
 
 /* Fused route (no [nq, np] dot matrix in HBM; lib_ongaku_test.py:148-175 + ddsp_prematch_dataset.py:1195-1210: the reference's
  * 20-row cdist + topk loop over the whole pool).  The caller walks the pool's rows in EPOCHS [p_base, p_base + np) of growing
@@ -270,8 +287,9 @@ int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const 
  * (distance, pool index) key.
  *   thr == thr_idx == NULL (the first epoch): every 256 x 256 tile bounds its rows itself — at least 32 of its columns lie at
  *     or below the bound it derives, so no row's top-k (k <= 32) can lie beyond it;
- *   otherwise (thr[row], thr_idx[row]) = the row's k-th best key over the rows searched so far (knnsvc_knn_refine's thr_out /
- *     thr_idx_out; the index in the chunk's index space, i.e. without idx_offset): exactly the pairs with key <= it pass.
+ *   otherwise (thr[row], thr_idx[row]) = the row's threshold key over the rows searched so far (knnsvc_knn_refine's thr_out /
+ *     thr_idx_out: the k-th best distance + the guard band of the exact re-score; the index in the chunk's index space, i.e.
+ *     without idx_offset): exactly the pairs with key <= it pass.
  * Survivors are appended to cand[row][0 .. cap) as (pool index = p_base + row in epoch, order-preserving bits of the distance;
  * 0xFFFFFFFF = NaN), 8 bytes each; cand_count[row] counts them (the caller zeroes cand_count and the flag once; refine
  * resets the counts).  Bit 1 of *overflow_flag set afterwards: some row had more than cap survivors — the caller must fall
@@ -280,11 +298,11 @@ int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const 
  * bound found for each row — knnsvc_knn_refine's row_bound: it starts from it and drops the survivors of weaker tiles unseen —,
  * then the per-half-tile bounds and arrival counters through which the tiles of a row tile, running side by side, tighten each
  * other's bounds (a bounded wait; only tightness depends on it, never the result).
- * knnsvc_knn_refine: prev_idx / prev_dist (NULL in the first epoch: the previous refine's out_idx / out_dist, [nq, k]) + the
- * candidates -> ascending top-k with knnsvc_knn_select's keys and idx_offset semantics — after the last epoch identical to
- * evaluating every pair.  flags: bit 0 = a NaN distance was met, bit 1 (final_pass only) = a row ended with fewer than k
- * entries although no NaN was seen (the caller repeats the search on the dot-matrix route).  thr_out / thr_idx_out (NULL after
- * the last epoch): the next epoch's thresholds.
+ * knnsvc_knn_refine: the row's wide list so far (`wide` [nq][64], read when has_prev != 0: the previous refine's output) + the
+ * candidates -> the wide list, written back to `wide` — after the last epoch identical to knnsvc_knn_select's over every
+ * pair; knnsvc_knn_rescore turns it into the top-k.  flags: bit 0 = a NaN distance was met, bit 1 (final_pass only) = a row
+ * ended with fewer than k entries although no NaN was seen (the caller repeats the search on the dot-matrix route).
+ * thr_out / thr_idx_out (NULL after the last epoch): the next epoch's thresholds (the k-th distance + the guard band).
  * nq * dim and np * dim below 2^28 per call (chunk larger searches).
  * max_blocks: the screen kernel is persistent (a block walks tiles); 0 = one block per CU, otherwise at most this many blocks
  * (rounded down to a multiple of 8), so that a search inside a stream pipeline leaves CUs to the other streams' kernels. */
@@ -293,8 +311,8 @@ int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, const float* q
                       int32_t dim, const float* thr, const int64_t* thr_idx, int64_t mask_lo, int64_t mask_hi, int64_t p_base,
                       int32_t* cand_count, void* cand, int32_t cap, uint32_t* cold_ws, int32_t* overflow_flag, int32_t max_blocks,
                       void* stream);
-int knnsvc_knn_refine(int32_t* cand_count, const void* cand, int32_t cap, int64_t nq, int32_t k, int64_t idx_offset,
-                      const uint32_t* row_bound, const int64_t* prev_idx, const float* prev_dist, int64_t* out_idx, float* out_dist, float* thr_out,
+int knnsvc_knn_refine(int32_t* cand_count, const void* cand, int32_t cap, int64_t nq, int32_t k,
+                      const uint32_t* row_bound, int32_t has_prev, void* wide, float* thr_out,
                       int64_t* thr_idx_out, int32_t final_pass, int32_t* flags, void* stream);
 
 /* Merge `parts` per-shard top-k lists ([parts][nq][k], e.g. after an RCCL all-gather) into one. */

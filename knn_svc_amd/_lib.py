@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -74,11 +74,12 @@ SIGNATURES = {
     "knnsvc_mask_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "knnsvc_row_norms": (i32, [vp, i64, i32, i32, vp, vp, vp, vp]),
     "knnsvc_knn_workspace_bytes": (sz, [i64, i64, i32]),
-    "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, i64, i64, vp, vp, vp, sz, vp, vp]),
-    "knnsvc_knn_select": (i32, [vp, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i64, vp, vp, vp, vp]),
+    "knnsvc_knn_topk": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i64, i64, i64, vp, vp, vp, sz, vp, i32, vp]),
+    "knnsvc_knn_rescore": (i32, [vp, i64, i32, vp, vp, vp, vp, vp, vp, i64, i32, i64, i64, i64, i32, vp, vp, vp]),
+    "knnsvc_knn_select": (i32, [vp, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, vp, vp, vp]),
     "knnsvc_knn_merge": (i32, [vp, vp, i32, i64, i32, vp, vp, vp]),
     "knnsvc_knn_screen": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, i64, i64, i64, vp, vp, i32, vp, vp, i32, vp]),
-    "knnsvc_knn_refine": (i32, [vp, vp, i32, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "knnsvc_knn_refine": (i32, [vp, vp, i32, i64, i32, vp, i32, vp, vp, vp, i32, vp, vp]),
     "knnsvc_log_f0_median": (i32, [vp, i64, vp, vp, vp]),
     "knnsvc_shift_f0": (i32, [vp, i64, vp, vp, vp, vp]),
     "knnsvc_reload_knobs": (i32, []),

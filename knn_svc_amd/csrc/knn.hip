@@ -8,6 +8,13 @@
 // row's sorted list (LDS) by a 64-lane bitonic sort.  Per-split lists are merged by a second
 // small kernel.  Keys are (order-preserving bits of the f32 distance) << 32 | pool index, so
 // ties resolve to the lower pool index on every device count.
+//
+// Round 5 — exact re-score.  Whatever produced the dot products (the f16x2 matrix-core loop: 96 fp32 roundings along K; the fp32
+// MFMA tile), they only PICK candidates now: every selection kernel keeps a WIDE list per row — up to 64 keys, one per lane: the
+// k best plus everything within KNN_GUARD of the k-th — and knn_rescore_kernel recomputes q.p for those rows in fp64, rounds ONCE
+// to fp32, replays ref_distance and sorts by (distance bits, index).  The order a caller sees is then that of the reference's
+// formula on correctly rounded dot products: it differs from the reference's own order only where the reference's BLAS
+// rounding (<= 6.8e-7 on fixture g3c) decides, and no longer where this path's (1.22e-6) did.
 #include <stdlib.h>
 #include "gemm_core.h"
 #include "gemm2_core.h"
@@ -61,6 +68,36 @@ __device__ __forceinline__ void list_insert(unsigned long long& mine, unsigned l
     if (lane >= k) mine = KEY_INF;
 }
 
+// ---- wide lists: 64 keys in ascending order, one per lane (unused lanes: KEY_INF).  The k-th key + KNN_GUARD bounds what a list
+// keeps; when more than 64 keys lie inside the guard band (thousands of identical pool rows) the 64 best by (distance, index) stay.
+constexpr int KW = 64;
+constexpr float KNN_GUARD = 4.0e-6f;      // > 3 x the largest |screening distance - exact distance| measured (1.22e-6, g3c): 2 x is the least that keeps every exact top-k member listed
+__device__ __forceinline__ unsigned long long guard_key(unsigned long long kth) {
+    if (kth == KEY_INF) return KEY_INF;
+    const float d = unsortable((unsigned)(kth >> 32)) + KNN_GUARD;
+    return ((unsigned long long)sortable(d) << 32) | 0xFFFFFFFFull;
+}
+__device__ __forceinline__ unsigned long long wide_thr(unsigned long long mine, int k) {       // a candidate can matter iff key <= this
+    const unsigned long long g = guard_key(readlane64(mine, k - 1)), w = readlane64(mine, KW - 1);
+    return g < w ? g : w;
+}
+// mine (ascending) U c (ascending) -> the 64 smallest, ascending: min(a_i, c_{63-i}) is bitonic and holds them; six
+// compare-exchange stages sort it
+__device__ __forceinline__ void wide_merge_sorted(unsigned long long& mine, unsigned long long c, int lane) {
+    const unsigned long long r = __shfl(c, 63 - lane, 64);
+    unsigned long long m = mine < r ? mine : r;
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const unsigned long long o = __shfl_xor(m, j, 64);
+        const unsigned long long mn = m < o ? m : o, mx = m < o ? o : m;
+        m = ((lane & j) == 0) ? mn : mx;
+    }
+    mine = m;
+}
+__device__ __forceinline__ void wide_merge(unsigned long long& mine, unsigned long long cand, int lane) {      // cand: any order
+    wide_merge_sorted(mine, wave_sort64(cand, lane), lane);
+}
+
 // the reference's operation sequence on top of dot = sum_k q_k p_k :
 //   cdist (mm route) : r = -2*dot + |q|^2 + |p|^2 ; cd = sqrt(max(r, 1e-30))
 //   fast_cosine_dist : 1 - (((-cd*cd + qn*qn) + pn*pn) / 2) / (qn*pn)
@@ -88,7 +125,7 @@ struct RowLoader {      // rows of a [rows][dim] row-major matrix, 16-byte vecto
 
 constexpr int LDD = 128;                                  // distance tile pitch
 constexpr int LDS_STAGE = G::LDS_FLOATS;                  // 18432 floats (>= 128*128)
-constexpr int KNN_LDS_BYTES = LDS_STAGE * 4 + 128 * KMAX * 8 /*lists*/ + 8 * 128 * 8 /*scratch*/ + 128 * 4 * 2;
+constexpr int KNN_LDS_BYTES = LDS_STAGE * 4 + 128 * KW * 8 /*wide lists*/ + 128 * 4 * 2;
 
 __global__ __launch_bounds__(512) void knn_tile_kernel(
     const float* __restrict__ q, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
@@ -96,9 +133,8 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
     int dim, int k, long rows_per_split, long mask_lo, long mask_hi, unsigned long long* __restrict__ part, int* nan_flag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dist = lds;                                                       // [128][LDD] (aliases staging)
-    unsigned long long* lists = (unsigned long long*)(lds + LDS_STAGE);      // [128][32]
-    unsigned long long* scratch = lists + 128 * KMAX;                        // [8 waves][128]
-    float* s_qn = (float*)(scratch + 8 * 128);
+    unsigned long long* lists = (unsigned long long*)(lds + LDS_STAGE);      // [128][KW]: wide lists
+    float* s_qn = (float*)(lists + 128 * KW);
     float* s_qsq = s_qn + 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,7 +142,7 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
     const long p_begin = (long)blockIdx.y * rows_per_split;
     const long p_end = p_begin + rows_per_split < np ? p_begin + rows_per_split : np;
 
-    for (int i = tid; i < 128 * KMAX; i += NT) lists[i] = KEY_INF;
+    for (int i = tid; i < 128 * KW; i += NT) lists[i] = KEY_INF;
     if (tid < 128) {
         const long r = q0 + tid;
         s_qn[tid] = r < nq ? qn[r] : 1.f;
@@ -148,43 +184,33 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
         }
         __syncthreads();
 
-        // selection: wave w owns query rows 16w .. 16w+15
-        unsigned long long* my_scratch = scratch + wave * 128;
+        // selection: wave w owns query rows 16w .. 16w+15; the row's wide list lives in LDS, one key per lane
         for (int rr = 0; rr < 16; ++rr) {
             const int row = wave * 16 + rr;
             if (q0 + row >= nq) break;
-            unsigned long long* lst = lists + row * KMAX;
-            unsigned long long thr = lst[k - 1];
+            unsigned long long* lst = lists + row * KW;
+            unsigned long long mine = lst[lane];
+            const unsigned long long thr = wide_thr(mine, k);
             const float d0 = dist[row * LDD + lane], d1 = dist[row * LDD + 64 + lane];
             // NaN / +inf never enter: their sortable bits are >= those of +inf
-            unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)(p0 + lane);
-            unsigned long long k1 = ((unsigned long long)sortable(d1) << 32) | (unsigned)(p0 + 64 + lane);
-            const bool f0 = (d0 < __builtin_inff()) && k0 < thr;
-            const bool f1 = (d1 < __builtin_inff()) && k1 < thr;
+            const unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)(p0 + lane);
+            const unsigned long long k1 = ((unsigned long long)sortable(d1) << 32) | (unsigned)(p0 + 64 + lane);
+            const bool f0 = (d0 < __builtin_inff()) && k0 <= thr;
+            const bool f1 = (d1 < __builtin_inff()) && k1 <= thr;
             const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
             if ((b0 | b1) == 0ull) continue;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const int c0 = __popcll(b0), total = c0 + __popcll(b1);
-            if (f0) my_scratch[__popcll(b0 & lt)] = k0;
-            if (f1) my_scratch[c0 + __popcll(b1 & lt)] = k1;
-            __builtin_amdgcn_wave_barrier();
-            for (int base = 0; base < total; base += 32) {
-                unsigned long long v;
-                if (lane < 32) v = lane < k ? lst[lane] : KEY_INF;
-                else v = (base + lane - 32) < total ? my_scratch[base + lane - 32] : KEY_INF;
-                v = wave_sort64(v, lane);
-                if (lane < k) lst[lane] = v;
-                __builtin_amdgcn_wave_barrier();
-            }
+            if (b0) wide_merge(mine, f0 ? k0 : KEY_INF, lane);
+            if (b1) wide_merge(mine, f1 ? k1 : KEY_INF, lane);
+            lst[lane] = mine;
         }
         __syncthreads();      // dist tile is about to be overwritten by the next tile's staging
     }
     if (saw_nan) atomicOr(nan_flag, 1);
 
-    // per-split lists -> workspace  part[split][q][k]
-    for (int i = tid; i < 128 * k; i += NT) {
-        const int row = i / k, e = i - row * k;
-        if (q0 + row < nq) part[((long)blockIdx.y * nq + q0 + row) * k + e] = lists[row * KMAX + e];
+    // per-split wide lists -> workspace  part[split][q][KW]
+    for (int i = tid; i < 128 * KW; i += NT) {
+        const int row = i / KW, e = i - row * KW;
+        if (q0 + row < nq) part[((long)blockIdx.y * nq + q0 + row) * KW + e] = lists[row * KW + e];
     }
 }
 
@@ -195,20 +221,18 @@ __global__ __launch_bounds__(512) void knn_tile_kernel(
 template <bool SCREEN>
 __global__ __launch_bounds__(256) void knn_select_kernel(
     const float* __restrict__ dots, long ld, const float* __restrict__ qn, const float* __restrict__ qsq, long nq,
-    const float* __restrict__ pn, const float* __restrict__ psq, long np, int k, long idx_offset,
-    long mask_lo, long mask_hi, long* __restrict__ out_idx, float* __restrict__ out_dist, int* nan_flag) {
-    __shared__ unsigned long long lists[4][KMAX];
-    __shared__ unsigned long long scratch[4][128];
+    const float* __restrict__ pn, const float* __restrict__ psq, long np, int k,
+    long mask_lo, long mask_hi, unsigned long long* __restrict__ wide_out, int* nan_flag) {
+    __shared__ unsigned long long lists[4][KW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row = blockIdx.x;
     const float* drow = dots + row * ld;
     const float v_qn = qn[row], v_qsq = qsq[row];
-    unsigned long long* my_scratch = scratch[wave];
-    // the wave's sorted top-k lives in registers, one key per lane (lanes >= k: KEY_INF).  After the first tiles a
-    // surviving candidate is rare and single: it is inserted with list_insert; only bursts (the warm-up, when everything
-    // beats an empty list) go through the scratch buffer and the 64-lane bitonic merge.
+    // the wave's WIDE list lives in registers, one key per lane: the k best so far and everything within KNN_GUARD of the k-th
+    // (wide_thr).  After the first tiles a surviving candidate is rare and single: it is inserted with list_insert; bursts (the
+    // warm-up, when everything beats an empty list) go through wide_merge (one 64-lane sort + six merge stages per 64 columns).
     unsigned long long mine = KEY_INF, thr = KEY_INF;
-    bool saw_nan = false, has_thr = false;      // has_thr: the list holds k real entries, thr_d is its largest distance
+    bool saw_nan = false, has_thr = false;      // has_thr: the list holds k real entries, thr_d bounds what can still matter
     float thr_d = 0.f;
     const float v_rq = __builtin_amdgcn_rcpf(v_qn);
 #ifndef KN_SELECT_U
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
             if (base >= np) break;
             const long p0 = base + lane, p1 = base + 64 + lane;
             // Screen: the reference formula costs a correctly rounded sqrt and two divisions per element, and almost no
-            // element can beat the current k-th distance.  approx = 1 - dot / (|q||p|) in three instructions; the formula's
+            // element can beat the current threshold.  approx = 1 - dot / (|q||p|) in three instructions; the formula's
             // own rounding (r = -2 dot + |q|^2 + |p|^2 cancels to ~2 dot) keeps |reference - exact| below
             // ~3 eps (|q|/|p| + |p|/|q| + 2), the approximation adds a few eps: a margin of 64 eps (1 + ratio) is > 10x that.
             // Any NaN / inf in the inputs turns approx or the margin into NaN, and a NaN comparison sends the sub-chunk
@@ -252,76 +276,148 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
             // NaN / +inf never enter: their sortable bits are >= those of +inf
             const unsigned long long k0 = ((unsigned long long)sortable(d0) << 32) | (unsigned)p0;
             const unsigned long long k1 = ((unsigned long long)sortable(d1) << 32) | (unsigned)p1;
-            const bool f0 = (d0 < __builtin_inff()) && k0 < thr;
-            const bool f1 = (d1 < __builtin_inff()) && k1 < thr;
+            const bool f0 = (d0 < __builtin_inff()) && k0 <= thr;
+            const bool f1 = (d1 < __builtin_inff()) && k1 <= thr;
             unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
             if ((b0 | b1) == 0ull) continue;
-            const int c0 = __popcll(b0), total = c0 + __popcll(b1);
+            const int total = __popcll(b0) + __popcll(b1);
             if (total <= 8) {
                 while (b0) {
                     const int l = __builtin_ctzll(b0); b0 &= b0 - 1;
                     const unsigned long long key = readlane64(k0, l);
-                    if (key < thr) { list_insert(mine, key, lane, k); thr = readlane64(mine, k - 1); }
+                    if (key <= thr) { list_insert(mine, key, lane, KW); thr = wide_thr(mine, k); }
                 }
                 while (b1) {
                     const int l = __builtin_ctzll(b1); b1 &= b1 - 1;
                     const unsigned long long key = readlane64(k1, l);
-                    if (key < thr) { list_insert(mine, key, lane, k); thr = readlane64(mine, k - 1); }
+                    if (key <= thr) { list_insert(mine, key, lane, KW); thr = wide_thr(mine, k); }
                 }
             } else {
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                if (f0) my_scratch[__popcll(b0 & lt)] = k0;
-                if (f1) my_scratch[c0 + __popcll(b1 & lt)] = k1;
-                __builtin_amdgcn_wave_barrier();
-                for (int b = 0; b < total; b += 32) {
-                    unsigned long long v = mine;                       // lanes < 32: the list (KEY_INF beyond k)
-                    if (lane >= 32) v = (b + lane - 32) < total ? my_scratch[b + lane - 32] : KEY_INF;
-                    v = wave_sort64(v, lane);
-                    mine = lane < k ? v : KEY_INF;
-                }
-                __builtin_amdgcn_wave_barrier();
-                thr = readlane64(mine, k - 1);
+                if (b0) wide_merge(mine, f0 ? k0 : KEY_INF, lane);
+                if (b1) wide_merge(mine, f1 ? k1 : KEY_INF, lane);
+                thr = wide_thr(mine, k);
             }
             has_thr = thr != KEY_INF;
             thr_d = unsortable((unsigned)(thr >> 32));
         }
     }
     if (saw_nan) atomicOr(nan_flag, 1);
-    if (lane < KMAX) lists[wave][lane] = mine;
+    lists[wave][lane] = mine;
     __syncthreads();
     if (wave == 0) {
-        unsigned long long best = lane < k ? lists[0][lane] : KEY_INF;
-        for (int s = 1; s < 4; ++s) {
-            unsigned long long v = best;
-            if (lane >= 32) v = (lane - 32) < k ? lists[s][lane - 32] : KEY_INF;
-            else if (lane >= k) v = KEY_INF;
-            best = wave_sort64(v, lane);
+        unsigned long long best = lists[0][lane];
+#pragma unroll
+        for (int s = 1; s < 4; ++s) wide_merge_sorted(best, lists[s][lane], lane);
+        if (best > wide_thr(best, k)) best = KEY_INF;           // beyond the guard band of the final k-th: cannot matter
+        wide_out[row * KW + lane] = best;
+    }
+}
+
+// one wave per query row: fold `parts` wide lists into one
+__global__ __launch_bounds__(256) void knn_merge_keys_kernel(const unsigned long long* __restrict__ part,
+                                                            int parts, long nq, int k, unsigned long long* __restrict__ wide_out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    unsigned long long best = part[row * KW + lane];
+    for (int s = 1; s < parts; ++s) wide_merge_sorted(best, part[((long)s * nq + row) * KW + lane], lane);
+    if (best > wide_thr(best, k)) best = KEY_INF;
+    wide_out[row * KW + lane] = best;
+}
+
+// Exact re-score (round 5): one workgroup per query row, its wide list in -> ascending top-k out.  For every listed pool row the
+// dot product is recomputed in fp64 from the fp32 operands (products exact, sums at 2^-53: the correctly rounded fp32 dot up
+// to double-rounding ties), rounded once to fp32 and put through ref_distance: the distance the reference's formula gives on an
+// exact matrix product.  Keys (distance bits, index) are re-sorted; ties keep the lower index.  exact = 0 (KNNSVC_KNN_RESCORE=0,
+// A/B aid) passes the screening distances through.  The pass is a gather of ~33 rows of 4 KB per query row (200 MB at the
+// north-star point): eight waves share the row's entries, four entries per wave in flight (DIM = 1024: every load of a
+// group is issued before the first is used).
+constexpr int RS_WAVES = 8, RS_FLIGHT = 4;
+template <int DIM>
+__global__ __launch_bounds__(RS_WAVES * 64) void knn_rescore_kernel(const unsigned long long* __restrict__ wide, long nq, int k,
+                                                         const float* __restrict__ q, const float* __restrict__ qn,
+                                                         const float* __restrict__ qsq, const float* __restrict__ pool,
+                                                         const float* __restrict__ pn, const float* __restrict__ psq, int dim_rt,
+                                                         long idx_offset, long mask_lo, long mask_hi, int exact,
+                                                         long* __restrict__ out_idx, float* __restrict__ out_dist) {
+    __shared__ unsigned long long s_keys[KW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dim = DIM ? DIM : dim_rt;
+    // workgroup b runs on XCD b % 8: each XCD takes one contiguous eighth of the query rows, so the rows in flight on one L2 are
+    // neighbours in time — on real (temporally smooth) features they list mostly the same pool rows
+    const long rpx = (nq + 7) / 8;
+    const long row = (long)(blockIdx.x & 7) * rpx + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= rpx || row >= nq) return;
+    const unsigned long long key = wide[row * KW + lane];
+    const int n = __popcll(__ballot(key != KEY_INF));            // a sorted list: its entries are the first n lanes
+    if (exact) {
+        const float* qr = q + row * (long)dim;
+        const float v_qn = qn[row], v_qsq = qsq[row];
+        const int idx = (int)(unsigned)(key & 0xFFFFFFFFull);
+        for (int e0 = wave; e0 < n; e0 += RS_WAVES * RS_FLIGHT) {
+            long pp[RS_FLIGHT];
+            const float* rp[RS_FLIGHT];
+            double acc[RS_FLIGHT][4];
+#pragma unroll
+            for (int f = 0; f < RS_FLIGHT; ++f) {
+                const int e = e0 + f * RS_WAVES;
+                pp[f] = (long)(unsigned)__builtin_amdgcn_readlane(idx, e < n ? e : e0);      // (past the list: the group's first row again)
+                rp[f] = pool + pp[f] * dim;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[f][t] = 0.0;
+            }
+#pragma unroll
+            for (int c0 = 0; c0 < (DIM ? DIM : 1 << 30); c0 += 256) {
+                const int c = c0 + lane * 4;
+                if (!DIM && c0 >= dim) break;
+                const bool in = DIM ? true : c < dim;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 vq = in ? *(const f32x4*)(qr + c) : z;
+                f32x4 vp[RS_FLIGHT];
+#pragma unroll
+                for (int f = 0; f < RS_FLIGHT; ++f) vp[f] = in ? *(const f32x4*)(rp[f] + c) : z;
+#pragma unroll
+                for (int f = 0; f < RS_FLIGHT; ++f)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[f][t] = fma((double)vq[t], (double)vp[f][t], acc[f][t]);
+            }
+            double dots[RS_FLIGHT];
+#pragma unroll
+            for (int f = 0; f < RS_FLIGHT; ++f) dots[f] = wave_sum_d((acc[f][0] + acc[f][1]) + (acc[f][2] + acc[f][3]));
+#pragma unroll
+            for (int f = 0; f < RS_FLIGHT; ++f) {
+                const int e = e0 + f * RS_WAVES;
+                if (e >= n) break;                                       // (wave-uniform)
+                const unsigned long long old = readlane64(key, e);
+                if (lane == f) {
+                    float d = ref_distance((float)dots[f], v_qsq, psq[pp[f]], v_qn, pn[pp[f]]);
+                    if (pp[f] >= mask_lo && pp[f] < mask_hi) d = 1.f;
+                    // (a listed pair has a finite screening distance; should the exact one not be finite — it cannot, from the same
+                    //  finite operands — the pair keeps its screening key)
+                    s_keys[e] = d < __builtin_inff() ? (((unsigned long long)sortable(d) << 32) | (unsigned)pp[f]) : old;
+                }
+            }
         }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        unsigned long long best = key;
+        if (exact) best = wave_sort64(lane < n ? s_keys[lane] : KEY_INF, lane);
         if (lane < k) {
             out_idx[row * k + lane] = (best == KEY_INF ? 0l : (long)(unsigned)(best & 0xFFFFFFFFull)) + idx_offset;      // unfilled (NaN row): a valid row, NaN distance
             out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
         }
     }
 }
-
-// one wave per query row: fold `parts` sorted key lists into one
-__global__ __launch_bounds__(256) void knn_merge_keys_kernel(const unsigned long long* __restrict__ part,
-                                                            int parts, long nq, int k, long idx_offset,
-                                                            long* __restrict__ out_idx, float* __restrict__ out_dist) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nq) return;
-    unsigned long long best = lane < k ? part[row * k + lane] : KEY_INF;
-    for (int s = 1; s < parts; ++s) {
-        unsigned long long v = best;
-        if (lane >= 32) v = (lane - 32) < k ? part[((long)s * nq + row) * k + lane - 32] : KEY_INF;
-        else if (lane >= k) v = KEY_INF;
-        best = wave_sort64(v, lane);
-    }
-    if (lane < k) {
-        out_idx[row * k + lane] = (best == KEY_INF ? 0l : (long)(unsigned)(best & 0xFFFFFFFFull)) + idx_offset;      // unfilled (NaN row): a valid row, NaN distance
-        out_dist[row * k + lane] = unsortable((unsigned)(best >> 32));
-    }
+static void launch_rescore(const unsigned long long* wide, long nq, int k, const float* q, const float* qn, const float* qsq, const float* pool,
+                           const float* pn, const float* psq, int dim, long idx_offset, long mask_lo, long mask_hi, int exact, long* out_idx,
+                           float* out_dist, hipStream_t st) {
+    if (dim == 1024)
+        hipLaunchKernelGGL(knn_rescore_kernel<1024>, dim3((unsigned)(8 * ((nq + 7) / 8))), dim3(RS_WAVES * 64), 0, st, wide, nq, k, q, qn, qsq, pool, pn, psq, dim,
+                           idx_offset, mask_lo, mask_hi, exact, out_idx, out_dist);
+    else
+        hipLaunchKernelGGL(knn_rescore_kernel<0>, dim3((unsigned)(8 * ((nq + 7) / 8))), dim3(RS_WAVES * 64), 0, st, wide, nq, k, q, qn, qsq, pool, pn, psq, dim,
+                           idx_offset, mask_lo, mask_hi, exact, out_idx, out_dist);
 }
 
 // merge of (dist, global idx) lists coming from other devices
@@ -697,6 +793,7 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
 #ifndef KN_KNN_PROF_LOADS
             KN_KP_T(6)
 #endif
+            tb += KNN_GUARD;                 // the wide lists keep everything within the guard band of the k-th (exact re-score)
             set_row(tb, 0xFFFFFFFFu);
             // the best bound found for the row (stored inverted: atomicMax over a zero-filled word): the refine pass starts from it
             // and drops the survivors of tiles that had to work with weaker bounds unseen
@@ -851,36 +948,28 @@ __global__ __launch_bounds__(256, 1) void knn_screen_kernel(
   }
 }
 
-// One wave per query row: the row's list so far (an earlier epoch's output) + the new candidates -> ascending top-k, same keys /
-// order as knn_select_kernel; the k-th key goes out as the next epoch's threshold and the row's candidate count is reset.  A
-// candidate is (pool index, distance bits): the screen evaluated the reference's formula; 0xFFFFFFFF marks a NaN distance.
-// Candidates are filtered against the list's current k-th key 256 at a time; a survivor is rare once the list is warm and is
-// inserted by ballot + lane shift, bursts go through the bitonic merge (round 3 merged every 32 candidates: 2 ms at cfg-5 size).
+// One wave per query row: the row's WIDE list so far (an earlier epoch's output) + the new candidates -> wide list (the k best and
+// everything within KNN_GUARD of the k-th, ascending, same keys as knn_select_kernel); the list's threshold key (wide_thr) goes
+// out as the next epoch's threshold and the row's candidate count is reset.  A candidate is (pool index, distance bits): the
+// screen evaluated the reference's formula; 0xFFFFFFFF marks a NaN distance.  Candidates are filtered against the threshold 256
+// at a time; a survivor is rare once the list is warm and is inserted by ballot + lane shift, bursts go through wide_merge.
 __global__ __launch_bounds__(256) void knn_refine_kernel(int* __restrict__ cand_count, const unsigned* __restrict__ cand, int cap, long nq,
-                                                        int k, long idx_offset, const unsigned* __restrict__ row_bound,
-                                                        const long* __restrict__ prev_idx,
-                                                        const float* __restrict__ prev_dist, long* __restrict__ out_idx,
-                                                        float* __restrict__ out_dist, float* __restrict__ thr_out,
+                                                        int k, const unsigned* __restrict__ row_bound, int has_prev,
+                                                        unsigned long long* __restrict__ wide, float* __restrict__ thr_out,
                                                         long* __restrict__ thr_idx_out, int final_pass, int* flags) {
-    __shared__ unsigned long long scratch[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wave;
     if (row >= nq) return;
     int cnt = cand_count[row];
     cnt = cnt < cap ? cnt : cap;
     const unsigned long long* cr = (const unsigned long long*)(cand + row * (long)cap * 2);      // little endian: index | bits << 32
-    unsigned long long* my_scratch = scratch[wave];
-    unsigned long long mine = KEY_INF;                                  // lanes < k: the sorted list
+    unsigned long long mine = has_prev ? wide[row * KW + lane] : KEY_INF;      // (sorted, its unused tail is KEY_INF)
     bool saw_nan = false;
-    if (prev_idx && lane < k) {
-        const float d = prev_dist[row * k + lane];
-        if (d < __builtin_inff()) mine = ((unsigned long long)sortable(d) << 32) | (unsigned)(prev_idx[row * k + lane] - idx_offset);
-    }
-    // (a list handed over by an earlier epoch is sorted and its unused tail is KEY_INF: already in list form)
-    // first epoch: the row's k-th best cannot lie beyond the best bound a tile derived for it (ties at the bound pass: index = max)
+    // first epoch: nothing that matters lies beyond the best bound a tile derived for the row (guard band included; ties at the
+    // bound pass: index = max)
     unsigned long long bound_key = KEY_INF;
     if (row_bound) { const unsigned b = ~row_bound[row]; if (b != 0xFFFFFFFFu) bound_key = ((unsigned long long)b << 32) | 0xFFFFFFFFull; }
-#define KN_THR() ({ const unsigned long long t_ = readlane64(mine, k - 1); t_ < bound_key ? t_ : bound_key; })
+#define KN_THR() ({ const unsigned long long t_ = wide_thr(mine, k); t_ < bound_key ? t_ : bound_key; })
     unsigned long long thr = KN_THR();
     constexpr unsigned INF_BITS = 0xFF800000u;                          // sortable(+inf): NaN / +inf never enter
     for (int base = 0; base < cnt; base += 256) {
@@ -899,51 +988,39 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(int* __restrict__ cand_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (base + u * 64 >= cnt) break;
-            const bool f = kv[u] <= thr && kv[u] != KEY_INF;           // (<=: the bound key itself is no list entry; list keys are unique)
+            const bool f = kv[u] <= thr && kv[u] != KEY_INF;
             unsigned long long b = __ballot(f);
             if (b == 0ull) continue;
-            const int total = __popcll(b);
-            if (total <= 8) {
+            if (__popcll(b) <= 8) {
                 while (b) {
                     const int l = __builtin_ctzll(b); b &= b - 1;
                     const unsigned long long key = readlane64(kv[u], l);
-                    if (key <= thr) { list_insert(mine, key, lane, k); thr = KN_THR(); }
+                    if (key <= thr) { list_insert(mine, key, lane, KW); thr = KN_THR(); }
                 }
             } else {
-                if (f) my_scratch[__popcll(b & ((1ull << lane) - 1ull))] = kv[u];
-                __builtin_amdgcn_wave_barrier();
-                for (int s0 = 0; s0 < total; s0 += 32) {
-                    unsigned long long v = mine;                       // lanes < 32: the list (KEY_INF beyond k)
-                    if (lane >= 32) v = (s0 + lane - 32) < total ? my_scratch[s0 + lane - 32] : KEY_INF;
-                    v = wave_sort64(v, lane);
-                    mine = lane < k ? v : KEY_INF;
-                }
-                __builtin_amdgcn_wave_barrier();
+                wide_merge(mine, f ? kv[u] : KEY_INF, lane);
                 thr = KN_THR();
             }
         }
     }
 #undef KN_THR
-    thr = readlane64(mine, k - 1);
+    thr = wide_thr(mine, k);
+    if (mine > thr) mine = KEY_INF;                                     // beyond the guard band of the k-th: cannot matter any more
     const bool nan_row = __ballot(saw_nan) != 0ull;
+    const bool is_short = readlane64(mine, k - 1) == KEY_INF;
     if (lane == 0) {
         cand_count[row] = 0;                                            // the next epoch starts an empty list
         int fl = nan_row ? 1 : 0;
         // fewer than k entries at the end without a NaN in sight: the candidate set was NOT a superset of the top-k — cannot happen
         // by construction; if it ever does, the caller repeats the search on the dot-matrix route instead of using a short list
-        if (final_pass && thr == KEY_INF && !nan_row) fl |= 2;
+        if (final_pass && is_short && !nan_row) fl |= 2;
         if (fl) atomicOr(flags, fl);
         if (thr_out) {
             thr_out[row] = thr == KEY_INF ? __builtin_inff() : unsortable((unsigned)(thr >> 32));
             thr_idx_out[row] = (long)(unsigned)(thr & 0xFFFFFFFFull);
         }
     }
-    if (lane < k) {
-        // (an unfilled place — a NaN row — is a VALID row index with a NaN distance, as knn_select_kernel leaves it: the flag is read
-        //  by the host only after the later stages have been enqueued, and those gather pool rows through these indices)
-        out_idx[row * k + lane] = (mine == KEY_INF ? 0l : (long)(unsigned)(mine & 0xFFFFFFFFull)) + idx_offset;
-        out_dist[row * k + lane] = unsortable((unsigned)(mine >> 32));
-    }
+    wide[row * KW + lane] = mine;
 }
 
 #ifdef KN_KNN_PROF
@@ -979,14 +1056,14 @@ extern "C" int knnsvc_row_norms(const float* x, int64_t rows, int32_t dim, int32
 
 extern "C" size_t knnsvc_knn_workspace_bytes(int64_t nq, int64_t np, int32_t k) {
     if (nq <= 0 || np <= 0 || k <= 0) return 0;
-    return (size_t)split_count(nq, np) * (size_t)nq * (size_t)k * 8;
+    return ((size_t)split_count(nq, np) + 1) * (size_t)nq * (size_t)KW * 8;       // per-split wide lists + the merged one
 }
 
 extern "C" int knnsvc_knn_topk(const float* q, const float* q_norm, const float* q_sq, int64_t nq,
                                const float* pool, const float* p_norm, const float* p_sq, int64_t np,
                                int32_t dim, int32_t k, int64_t idx_offset, int64_t mask_lo, int64_t mask_hi,
                                int64_t* out_idx, float* out_dist,
-                               void* workspace, size_t workspace_bytes, int32_t* nan_flag, void* stream) {
+                               void* workspace, size_t workspace_bytes, int32_t* nan_flag, int32_t rescore, void* stream) {
     KN_REQUIRE(q && q_norm && q_sq && pool && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_topk: null pointer");
     KN_REQUIRE(nq > 0 && np > 0, "knn_topk: empty query or pool");
     KN_REQUIRE(k >= 1 && k <= KMAX, "knn_topk: k must be in 1..32");
@@ -995,7 +1072,7 @@ extern "C" int knnsvc_knn_topk(const float* q, const float* q_norm, const float*
     KN_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)pool & 15) == 0, "knn_topk: q/pool must be 16-byte aligned");
     KN_REQUIRE(np < (1ll << 32), "knn_topk: pool rows must fit 32 bits");
     const int S = split_count(nq, np);
-    const size_t need = (size_t)S * nq * k * 8;
+    const size_t need = ((size_t)S + 1) * nq * KW * 8;
     if (workspace_bytes < need || !workspace)
         return knnsvc_fail(KNNSVC_EWORKSPACE, "knn_topk: workspace %zu < %zu bytes", workspace_bytes, need);
     static bool attr = false;
@@ -1013,9 +1090,29 @@ extern "C" int knnsvc_knn_topk(const float* q, const float* q_norm, const float*
                        p_sq, (long)np, dim, k, rows_per_split, (long)mask_lo, (long)mask_hi, (unsigned long long*)workspace, nan_flag);
     int rc = knnsvc_check_launch("knn_tile");
     if (rc) return rc;
+    unsigned long long* wide = (unsigned long long*)workspace + (size_t)S * nq * KW;
     hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, st,
-                       (const unsigned long long*)workspace, S, (long)nq, k, (long)idx_offset, (long*)out_idx, out_dist);
-    return knnsvc_check_launch("knn_merge_keys");
+                       (const unsigned long long*)workspace, S, (long)nq, k, wide);
+    rc = knnsvc_check_launch("knn_merge_keys");
+    if (rc) return rc;
+    launch_rescore((const unsigned long long*)wide, (long)nq, k, q, q_norm, q_sq, pool, p_norm, p_sq, dim, (long)idx_offset, (long)mask_lo,
+                   (long)mask_hi, rescore ? 1 : 0, (long*)out_idx, out_dist, st);
+    return knnsvc_check_launch("knn_rescore");
+}
+
+extern "C" int knnsvc_knn_rescore(const void* wide, int64_t nq, int32_t k, const float* q, const float* q_norm, const float* q_sq,
+                                  const float* pool, const float* p_norm, const float* p_sq, int64_t np, int32_t dim,
+                                  int64_t idx_offset, int64_t mask_lo, int64_t mask_hi, int32_t exact,
+                                  int64_t* out_idx, float* out_dist, void* stream) {
+    KN_REQUIRE(wide && out_idx && out_dist, "knn_rescore: null pointer");
+    KN_REQUIRE(nq > 0 && nq <= 0x7FFFFFFFll && k >= 1 && k <= KMAX, "knn_rescore: bad sizes");
+    if (exact) {
+        KN_REQUIRE(q && q_norm && q_sq && pool && p_norm && p_sq && np > 0, "knn_rescore: the exact pass needs the fp32 operands and their norms");
+        KN_REQUIRE(dim > 0 && dim % 4 == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)pool & 15) == 0, "knn_rescore: dim % 4 == 0 and 16-byte aligned rows");
+    }
+    launch_rescore((const unsigned long long*)wide, (long)nq, k, q, q_norm, q_sq, pool, p_norm, p_sq, dim, (long)idx_offset, (long)mask_lo,
+                   (long)mask_hi, exact ? 1 : 0, (long*)out_idx, out_dist, (hipStream_t)stream);
+    return knnsvc_check_launch("knn_rescore");
 }
 
 extern "C" int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx, int32_t parts, int64_t nq, int32_t k,
@@ -1028,10 +1125,10 @@ extern "C" int knnsvc_knn_merge(const float* part_dist, const int64_t* part_idx,
 }
 
 extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_norm, const float* q_sq, int64_t nq,
-                                 const float* p_norm, const float* p_sq, int64_t np, int32_t k, int64_t idx_offset,
+                                 const float* p_norm, const float* p_sq, int64_t np, int32_t k,
                                  int64_t mask_lo, int64_t mask_hi,
-                                 int64_t* out_idx, float* out_dist, int32_t* nan_flag, void* stream) {
-    KN_REQUIRE(dots && q_norm && q_sq && p_norm && p_sq && out_idx && out_dist && nan_flag, "knn_select: null pointer");
+                                 void* wide_out, int32_t* nan_flag, void* stream) {
+    KN_REQUIRE(dots && q_norm && q_sq && p_norm && p_sq && wide_out && nan_flag, "knn_select: null pointer");
     KN_REQUIRE(nq > 0 && np > 0 && ld >= np, "knn_select: empty query or pool, or ld < np");
     KN_REQUIRE(k >= 1 && k <= KMAX, "knn_select: k must be in 1..32");
     KN_REQUIRE(np >= k, "knn_select: pool smaller than k (the reference's topk would raise)");
@@ -1040,10 +1137,10 @@ extern "C" int knnsvc_knn_select(const float* dots, int64_t ld, const float* q_n
     const char* e = getenv("KNNSVC_KNN_SCREEN");
     if (e && e[0] == '0')
         hipLaunchKernelGGL(knn_select_kernel<false>, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
-                           (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi, (long*)out_idx, out_dist, nan_flag);
+                           (long)nq, p_norm, p_sq, (long)np, k, (long)mask_lo, (long)mask_hi, (unsigned long long*)wide_out, nan_flag);
     else
         hipLaunchKernelGGL(knn_select_kernel<true>, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dots, (long)ld, q_norm, q_sq,
-                           (long)nq, p_norm, p_sq, (long)np, k, (long)idx_offset, (long)mask_lo, (long)mask_hi, (long*)out_idx, out_dist, nan_flag);
+                           (long)nq, p_norm, p_sq, (long)np, k, (long)mask_lo, (long)mask_hi, (unsigned long long*)wide_out, nan_flag);
     return knnsvc_check_launch("knn_select");
 }
 
@@ -1081,7 +1178,10 @@ extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, con
     if (blocks >= 8) blocks = blocks / 8 * 8;          // a multiple of 8: with the padded (XCD-aware) tile order a block's tiles keep their XCD
     if (blocks > ntiles) blocks = ntiles;
     const long gy = cdiv64(np, 256);
-    const bool xch = !thr && cold_ws && 2 * gy >= 40 && 2 * gy <= XCH_MAX;      // the exchange pays from ~20 column tiles on (>= 32 bounds needed)
+    // the exchange pays from ~20 column tiles on (>= 32 bounds needed) — and only when every tile of the epoch is resident at once: under
+    // a grid cap (max_blocks: the lanes of the stream pipeline) the tiles of a row tile run one after another in the same block, and
+    // thread 0 would spin its full 8 us per tile for arrivals that cannot come
+    const bool xch = !thr && cold_ws && 2 * gy >= 40 && 2 * gy <= XCH_MAX && blocks >= cdiv64(nq, 256) * gy;
 #define KN_LAUNCH(COLD_, XCH_)                                                                                                       \
     hipLaunchKernelGGL((knn_screen_kernel<COLD_, XCH_>), dim3((unsigned)blocks), dim3(256), QG::LDS_BYTES, (hipStream_t)stream,       \
                        (const float*)q_f16x2, q_absmax, q_norm, q_sq, (long)nq, (const unsigned short*)p_f16x2, p_absmax, p_norm, p_sq, \
@@ -1094,14 +1194,14 @@ extern "C" int knnsvc_knn_screen(const void* q_f16x2, const float* q_absmax, con
     return knnsvc_check_launch("knn_screen");
 }
 
-extern "C" int knnsvc_knn_refine(int32_t* cand_count, const void* cand, int32_t cap, int64_t nq, int32_t k, int64_t idx_offset,
-                                 const uint32_t* row_bound, const int64_t* prev_idx, const float* prev_dist, int64_t* out_idx, float* out_dist, float* thr_out,
+extern "C" int knnsvc_knn_refine(int32_t* cand_count, const void* cand, int32_t cap, int64_t nq, int32_t k,
+                                 const uint32_t* row_bound, int32_t has_prev, void* wide, float* thr_out,
                                  int64_t* thr_idx_out, int32_t final_pass, int32_t* flags, void* stream) {
-    KN_REQUIRE(cand_count && cand && out_idx && out_dist && flags, "knn_refine: null pointer");
-    KN_REQUIRE((prev_idx == nullptr) == (prev_dist == nullptr) && (thr_out == nullptr) == (thr_idx_out == nullptr), "knn_refine: pointer pairs come together");
+    KN_REQUIRE(cand_count && cand && wide && flags, "knn_refine: null pointer");
+    KN_REQUIRE((thr_out == nullptr) == (thr_idx_out == nullptr), "knn_refine: pointer pairs come together");
     KN_REQUIRE(nq > 0 && cap > 0 && k >= 1 && k <= KMAX, "knn_refine: bad sizes");
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, (hipStream_t)stream, cand_count,
-                       (const unsigned*)cand, cap, (long)nq, k, (long)idx_offset, (const unsigned*)row_bound, (const long*)prev_idx, prev_dist, (long*)out_idx, out_dist,
+                       (const unsigned*)cand, cap, (long)nq, k, (const unsigned*)row_bound, has_prev ? 1 : 0, (unsigned long long*)wide,
                        thr_out, (long*)thr_idx_out, final_pass, flags);
     return knnsvc_check_launch("knn_refine");
 }

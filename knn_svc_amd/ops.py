@@ -450,6 +450,23 @@ def prepare_knn_pool(pool, k=32, p_stats=None):
     return chunks
 
 
+def knn_rescore_on() -> bool:
+    """KNNSVC_KNN_RESCORE=0 (A/B aid): the lists keep the order of the screening distances (round 4's behaviour) instead of
+    being re-scored from exact dot products (knnsvc_knn_rescore)."""
+    import os
+    return os.environ.get("KNNSVC_KNN_RESCORE", "1") != "0"
+
+
+KNN_WIDE = 64                     # keys per row of a wide list (include/knnsvc_hip.h, knnsvc_knn_rescore)
+
+
+def _knn_rescore(wide, q, qn, qs, pc, pn, ps, k, idx_offset, mask, idx_out, dist_out):
+    """wide [m, 64] int64 keys -> exact top-k (idx_out / dist_out [m, k])."""
+    m, dim = q.shape
+    check(_lib.load().knnsvc_knn_rescore(_p(wide), m, k, _p(q), _p(qn), _p(qs), _p(pc), _p(pn), _p(ps), pc.shape[0], dim, idx_offset,
+                                         mask[0], mask[1], 1 if knn_rescore_on() else 0, _p(idx_out), _p(dist_out), _stream()), "knn_rescore")
+
+
 def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None, allow_fused=True, max_blocks=0):
     """q.p^T on the f16x2 matrix-core loop (Gemm2QuadS), then the reference's distance formula + selection.  Two routes over
     the SAME dot-product bits (both sum over K in the 16x16x32 grouping, whatever the sizes):
@@ -491,9 +508,11 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
                 dots = torch.empty(m, npad, device=dev, dtype=torch.float32)
                 conv_gemm(qc, pc, dots, m=m, n=npad, cin=dim, w2=p2, x_split=True, x_absmax=q_slot, w_absmax=p_slot,
                           fixed_tile=2)         # a shard / a query set of any size gives the whole search's distance bits
+                wide = torch.empty(m, KNN_WIDE, device=dev, dtype=torch.int64)
                 check(lib.knnsvc_knn_select(_p(dots), npad, _p(qn[q0:]), _p(qs[q0:]), m, _p(pn[p0:]), _p(ps[p0:]), npc, k,
-                                            idx_offset + p0, mask[0] - p0, mask[1] - p0, _p(idx[q0:]), _p(dist[q0:]), _p(flag),
-                                            _stream()), "knn_select")
+                                            mask[0] - p0, mask[1] - p0, _p(wide), _p(flag), _stream()), "knn_select")
+                _knn_rescore(wide, q[q0:q0 + m], qn[q0:], qs[q0:], pc, pn[p0:], ps[p0:], k, idx_offset + p0,
+                             (mask[0] - p0, mask[1] - p0), idx[q0:], dist[q0:])
         parts_i.append(idx); parts_d.append(dist)
     if len(parts_i) == 1:
         return parts_i[0], parts_d[0]
@@ -568,6 +587,7 @@ def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offse
         zeroed = torch.zeros(m * (2 + 2 * gy0) + 32 * -(-m // 256), device=dev, dtype=torch.int32)
         cnt, bound = zeroed[:m], zeroed[m:]
         cand = torch.empty(m * KNN_FUSED_CAP * 2, device=dev, dtype=torch.int32)
+        wide = torch.empty(m, KNN_WIDE, device=dev, dtype=torch.int64)       # the rows' wide lists, handed from epoch to epoch
         thr = torch.empty(m, device=dev, dtype=torch.float32)
         thr_idx = torch.empty(m, device=dev, dtype=torch.int64)
         for e, (t0, t1) in enumerate(epochs):
@@ -580,10 +600,11 @@ def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offse
                                         c0, _p(cnt), _p(cand), KNN_FUSED_CAP, _p(None) if e else _p(bound), _p(flag), int(max_blocks), _stream()), "knn_screen")
             if KNN_DEBUG_COUNTS is not None:           # tools/knn_prof.py: survivors per row and epoch (a clone: refine resets the counts)
                 KNN_DEBUG_COUNTS.append((e, cnt.clone()))
-            check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, m, k, idx_offset, _p(None) if e else _p(bound),
-                                        _p(idx_out[q0:]) if e else _p(None),
-                                        _p(dist_out[q0:]) if e else _p(None), _p(idx_out[q0:]), _p(dist_out[q0:]), _p(None) if last else _p(thr),
-                                        _p(None) if last else _p(thr_idx), 1 if last else 0, _p(flag), _stream()), "knn_refine")
+            check(lib.knnsvc_knn_refine(_p(cnt), _p(cand), KNN_FUSED_CAP, m, k, _p(None) if e else _p(bound), 1 if e else 0, _p(wide),
+                                        _p(None) if last else _p(thr), _p(None) if last else _p(thr_idx), 1 if last else 0, _p(flag),
+                                        _stream()), "knn_refine")
+        # the candidates' order came from the screening products; the order that goes out comes from exact ones
+        _knn_rescore(wide, q[q0:q0 + m], qn[q0:], qs[q0:], pc, pn, ps, k, idx_offset, mask, idx_out[q0:], dist_out[q0:])
 
 
 def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=True, return_flag=False, mask=None,
@@ -621,7 +642,7 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     dist = torch.empty(nq, k, device=q.device, dtype=torch.float32)
     flag = torch.zeros(1, device=q.device, dtype=torch.int32)
     check(lib.knnsvc_knn_topk(_p(q), _p(qn), _p(qs), nq, _p(pool), _p(pn), _p(ps), npool, dim, k, idx_offset, mask[0], mask[1],
-                              _p(idx), _p(dist), _p(ws), ws_bytes, _p(flag), _stream()), "knn_topk")
+                              _p(idx), _p(dist), _p(ws), ws_bytes, _p(flag), 1 if knn_rescore_on() else 0, _stream()), "knn_topk")
     if check_nan:
         raise_if_nan(flag)
     return (idx, dist, flag) if return_flag else (idx, dist)

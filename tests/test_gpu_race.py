@@ -47,3 +47,4 @@ def test_hand_packed_fp32_kernels_are_bit_stable_beside_mfma_workgroups():
     print("hand-packed fp32 beside MFMA co-runners:", res)
     assert all(v == 0 for v in res["differ"].values()), res
     assert any(k.startswith("W128") for k in res["co_runners"]), res
+    assert res["kernels"]["gemm_gelu_quad"] == "Q256S", res          # the 256 x 256 kernel's specialised GELU epilogue was the one tested

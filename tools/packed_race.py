@@ -20,11 +20,11 @@ def run(runs=30):
     w0, g0, b0 = (rn(512, 10) / 3).to(dev), (1 + 0.1 * rn(512)).to(dev), (0.1 * rn(512)).to(dev)
     # (2) FFN1-shaped GEMM with the GELU epilogue on the 256 x 256 kernel (1500 x 1024 -> 4096), (3) a GELU epilogue on the
     # 128 x 128 kernel (K = 512: below the quad kernel's K >= 1024 rule; three workgroups per CU: they DO share CUs with co-runners)
-    x1 = rn(1500, 1024).to(dev); w1 = ops.attach_split((rn(4096, 1024) / 32).to(dev)); b1 = (0.1 * rn(4096)).to(dev)
+    x1 = ops.split_pack(rn(1500, 1024)).to(dev); w1 = ops.attach_split((rn(4096, 1024) / 32).to(dev)); b1 = (0.1 * rn(4096)).to(dev)
     x2 = rn(6000, 512).to(dev); w2 = ops.attach_split((rn(512, 512) / 22).to(dev)); b2 = (0.1 * rn(512)).to(dev)
     cases = {
         "conv0_ln_gelu": lambda: ops.wavlm_conv0(wav, w0, g0, b0, 10, 5),
-        "gemm_gelu_quad": lambda: ops.linear(x1, w1, b1, act=ops.ACT_GELU),
+        "gemm_gelu_quad": lambda: ops.linear(x1, w1, b1, act=ops.ACT_GELU, x_split=True),      # pre-split A -> conv_gemm2quad_kernel, EPI = 2
         "gemm_gelu_128": lambda: ops.linear(x2, w2, b2, act=ops.ACT_GELU),
     }
     names = {}
