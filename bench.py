@@ -102,7 +102,7 @@ class GemmTimer:
             # only launches that can reach the dominant kernel (n > 64, 32-channel slabs) get an event pair, unless
             # --stages asked for the full table: event records around the many small launches would slow the eager pass
             cand = kw["n"] > 64 and kw["cin"] % 32 == 0
-            if not (self.enabled and (cand or self.all_variants)):
+            if kw.get("defer") is not None or not (self.enabled and (cand or self.all_variants)):      # (deferred: launched later, as part of one grid)
                 return orig(x, w, out, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -258,7 +258,9 @@ def run_steps(n, depth, enc, voc, src, sf0, pool_w, pool_f0, max_batch, pipe):
     stream scheduler (knn_svc_amd.pipeline.LanePipeline) — the back half of conversion i (match:
     single-workgroup recurrences on 2-4 CUs; vocoder) is enqueued on a second stream and runs while the front
     half of conversion i+1 (the encoder) fills the rest of the chip, the way bulk_match streams a list of
-    sources.  Every conversion still does all of its work (cold pool)."""
+    sources.  Every conversion still does all of its work (cold pool).  (Tried in round 5, same box: the generator behind the
+    NEXT encoder on the first stream instead of beside it — 37.1 ms per step against 35.8; on a third, normal-priority
+    stream — 36.0: the generator fills what the encoder's launches leave idle, and needs to run beside them for that.)"""
     if depth <= 1:
         y = None
         for _ in range(n):

@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 12
+#define KNNSVC_ABI_VERSION 13
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -120,6 +120,14 @@ typedef struct knnsvc_conv_desc {
 
 int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream);
 
+/* `count` (1..4) convolutions of the same output shape [m, n] in ONE launch (hifigan/ddsp_models.py:206-227: the three
+ * ResBlock branches of a generator stage — kernel sizes 3 / 7 / 11 — only share their input; the reference runs them one
+ * after the other and averages).  When every descriptor takes the windowed kernel (stride 1, >= 3 taps, fp32 input, split
+ * weights, (taps - 1) * dil <= 64, batches = groups = 1) the descriptors become the y dimension of one grid: the branches
+ * fill the chip together without streams of their own.  Otherwise: one knnsvc_conv_gemm per descriptor, in order.  Results
+ * are bit-identical to separate launches either way.  Put the descriptor with the most taps first. */
+int knnsvc_conv_gemm_multi(const knnsvc_conv_desc* descs, int32_t count, void* stream);
+
 /* One ResBlock1 iteration of the generator in one launch (hifigan/ddsp_models.py:13-44):
  *     t1 = lrelu(conv1d(lrelu(x), w1, dilation = dil) + b1);   out = conv1d(t1, w2) + b2 + x
  * x, out: channel-last [t, channels] fp32 (row pitches ldx / ldo), both convolutions `taps` wide with "same" zero padding; the
@@ -139,6 +147,8 @@ typedef struct knnsvc_pair_desc {
     const int32_t* n_dyn; int32_t dyn_mul;
 } knnsvc_pair_desc;
 int knnsvc_resblock_pair(const knnsvc_pair_desc* d, void* stream);
+/* The pairs of `count` (1..4) ResBlock branches (same channels and length, any odd taps) in one launch: see knnsvc_conv_gemm_multi. */
+int knnsvc_resblock_pair_multi(const knnsvc_pair_desc* descs, int32_t count, void* stream);
 
 /* out = alpha * x (accumulate = 0) or out + alpha * x (accumulate = 1) over n floats (n % 4 == 0): one term of the layer
  * weighting `(feats * w[:, None]).sum(0)` over WavLM's layer outputs (ddsp_prematch_dataset.py:349-350) when w is not one-hot

@@ -776,9 +776,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
 
 // stride-1 multi-tap convolutions: one window of BM + HALO input rows per 32-channel slab, every tap reads it shifted
 // (gemm2_core.h, Gemm2Win)
-template <class G, int MINB>
-__global__ __launch_bounds__(256, MINB) void conv_gemm2win_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <class G>
+__device__ __forceinline__ void conv_gemm2win_body(ConvArgs& a, float* lds) {
     resolve_scales(a);
     const int z = blockIdx.z;
     const int b = z / a.groups, g = z - b * a.groups;
@@ -816,6 +815,27 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm2win_kernel(ConvArgs a) {
 }
 
 template <class G, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm2win_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    conv_gemm2win_body<G>(a, lds);
+}
+
+// Several convolutions of the same output shape in ONE launch (round 5): blockIdx.y picks the descriptor.  The generator's three
+// ResBlock branches of a stage (kernel sizes 3 / 7 / 11: hifigan/ddsp_models.py:206-227) only share their input; until round 4
+// they ran on three streams, and whether those streams really overlapped was up to HIP's stream -> hardware-queue mapping (34.8 vs
+// 38.3 ms per bench step depending on how many streams the process had created before).  Here the branches' launches of one step
+// are one grid: the dispatcher sees all their workgroups at once, nothing depends on queues.  Same body, same descriptors: same
+// bits as the separate launches.  The heaviest descriptor (most taps) should come first: workgroups are dispatched y-major.
+constexpr int KN_MAX_MULTI = 4;
+struct ConvArgsN { ConvArgs b[KN_MAX_MULTI]; };
+template <class G, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm2win_multi_kernel(ConvArgsN args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ConvArgs a = args.b[blockIdx.y];
+    conv_gemm2win_body<G>(a, lds);
+}
+
+template <class G, int MINB>
 int launch2win(const ConvArgs& a, int batches, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
@@ -828,6 +848,22 @@ int launch2win(const ConvArgs& a, int batches, hipStream_t st) {
     dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
     hipLaunchKernelGGL((conv_gemm2win_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, a);
     return knnsvc_check_launch("conv_gemm2win");
+}
+
+template <class G, int MINB>
+int launch2win_multi(const ConvArgsN& an, int count, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_gemm2win_multi_kernel<G, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "conv_gemm_multi: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    const ConvArgs& a = an.b[0];
+    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
+    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), (unsigned)count, 1);
+    hipLaunchKernelGGL((conv_gemm2win_multi_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, an);
+    return knnsvc_check_launch("conv_gemm2win_multi");
 }
 
 // 256x256 block / 128x128 wave tiles, hand-pipelined loop (gemm2_core.h, Gemm2QuadS): A2 activations + split weights
@@ -1057,7 +1093,8 @@ const Knobs& knobs() { if (!g_knobs.loaded) load_knobs(); return g_knobs; }
 
 extern "C" int knnsvc_reload_knobs(void) { load_knobs(); return KNNSVC_OK; }
 
-extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
+// descriptor -> kernel arguments (validation included); `fast`: the buffer-load fast path applies, `vec4`: 16-byte vectors do
+static int conv_prep(const knnsvc_conv_desc* d, ConvArgs& a, bool& fast, bool& vec4, bool& quad_ok) {
     KN_REQUIRE(d && d->x && d->w && d->out, "conv_gemm: null operand");
     KN_REQUIRE(d->cin > 0 && d->taps > 0 && d->n > 0 && d->m >= 0 && d->t_in >= 0, "conv_gemm: bad sizes");
     KN_REQUIRE(d->batches > 0 && d->groups > 0, "conv_gemm: batches/groups must be positive");
@@ -1073,9 +1110,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         KN_REQUIRE(d->ldo >= d->n, "conv_gemm: ldo < n");
     }
     if (d->resid) KN_REQUIRE(d->ldr > 0, "conv_gemm: resid without ldr");
-    if (d->m == 0) return KNNSVC_OK;
 
-    ConvArgs a;
     a.x = d->x; a.x_bstride = d->x_bstride; a.x_gstride = d->x_gstride; a.ldx = d->ldx; a.t_in = d->t_in;
     a.cin = d->cin; a.taps = d->taps; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.a_slope = d->a_slope;
     a.w = d->w; a.w_gstride = d->w_gstride; a.n = d->n;
@@ -1102,14 +1137,13 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             !knobs().generic_epilogue;      // KNNSVC_EPILOGUE=g: generic epilogue (A/B)
 
     // 16-byte vector path needs every float4 of A and W to be aligned and inside one tap
-    const bool vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
+    vec4 = (d->cin % 4 == 0) && (d->ldx % 4 == 0) && (((uintptr_t)d->x & 15) == 0) &&
                       (((uintptr_t)d->w & 15) == 0) && (d->x_bstride % 4 == 0) && (d->x_gstride % 4 == 0) &&
                       (d->w_gstride % 4 == 0);
-    hipStream_t st = (hipStream_t)stream;
     if (prepare<G128>() || prepare<G64>() || prepare<G32>())
         return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
     // buffer-load fast path: every slab inside one tap, resources below 1 GiB
-    const bool fast = vec4 && (d->cin % 32 == 0) && ((long)d->t_in * d->ldx * 4 < (1L << 30)) &&
+    fast = vec4 && (d->cin % 32 == 0) && ((long)d->t_in * d->ldx * 4 < (1L << 30)) &&
                       ((long)d->n * a.K * 4 < (1L << 30)) && ((long)d->m * d->stride * d->ldx * 4 < (1L << 30));
     if (a.out_split)
         KN_REQUIRE(!d->resid && !d->accumulate && a.div == 1.0f && !d->convt_u && d->n % 32 == 0 && d->ldo % 32 == 0 &&
@@ -1131,11 +1165,51 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
         a.x_absmax = d->x_absmax; a.w_absmax = d->w_absmax;      // device-side scales override the two above
         a.x_bound_mul = d->x_bound_mul > 0.f ? d->x_bound_mul : 1.0f; a.x_bound_add = d->x_bound_add;
         KN_REQUIRE(d->x_bound_add >= 0.f && d->x_bound_mul >= 0.f, "conv_gemm: x_bound_mul / x_bound_add must be non-negative");
-        const bool quad_ok = a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
+        quad_ok = a.x_split && a.lin && d->n % 4 == 0 && d->ldo % 4 == 0 && (!d->resid || d->ldr % 4 == 0) && ((uintptr_t)d->out & 15) == 0 &&
             (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
             d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
             d->bias_gstride % 4 == 0;
         KN_REQUIRE(d->fixed_tile != 2 || quad_ok, "conv_gemm: fixed_tile 2 needs the quad kernel's operand layout (split A, 16-byte rows, n % 4 == 0)");
+    }
+    return KNNSVC_OK;
+}
+
+// the windowed kernel's tile shape for `z` convolutions of [m, n] in one grid (z = batches * groups * descriptors)
+enum WinShape { WS_NONE, WS_128D, WS_128S, WS_160, WS_128, WS_64, WS_32, WS_64P };
+static WinShape win_shape(const knnsvc_conv_desc* d, const ConvArgs& a, long z) {
+    if (a.x_split || d->convt_u || d->stride != 1 || d->taps < 3 || d->dil < 1 || d->ldx % 4 != 0 || !knobs().win) return WS_NONE;
+    const int halo = (d->taps - 1) * d->dil;
+    if (halo <= 64) {
+        if (d->n > 64) {
+            // fewer than ~2/3 of the chip's 768 resident slots at 128-row tiles: halve the tile height
+            if (knobs().win_small && cdiv64(d->m, 128) * cdiv64(d->n, 128) * z < 512) {
+                // two steps of weight prefetch where a launch leaves at most one workgroup per CU (nothing else hides the L2
+                // round trip: 3750 x 256, k = 11: 70 -> 59 us); with more workgroups per CU the neighbours already do and the
+                // second register set only costs (15 000 x 256, k = 7: 61 -> 66 us).  Same products, same order: same bits.
+                if (knobs().win_deep && cdiv64(d->m, 64) * cdiv64(d->n, 128) * z <= 256) return WS_128D;
+                return WS_128S;
+            }
+            // Tile-count quantisation: 768 blocks are resident at once (3 per CU); a launch of 938 128-row tiles (the
+            // generator's C = 128 stage at 30 s: 120 000 rows) runs two rounds, the second 22 % full.  160-row tiles make
+            // it 750 — one round.  Pick the height with the fewer (rounds x rows per round).  KNNSVC_WIN160=0: off.
+            const long zz = z * cdiv64(d->n, 128);
+            const long r128 = cdiv64(cdiv64(d->m, 128) * zz, 768) * 128, r160 = cdiv64(cdiv64(d->m, 160) * zz, 768) * 160;
+            return (knobs().win160 && r160 < r128) ? WS_160 : WS_128;
+        }
+        return d->n > 32 ? WS_64 : WS_32;
+    }
+    if (halo <= 128 && d->n > 32 && d->n <= 64) return WS_64P;
+    return WS_NONE;
+}
+
+extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
+    ConvArgs a;
+    bool fast = false, vec4 = false, quad_ok = false;
+    const int rc = conv_prep(d, a, fast, vec4, quad_ok);
+    if (rc) return rc;
+    if (d->m == 0) return KNNSVC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (fast && a.w2) {        // fp32 emulated on the fp16 matrix cores (gemm2_core.h)
         if (d->fixed_tile != 1 && quad_ok) {
             // 256x256 block, 128x128 wave tiles, hand-pipelined loop (Gemm2QuadS: v_mfma_f32_16x16x32_f16, 32-k slabs): every A2
             // launch with K >= 1024 and n >= 256 — FFN1 / FFN2 / QKV / out-proj, the conv stack, the kNN's dot matrix.
@@ -1157,36 +1231,15 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
             }
         }
         // stride-1 multi-tap convolutions on fp32 input: windowed kernel (A staged once per channel slab, not once per tap)
-        if (!a.x_split && !d->convt_u && d->stride == 1 && d->taps >= 3 && d->dil >= 1 && d->ldx % 4 == 0) {
-            const bool win_on = knobs().win;
-            const int halo = (d->taps - 1) * d->dil;
-            if (win_on && halo <= 64) {
-                if (d->n > 64) {
-                    // fewer than ~2/3 of the chip's 768 resident slots at 128-row tiles: halve the tile height
-                    if (knobs().win_small && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 512) {
-                        const bool deep_on = knobs().win_deep;
-                        // two steps of weight prefetch where a launch leaves at most one workgroup per CU (nothing else hides the L2
-                        // round trip: 3750 x 256, k = 11: 70 -> 59 us); with more workgroups per CU the neighbours already do and the
-                        // second register set only costs (15 000 x 256, k = 7: 61 -> 66 us).  Same products, same order: same bits.
-                        if (deep_on && cdiv64(d->m, 64) * cdiv64(d->n, 128) * d->batches * d->groups <= 256) {
-                            g_last_kernel = "W128D"; return launch2win<W128D, 4>(a, d->batches, st);
-                        }
-                        g_last_kernel = "W128S"; return launch2win<W128S, 4>(a, d->batches, st);
-                    }
-                    // Tile-count quantisation: 768 blocks are resident at once (3 per CU); a launch of 938 128-row tiles (the
-                    // generator's C = 128 stage at 30 s: 120 000 rows) runs two rounds, the second 22 % full.  160-row tiles make
-                    // it 750 — one round.  Pick the height with the fewer (rounds x rows per round).  KNNSVC_WIN160=0: off.
-                    const bool w160_on = knobs().win160;
-                    const long z = (long)d->batches * d->groups * cdiv64(d->n, 128);
-                    const long r128 = cdiv64(cdiv64(d->m, 128) * z, 768) * 128, r160 = cdiv64(cdiv64(d->m, 160) * z, 768) * 160;
-                    if (w160_on && r160 < r128) { g_last_kernel = "W160"; return launch2win<W160, 3>(a, d->batches, st); }
-                    g_last_kernel = "W128"; return launch2win<W128, 3>(a, d->batches, st);
-                }
-                if (d->n > 32) { g_last_kernel = "W64"; return launch2win<W64, 2>(a, d->batches, st); }
-                g_last_kernel = "W32";
-                return launch2win<W32, 3>(a, d->batches, st);
-            }
-            if (win_on && halo <= 128 && d->n > 32 && d->n <= 64) { g_last_kernel = "W64P"; return launch2win<W64P, 2>(a, d->batches, st); }
+        switch (win_shape(d, a, (long)d->batches * d->groups)) {
+            case WS_128D: g_last_kernel = "W128D"; return launch2win<W128D, 4>(a, d->batches, st);
+            case WS_128S: g_last_kernel = "W128S"; return launch2win<W128S, 4>(a, d->batches, st);
+            case WS_160: g_last_kernel = "W160"; return launch2win<W160, 3>(a, d->batches, st);
+            case WS_128: g_last_kernel = "W128"; return launch2win<W128, 3>(a, d->batches, st);
+            case WS_64: g_last_kernel = "W64"; return launch2win<W64, 2>(a, d->batches, st);
+            case WS_32: g_last_kernel = "W32"; return launch2win<W32, 3>(a, d->batches, st);
+            case WS_64P: g_last_kernel = "W64P"; return launch2win<W64P, 2>(a, d->batches, st);
+            case WS_NONE: break;
         }
         if (d->n > 64 && cdiv64(d->m, 128) * cdiv64(d->n, 128) * d->batches * d->groups < 256) {
             if (knobs().gemm_small) { g_last_kernel = "F64S"; return launch2<F64S>(a, d->batches, st); }
@@ -1209,6 +1262,38 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
 }
 
 extern "C" const char* knnsvc_conv_gemm_last_kernel(void) { return g_last_kernel; }
+
+extern "C" int knnsvc_conv_gemm_multi(const knnsvc_conv_desc* descs, int32_t count, void* stream) {
+    KN_REQUIRE(descs && count >= 1 && count <= KN_MAX_MULTI, "conv_gemm_multi: 1..4 descriptors");
+    ConvArgsN an;
+    bool one_grid = true;
+    for (int i = 0; i < count; ++i) {
+        bool fast = false, vec4 = false, quad_ok = false;
+        const int rc = conv_prep(&descs[i], an.b[i], fast, vec4, quad_ok);
+        if (rc) return rc;
+        const knnsvc_conv_desc& d = descs[i];
+        // one grid needs one output shape and the windowed kernel for every descriptor; anything else: one launch each
+        one_grid = one_grid && fast && an.b[i].w2 && d.batches == 1 && d.groups == 1 && d.m == descs[0].m && d.n == descs[0].n && d.m > 0 &&
+                   win_shape(&d, an.b[i], count) != WS_NONE && win_shape(&d, an.b[i], count) == win_shape(&descs[0], an.b[0], count);
+    }
+    if (!one_grid || count == 1) {
+        for (int i = 0; i < count; ++i) { const int rc = knnsvc_conv_gemm(&descs[i], stream); if (rc) return rc; }
+        return KNNSVC_OK;
+    }
+    for (int i = count; i < KN_MAX_MULTI; ++i) an.b[i] = an.b[0];
+    hipStream_t st = (hipStream_t)stream;
+    switch (win_shape(&descs[0], an.b[0], count)) {
+        case WS_128D: g_last_kernel = "W128Dx"; return launch2win_multi<W128D, 4>(an, count, st);
+        case WS_128S: g_last_kernel = "W128Sx"; return launch2win_multi<W128S, 4>(an, count, st);
+        case WS_160: g_last_kernel = "W160x"; return launch2win_multi<W160, 3>(an, count, st);
+        case WS_128: g_last_kernel = "W128x"; return launch2win_multi<W128, 3>(an, count, st);
+        case WS_64: g_last_kernel = "W64x"; return launch2win_multi<W64, 2>(an, count, st);
+        case WS_32: g_last_kernel = "W32x"; return launch2win_multi<W32, 3>(an, count, st);
+        case WS_64P: g_last_kernel = "W64Px"; return launch2win_multi<W64P, 2>(an, count, st);
+        case WS_NONE: break;
+    }
+    return knnsvc_fail(KNNSVC_EINVAL, "conv_gemm_multi: no windowed kernel for this shape");
+}
 
 extern "C" int knnsvc_split_weight_bf16x3(const float* w, int64_t rows, int32_t K, void* out, void* stream) {
     KN_REQUIRE(w && out && rows > 0 && K > 0 && K % 32 == 0, "split_weight: K must be a positive multiple of 32");
@@ -1298,9 +1383,8 @@ struct PairArgs {
     const int* n_dyn; int dyn_mul;
 };
 
-template <class G, int MINB>
-__global__ __launch_bounds__(256, MINB) void conv_pair_kernel(PairArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <class G>
+__device__ __forceinline__ void conv_pair_body(const PairArgs& a, float* lds) {
     typedef __attribute__((address_space(3))) char lds_c;
     typedef __attribute__((address_space(3))) unsigned short lds_h;
     static_assert(G::NR == 16, "32x32 accumulator tiles");
@@ -1401,6 +1485,39 @@ __global__ __launch_bounds__(256, MINB) void conv_pair_kernel(PairArgs a) {
 }
 
 template <class G, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_pair_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    conv_pair_body<G>(a, lds);
+}
+// the pairs of several ResBlock branches in ONE launch: blockIdx.y picks the branch (see conv_gemm2win_multi_kernel)
+struct PairArgsN { PairArgs b[KN_MAX_MULTI]; };
+template <class G, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_pair_multi_kernel(PairArgsN args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const PairArgs a = args.b[blockIdx.y];
+    conv_pair_body<G>(a, lds);
+}
+
+template <class G, int MINB>
+int launch_pair_multi(const PairArgsN& an, int count, hipStream_t st) {
+    constexpr int IR = G::BM + 16;
+    const int ncs = an.b[0].C / 32;
+    const int lds_bytes = G::LDS_BYTES > (ncs * IR + G::BN) * G::PITCH ? G::LDS_BYTES : (ncs * IR + G::BN) * G::PITCH;
+    static int attr = 0;
+    if (attr < lds_bytes) {
+        if (hipFuncSetAttribute((const void*)conv_pair_multi_kernel<G, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return knnsvc_fail(KNNSVC_EHIP, "resblock_pair_multi: hipFuncSetAttribute failed");
+        attr = lds_bytes;
+    }
+    int taps_max = 1;
+    for (int i = 0; i < count; ++i) taps_max = an.b[i].taps > taps_max ? an.b[i].taps : taps_max;
+    // a branch with fewer taps yields more rows per workgroup and needs fewer of them: its surplus workgroups leave at once (t0 >= T)
+    const int BMo = G::BM - (taps_max - 1);
+    hipLaunchKernelGGL((conv_pair_multi_kernel<G, MINB>), dim3((unsigned)cdiv64(an.b[0].T, BMo), (unsigned)count), dim3(256), lds_bytes, st, an);
+    return knnsvc_check_launch("resblock_pair_multi");
+}
+
+template <class G, int MINB>
 int launch_pair(const PairArgs& a, hipStream_t st) {
     constexpr int IR = G::BM + 16;
     const int ncs = a.C / 32;
@@ -1421,7 +1538,7 @@ using P32 = Gemm2Win<256, 32, 4, 1, 2, 1, 64>;        // C = 32: window 46 KB + 
 using P128 = Gemm2Win<64, 128, 2, 2, 1, 2, 64>;       // C = 128: 64-row tiles (image 4 x 80 rows = 46 KB + weights 18.4 KB): 2 blocks / CU
 }  // namespace
 
-extern "C" int knnsvc_resblock_pair(const knnsvc_pair_desc* d, void* stream) {
+static int pair_prep(const knnsvc_pair_desc* d, PairArgs& a) {
     KN_REQUIRE(d && d->x && d->w1_f16x2 && d->w2_f16x2 && d->out, "resblock_pair: null operand");
     KN_REQUIRE(d->channels == 32 || d->channels == 64 || d->channels == 128, "resblock_pair: 32, 64 or 128 channels (other widths take the two-launch form)");
     KN_REQUIRE(d->taps >= 1 && d->taps <= 11 && (d->taps & 1) && d->dil >= 1 && d->dil * (d->taps - 1) <= 64, "resblock_pair: odd taps <= 11, dil * (taps - 1) <= 64");
@@ -1430,16 +1547,42 @@ extern "C" int knnsvc_resblock_pair(const knnsvc_pair_desc* d, void* stream) {
     KN_REQUIRE(d->w1_scale > 0.f && d->w2_scale > 0.f, "resblock_pair: weight scales");
     KN_REQUIRE(d->x_absmax || (d->a1_scale > 0.f && d->a2_scale > 0.f), "resblock_pair: a range slot or both activation scales");
     if (d->n_dyn) KN_REQUIRE(d->dyn_mul > 0, "resblock_pair: dyn_mul");
-    if (d->t == 0) return KNNSVC_OK;
-    PairArgs a;
     a.x = d->x; a.ldx = d->ldx; a.T = d->t; a.C = d->channels; a.taps = d->taps; a.dil = d->dil;
     a.w1 = (const unsigned short*)d->w1_f16x2; a.w2 = (const unsigned short*)d->w2_f16x2; a.b1 = d->b1; a.b2 = d->b2;
     a.out = d->out; a.ldo = d->ldo; a.slope = d->slope; a.w1_scale = d->w1_scale; a.w2_scale = d->w2_scale;
     a.x_absmax = d->x_absmax; a.bound_mul = d->t1_bound_mul > 0.f ? d->t1_bound_mul : 1.0f; a.bound_add = d->t1_bound_add;
     a.a1_scale = d->a1_scale; a.a2_scale = d->a2_scale; a.out_absmax = d->out_absmax; a.n_dyn = d->n_dyn; a.dyn_mul = d->dyn_mul;
+    return KNNSVC_OK;
+}
+
+extern "C" int knnsvc_resblock_pair(const knnsvc_pair_desc* d, void* stream) {
+    PairArgs a;
+    const int rc = pair_prep(d, a);
+    if (rc) return rc;
+    if (d->t == 0) return KNNSVC_OK;
     if (d->channels == 128) return launch_pair<P128, 2>(a, (hipStream_t)stream);
     if (d->channels == 64) return launch_pair<P64, 3>(a, (hipStream_t)stream);
     return launch_pair<P32, 3>(a, (hipStream_t)stream);
+}
+
+extern "C" int knnsvc_resblock_pair_multi(const knnsvc_pair_desc* descs, int32_t count, void* stream) {
+    KN_REQUIRE(descs && count >= 1 && count <= KN_MAX_MULTI, "resblock_pair_multi: 1..4 descriptors");
+    PairArgsN an;
+    bool one_grid = true;
+    for (int i = 0; i < count; ++i) {
+        const int rc = pair_prep(&descs[i], an.b[i]);
+        if (rc) return rc;
+        one_grid = one_grid && descs[i].channels == descs[0].channels && descs[i].t == descs[0].t && descs[i].t > 0 &&
+                   descs[i].n_dyn == descs[0].n_dyn && descs[i].dyn_mul == descs[0].dyn_mul;
+    }
+    if (!one_grid || count == 1) {
+        for (int i = 0; i < count; ++i) { const int rc = knnsvc_resblock_pair(&descs[i], stream); if (rc) return rc; }
+        return KNNSVC_OK;
+    }
+    for (int i = count; i < KN_MAX_MULTI; ++i) an.b[i] = an.b[0];
+    if (descs[0].channels == 128) return launch_pair_multi<P128, 2>(an, count, (hipStream_t)stream);
+    if (descs[0].channels == 64) return launch_pair_multi<P64, 3>(an, count, (hipStream_t)stream);
+    return launch_pair_multi<P32, 3>(an, count, (hipStream_t)stream);
 }
 
 namespace {

@@ -520,9 +520,7 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
             assert waves_out is not None
             tail = lambda item, r: r + (vocode_fn(r[0], r[2], r[1]),)
             if matching_list.is_cuda:
-                from .vocoder import serial_resblocks
-                with serial_resblocks() if lanes > 1 else contextlib.nullcontext():      # (many streams already: see vocoder.serial_resblocks)
-                    results = pipeline.LanePipeline(matching_list.device, max(1, lanes)).run(items, body, tail)
+                results = pipeline.LanePipeline(matching_list.device, max(1, lanes)).run(items, body, tail)
             else:
                 results = [tail(i, body(i)) for i in items]
             for item, r in zip(items, results):

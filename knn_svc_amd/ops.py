@@ -159,10 +159,11 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
               bias_gstride=0, o_bstride=0, o_gstride=0, r_bstride=0, r_gstride=0,
               convt_u=0, convt_cout=0, convt_pad=0, t_out=0, a_scale=0.0, x_split=False, out_split=False,
               w2=None, w2_scale=0.0, x_absmax=None, w_absmax=None, out_absmax=None, out_split_scale=0.0, dyn=None, x_bound=None,
-              fixed_tile=False):
+              fixed_tile=False, defer=None):
     """See knnsvc_conv_gemm.  x/out/resid may be views into wider buffers (pass ldx/ldo/ldr).
     ``x_absmax`` / ``w_absmax`` / ``out_absmax``: one-element device tensors (range slots of the f16x2 path, see the
-    header): bound of |x| / |w| the kernel derives its operand scales from, and where this launch folds max|out|."""
+    header): bound of |x| / |w| the kernel derives its operand scales from, and where this launch folds max|out|.
+    ``defer``: a list — the descriptor is appended to it instead of being launched (``conv_gemm_multi`` launches the list)."""
     lib = _lib.load()
     d = ConvDesc()
     d.x = x.data_ptr(); d.x_bstride = x_bstride; d.x_gstride = x_gstride
@@ -210,8 +211,32 @@ def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None
         d.dyn_t_out_mul = int(t_out) // nb if convt_u else 0
         if convt_u and int(t_out) % nb:
             raise KnnSvcError("conv_gemm: dynamic t_out must be a multiple of the bucket count")
+    if defer is not None:
+        defer.append(d)
+        return out
     check(lib.knnsvc_conv_gemm(C.byref(d), _stream()), "conv_gemm")
     return out
+
+
+def conv_gemm_multi(descs) -> None:
+    """Launch the descriptors collected with ``conv_gemm(..., defer=descs)`` — convolutions of one output shape (the generator's
+    three ResBlock branches of a step) — as ONE grid (knnsvc_conv_gemm_multi); same bits as separate launches."""
+    if not descs:
+        return
+    for i in range(0, len(descs), 4):
+        part = descs[i:i + 4]
+        arr = (ConvDesc * len(part))(*part)
+        check(_lib.load().knnsvc_conv_gemm_multi(arr, len(part), _stream()), "conv_gemm_multi")
+
+
+def resblock_pair_multi(descs) -> None:
+    """The same for ``resblock_pair(..., defer=descs)`` (knnsvc_resblock_pair_multi)."""
+    if not descs:
+        return
+    for i in range(0, len(descs), 4):
+        part = descs[i:i + 4]
+        arr = (PairDesc * len(part))(*part)
+        check(_lib.load().knnsvc_resblock_pair_multi(arr, len(part), _stream()), "resblock_pair_multi")
 
 
 def absmax(x2d, slot=None):
@@ -240,7 +265,7 @@ def resblock_pair_ok(channels: int, taps: int, dil: int) -> bool:
 
 
 def resblock_pair(x, w1, b1, w2, b2, out, *, t, channels, taps, dil, slope, x_absmax, t1_bound, out_absmax=None, dyn=None,
-                  ldx=None, ldo=None):
+                  ldx=None, ldo=None, defer=None):
     """out = conv1d(lrelu(conv1d(lrelu(x), w1, dilation=dil) + b1), w2) + b2 + x in one launch (see the header); w1 / w2 are packed
     conv weights carrying their f16x2 split (attach_split).  Bit-identical to the two conv_gemm launches."""
     d = PairDesc()
@@ -256,6 +281,9 @@ def resblock_pair(x, w1, b1, w2, b2, out, *, t, channels, taps, dil, slope, x_ab
         d.x_absmax = None; d.a1_scale = d.a2_scale = 16.0; d.out_absmax = None
     if dyn is not None:
         d.n_dyn = dyn[0].data_ptr(); d.dyn_mul = t // dyn[1]
+    if defer is not None:
+        defer.append(d)
+        return out
     check(_lib.load().knnsvc_resblock_pair(C.byref(d), _stream()), "resblock_pair")
     return out
 

@@ -167,10 +167,7 @@ class BatchConverter:
                                         nan_flags=flags, pool_prep=tg.prep, nn32=nn.get(i))
             tail = lambda i, r: voc(r[0], r[2], r[1])
             n_lanes = max(1, min(self.lanes, len(items)))
-            from .vocoder import serial_resblocks
-            import contextlib
-            with serial_resblocks() if n_lanes > 1 else contextlib.nullcontext():           # (many streams already)
-                ys = pipeline.LanePipeline(dev, n_lanes).run(items, body, tail)
+            ys = pipeline.LanePipeline(dev, n_lanes).run(items, body, tail)
             peak = torch.stack([y.abs().max() for y in ys])
             for f in flags:
                 ops.raise_if_nan(f)                          # one host read per search, after everything is enqueued

@@ -29,15 +29,14 @@ def _fold(sd, name):
 
 
 import threading as _threading
-_SERIAL = _threading.local()          # per host thread: the request-queue worker must not switch the main thread's generators to serial
+_SERIAL = _threading.local()          # per host thread
 
 
 class serial_resblocks:
-    """Context: generators run their ResBlock branches one after the other on the caller's stream.  For callers that already
-    keep many streams busy (the dataset-mode / serving pipelines: match lanes + their partner streams + the kNN stream + the
-    tail): HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues and streams that share a queue serialise — two more streams
-    per generator made the cfg 5 share 25-35 % SLOWER (12.0 -> 15.7-18.4 ms per source), while the north-star pipeline (one
-    lane) gains 7 % from them."""
+    """Context (A/B aid, equality tests): the three ResBlock branches of a stage are launched one after the other — one launch per
+    branch and step — instead of one grid per step (ops.conv_gemm_multi / ops.resblock_pair_multi).  Same kernels, same
+    descriptors, same buffers: the waveform is bit-identical either way.  (Until round 4 this context switched off the
+    per-branch STREAMS; those are gone — see Vocoder._forward.)"""
     def __enter__(self):
         self.prev = getattr(_SERIAL, "on", False); _SERIAL.on = True
     def __exit__(self, *a):
@@ -104,28 +103,12 @@ class Vocoder:
         self._graph_pools = {0: self._graph_pool}
         self.max_graphs = 48            # (bucket, mode) instances PER tail stream (Vocoder._evict)
         self.use_graphs = True
-        self.parallel_resblocks = os.environ.get("KNNSVC_PAR_RESBLOCKS", "1") != "0"
-        self._branch = {}
+        self.merge_branches = os.environ.get("KNNSVC_MERGE_BRANCHES", "1") != "0"
 
-    def _par(self) -> bool:
-        # (under an RCCL process group the branches run in series: with the communicator's streams on the card the parallel form
-        #  is the slower one — bench.py, one rank: 38.2 ms per step against 37.4; profiles/r04_rank1_rccl_ab.txt)
-        if not self.parallel_resblocks or getattr(_SERIAL, "on", False):
-            return False
-        if os.environ.get("KNNSVC_PAR_RESBLOCKS") == "1":
-            return True
-        from .pipeline import rccl_streams
-        return rccl_streams()[0] == 0
-
-    def _branch_streams(self, dev):
-        """Two side streams per (device, current stream) for the ResBlock branches (the generator may run on several streams)."""
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
-        if key not in self._branch:
-            pr = torch.cuda.current_stream(idx).priority
-            from .pipeline import new_stream
-            self._branch[key] = [new_stream(idx, priority=pr, kind="branch") for _ in range(2)]
-        return self._branch[key]
+    def _merged(self) -> bool:
+        """One grid per step for the three ResBlock branches of a stage (default); KNNSVC_MERGE_BRANCHES=0 / serial_resblocks():
+        one launch per branch."""
+        return self.merge_branches and not getattr(_SERIAL, "on", False)
 
     # -------------------------------------------------------------------------------------------
     def _conv(self, x, w, out, *, T_in, cin, cout, k, **kw):
@@ -152,7 +135,7 @@ class Vocoder:
             return self._forward(c, f0, harm)
         q = self.BUCKET_FRAMES
         Nb = -(-N // q) * q
-        key = Nb if self._par() else (Nb, "serial")
+        key = Nb if self._merged() else (Nb, "serial")
         from . import pipeline
         slot = pipeline.current_tail()          # tail stream index of the stream pipeline (0 outside one): graphs replayed from
         if slot:                                # different tail streams may overlap — one instance and one memory pool per tail
@@ -251,21 +234,13 @@ class Vocoder:
             return buf[:, ch:], buf.shape[1], self.side[level], cat_slot[n_up - 1 - level]
 
         # ---- head of the main path: input projection + conv_pre -> cat_pre[:, :uic] ------------------------
-        # It shares nothing with the side path below but the concat buffer's slot (both fold a maximum into it), and the side
-        # path — the synthesiser and eight short convolutions down to the frame rate, each a single wave of workgroups — is the
-        # critical path to the first stage: with free streams the head runs next to it (the ResBlock branches' fork / join).
+        # (It shares nothing with the side path below but the concat buffer's slot.  Round 3/4 ran it on a stream of its own next
+        #  to the side path (5.83 -> 5.70 ms); with the branch streams gone the generator is ONE stream again and the head simply
+        #  runs first.)
         s_x0, s_c = slot(), slot()
-
-        def head():
-            x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b, x_absmax=ops.absmax(c.contiguous(), s_c), out_absmax=s_x0, dyn=dyn)
-            self._conv(x0, self.pre_w, cat_pre, T_in=N, cin=x0.shape[1], cout=uic, k=7, m=N, pad=3, bias=self.pre_b,
-                       ldo=cat_pre.shape[1], x_absmax=s_x0, out_absmax=cat_pre_slot)
-        head_on = None
-        if self._par() and os.environ.get("KNNSVC_HEAD_FORK", "1") != "0":
-            head_on = self._branch_streams(dev)[0]
-            head_on.wait_event(torch.cuda.current_stream(dev).record_event())
-            with torch.cuda.stream(head_on):
-                head()
+        x0 = ops.linear(c.contiguous(), self.lin_w, self.lin_b, x_absmax=ops.absmax(c.contiguous(), s_c), out_absmax=s_x0, dyn=dyn)
+        self._conv(x0, self.pre_w, cat_pre, T_in=N, cin=x0.shape[1], cout=uic, k=7, m=N, pad=3, bias=self.pre_b,
+                   ldo=cat_pre.shape[1], x_absmax=s_x0, out_absmax=cat_pre_slot)
         # ---- excitation + sin_prenet -> res[0] -------------------------------------------------
         cond, ld0, c0, s0 = res_view(0)
         ops.additive_synth(f0.contiguous(), harm.contiguous() if self.kind == "mix" else None, self.prenet_w, self.prenet_b,
@@ -285,10 +260,6 @@ class Vocoder:
             self._conv(mid, rb["w"], dst, T_in=t_mid, cin=c_d, cout=c_d, k=3, m=lens[i + 1], pad=1, bias=rb["b"],
                        a_slope=LRELU, resid=mid, ldr=c_d, ldo=ld_d, x_absmax=s_mid, out_absmax=s_dst)
         # ---- main path ------------------------------------------------------------------------------
-        if head_on is None:
-            head()
-        else:
-            torch.cuda.current_stream(dev).wait_stream(head_on)
         x, s_x = new(N, uic), slot()
         self._conv(cat_pre, self.cpre_w, x, T_in=N, cin=cat_pre.shape[1], cout=uic, k=3, m=N, pad=1, bias=self.cpre_b,
                    x_absmax=cat_pre_slot, out_absmax=s_x)
@@ -340,31 +311,54 @@ class Vocoder:
 
             # Each branch writes its own output; knnsvc_mean3 takes (rb2 + (rb1 + rb0)) / 3 — the association of the reference's
             # running sum (xs += resblock(x); x = xs / num_kernels, ddsp_models.py:218-227) — and publishes the stage's range slot.
-            # The three ResBlocks (kernel sizes 3 / 7 / 11) only share their input: where few other streams are busy each runs on
-            # a stream of its own (forked from / joined into the current stream, also inside a graph capture), which fills the
-            # chip where one branch's launches do not — the first stage's convolutions are 470 blocks for 1024 slots — and overlaps
-            # the others' tails; inside the dataset-mode / serving pipelines they run one after the other (serial_resblocks).
-            # Same kernels, same buffers, same slots either way: the waveform does not depend on the mode.
+            # The three ResBlocks (kernel sizes 3 / 7 / 11) only share their input, and step m of one depends only on step m - 1
+            # of the same one: the launches of step m of ALL THREE are one grid (ops.conv_gemm_multi / ops.resblock_pair_multi:
+            # blockIdx.y = branch).  That fills the chip where one branch's launch does not — the first stage's convolutions are
+            # 470 workgroups for 768 slots — without any stream: rounds 3 and 4 ran the branches on three streams, and whether those
+            # overlapped was up to HIP's stream -> hardware-queue mapping (bench: 34.8 or 38.3 ms per step depending on how many
+            # streams the process had created before; off altogether under an RCCL group).  Same descriptors as the separate
+            # launches (serial_resblocks() runs those): the waveform does not depend on the mode.
             if nblk != 3:                            # other configurations: the running sum in the last epilogues, as round 2
                 for j, blk in enumerate(self.res[i]):
                     branch(j, blk, xs, s_xs, j > 0, float(nblk) if j == nblk - 1 else 1.0)
                 x, s_x, t_cur = xs, s_xs, t_out
                 continue
             outs = [new(t_out, cout) for _ in range(3)]
-            if self._par():
-                main = torch.cuda.current_stream(dev)
-                side = self._branch_streams(dev)
-                fork = main.record_event()
-                for j in (1, 2):                     # the side branches first: branch 0 follows on the caller's stream
-                    side[j - 1].wait_event(fork)
-                    with torch.cuda.stream(side[j - 1]):
-                        branch(j, self.res[i][j], outs[j], None, False, 1.0)
-                branch(0, self.res[i][0], outs[0], None, False, 1.0)
-                for st in side:
-                    main.wait_stream(st)
-            else:
+            if not self._merged():
                 for j, blk in enumerate(self.res[i]):
                     branch(j, blk, outs[j], None, False, 1.0)
+            else:
+                order = sorted(range(3), key=lambda j: -self.res[i][j]["k"])       # most taps first: workgroups are dispatched y-major
+                tmp = {j: (new(t_out, cout), new(t_out, cout), new(t_out, cout)) for j in range(3)}      # t1, ra, rb of each branch
+                state = {j: (xc, s_xc) for j in range(3)}
+                n_steps = len(self.res[i][0]["convs"])
+                assert all(len(b["convs"]) == n_steps for b in self.res[i])
+                for m in range(n_steps):
+                    pairs, c1s, c2s = [], [], []
+                    for j in order:
+                        blk = self.res[i][j]
+                        cv, kr = blk["convs"][m], blk["k"]
+                        d = cv["d"]
+                        t1, ra, rb_ = tmp[j]
+                        cur, s_cur = state[j]
+                        last = m == n_steps - 1
+                        dst = outs[j] if last else (ra if cur is not ra else rb_)
+                        s_dst = None if last else slot()
+                        if ops.resblock_pair_ok(cout, kr, d):
+                            ops.resblock_pair(cur, cv["w1"], cv["b1"], cv["w2"], cv["b2"], dst, t=t_out, channels=cout, taps=kr, dil=d,
+                                              slope=LRELU, x_absmax=s_cur, t1_bound=cv["t1_bound"], out_absmax=s_dst, dyn=self._dyn,
+                                              defer=pairs)
+                        else:
+                            self._conv(cur, cv["w1"], t1, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, dil=d,
+                                       pad=(kr * d - d) // 2, bias=cv["b1"], a_slope=LRELU, act=ops.ACT_LRELU, act_slope=LRELU,
+                                       x_absmax=s_cur, defer=c1s)
+                            self._conv(t1, cv["w2"], dst, T_in=t_out, cin=cout, cout=cout, k=kr, m=t_out, pad=(kr - 1) // 2,
+                                       bias=cv["b2"], resid=cur, ldr=cout, x_absmax=s_cur, x_bound=cv["t1_bound"], out_absmax=s_dst,
+                                       defer=c2s)
+                        state[j] = (dst, s_dst)
+                    ops.resblock_pair_multi(pairs)
+                    ops.conv_gemm_multi(c1s)
+                    ops.conv_gemm_multi(c2s)
             ops.mean3(outs[0], outs[1], outs[2], float(nblk), xs, out_absmax=s_xs, dyn=dyn)
             x, s_x, t_cur = xs, s_xs, t_out
         y = new(t_cur, 1)

@@ -1031,3 +1031,67 @@ def test_resblock_pair_equals_two_launches(C_, k, d):
     ob1, sb1 = one(xb, 8 * n_valid, sxb, dyn=(nd, 110))
     assert torch.equal(ob1[:8 * n_valid], ob2[:8 * n_valid]) and float(ob1[8 * n_valid:].abs().max()) == 0.0
     assert float(sb1.max()) == float(sb2.max())
+
+
+@pytest.mark.parametrize("C_,T", [(256, 3750), (128, 15000), (256, 1500), (64, 7000), (32, 9001)])
+def test_branches_in_one_grid_equal_one_launch_per_branch(C_, T):
+    """knnsvc_conv_gemm_multi / knnsvc_resblock_pair_multi: the launches of one step of a generator stage's three ResBlock
+    branches (kernel sizes 11 / 7 / 3, hifigan/ddsp_models.py:206-227) as ONE grid (blockIdx.y = branch) against one launch per
+    branch: same descriptors, same kernel body -> the same bits, outputs and range slots, for the windowed convolutions
+    (C = 128 / 256: both launches of a pair; whatever tile shape the merged grid's size selects) and for the fused pairs
+    (C = 32 / 64), also with a device-side length."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7 + C_)
+    x = (torch.randn(T, C_, generator=g) * 1.3).to(DEV)
+    sx = ops.absmax(x)
+    slope, d = 0.1, 3
+    br = []
+    for k in (11, 7, 3):
+        w1 = ops.attach_split(ops.pack_conv_weight(torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5).to(DEV))
+        w2 = ops.attach_split(ops.pack_conv_weight(torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5).to(DEV))
+        b1 = torch.randn(C_, generator=g).to(DEV); b2 = torch.randn(C_, generator=g).to(DEV)
+        bound = (float(w1.cpu().abs().sum(1).max()), float(b1.abs().max()))
+        br.append(dict(k=k, w1=w1, w2=w2, b1=b1, b2=b2, bound=bound))
+
+    def run(merged, dyn=None, rows=T):
+        outs, slots, names = [], [], []
+        c1, c2, pairs = [], [], []
+        t1s = [torch.full((rows, C_), float("nan"), device=DEV) for _ in br]
+        for b, t1 in zip(br, t1s):
+            out = torch.zeros(rows, C_, device=DEV); so = ops.new_slot(DEV)
+            k = b["k"]
+            if ops.resblock_pair_ok(C_, k, d):
+                ops.resblock_pair(x[:rows], b["w1"], b["b1"], b["w2"], b["b2"], out, t=rows, channels=C_, taps=k, dil=d, slope=slope, x_absmax=sx,
+                                  t1_bound=b["bound"], out_absmax=so, dyn=dyn, defer=pairs if merged else None)
+            else:
+                ops.conv_gemm(x[:rows], b["w1"], t1, m=rows, n=C_, cin=C_, taps=k, dil=d, pad=(k * d - d) // 2, t_in=rows, bias=b["b1"], a_slope=slope,
+                              act=ops.ACT_LRELU, act_slope=slope, x_absmax=sx, dyn=dyn, defer=c1 if merged else None)
+                if not merged:
+                    names.append(ops.last_conv_kernel())
+                ops.conv_gemm(t1, b["w2"], out, m=rows, n=C_, cin=C_, taps=k, pad=(k - 1) // 2, t_in=rows, bias=b["b2"], resid=x[:rows], ldr=C_,
+                              x_absmax=sx, x_bound=b["bound"], out_absmax=so, dyn=dyn, defer=c2 if merged else None)
+            outs.append(out); slots.append(so)
+        if merged:
+            ops.resblock_pair_multi(pairs)
+            ops.conv_gemm_multi(c1)
+            if c1:
+                names.append(ops.last_conv_kernel())
+            ops.conv_gemm_multi(c2)
+        torch.cuda.synchronize()
+        return outs, slots, names
+    a, sa, na = run(False)
+    b, sb, nb = run(True)
+    print(f"C = {C_}, T = {T}: per-branch kernels {na}, merged grid {nb}")
+    for j in range(3):
+        assert torch.equal(a[j], b[j]), (j, float((a[j] - b[j]).abs().max()))
+        assert float(sa[j].max()) == float(sb[j].max()) == float(a[j].abs().max())
+    if nb:
+        assert nb[0].endswith("x"), nb                    # the merged grid really was one launch of the windowed kernel
+    # bucketed: the same launches laid out for Tb rows with a device-side length
+    Tb = (T // 8) * 8
+    nd = torch.tensor([Tb // 8 - 3], device=DEV, dtype=torch.int32)
+    a, _sa, _ = run(False, dyn=(nd, Tb // 8), rows=Tb)
+    b, _sb, _ = run(True, dyn=(nd, Tb // 8), rows=Tb)
+    n_valid = 8 * (Tb // 8 - 3)
+    for j in range(3):
+        assert torch.equal(a[j][:n_valid], b[j][:n_valid])

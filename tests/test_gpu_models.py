@@ -342,6 +342,31 @@ def test_lane_pipeline_matches_sequential_order():
         assert torch.equal(a0 * 2.0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
 
 
+@pytest.mark.parametrize("kind", ["mix", "f0"])
+def test_generator_branches_in_one_grid_equal_one_launch_per_branch(kind):
+    """the three ResBlock branches of a stage run as ONE grid per step (no per-branch streams any more).  The
+    full-size generators, eager and through the bucketed hipGraph (ragged length), give the waveform of the
+    one-launch-per-branch form bit for bit, and creating unrelated streams first changes nothing (the round-4 headline depended
+    on how many streams the process had made before)."""
+    from knn_svc_amd.vocoder import Vocoder, serial_resblocks
+    h = C.HIFIGAN_V1
+    voc = Vocoder(S.seeded_state(S.generator_param_spec(h, kind), 2), h, kind, DEV)
+    g = torch.Generator().manual_seed(17)
+    dummies = [torch.cuda.Stream() for _ in range(3)]          # noqa: F841  (unrelated streams: must not matter)
+    for N in (150, 137):
+        c = torch.randn(N, 1024, generator=g).to(DEV)
+        harm = (torch.rand(N, 49, generator=g) * 0.02).to(DEV) if kind == "mix" else None
+        _, f0 = S.synth_clip(N * 320, 40 + N); f0 = torch.from_numpy(f0[:N].copy()).to(DEV)
+        with serial_resblocks():
+            ref = voc._forward(c, f0, harm).clone()
+        eager = voc._forward(c, f0, harm).clone()
+        assert torch.equal(ref, eager), float((ref - eager).abs().max())
+        for _ in range(3):                                        # first sight eager, capture, replay
+            y = voc.forward(c, f0, harm)
+        assert torch.equal(ref, y)
+    assert any(not (isinstance(k, tuple) and "serial" in k) for k in voc._graphs)
+
+
 def test_generators_on_three_tails_equal_one_generator():
     """The stream pipeline runs the tail of item i on tail stream i mod 3 when it has several lanes; the generator keeps one hipGraph
     instance (and one memory pool) per tail.  Seven utterances of three lengths through three tails — first sight (eager), capture
