@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 13
+#define KNNSVC_ABI_VERSION 14
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -237,6 +237,59 @@ int knnsvc_wavlm_attention(const float* qkv, const float* gate, const float* tab
 /* x[b, t, :] = 0 for t >= lens[b] on a [batches, T, dim] activation (row pitch ld): WavLM's `x[padding_mask] = 0`
  * (wavlm/WavLM.py:353, 574-575) in front of the positional convolution, for chunks padded up to a bucket length. */
 int knnsvc_mask_rows(float* x, int32_t batches, int32_t T, int32_t dim, int32_t ld, const int32_t* lens, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-model entry points (round 5): ONE call enqueues the layer sequence of a network on the caller's stream.
+ * A handle holds a copy of the descriptor — packed weights, their f16x2 splits and scales, LayerNorm vectors, the
+ * range plan decided at load — i.e. POINTERS to device memory the caller keeps alive until *_free; the library
+ * allocates nothing on the device and nothing at all inside the hot call (hipGraph-capturable), activations live in
+ * a caller-provided workspace.  The sequence is the one knn_svc_amd/wavlm.py issued launch by launch until round 4:
+ * same kernels, same arguments, same bits.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct knnsvc_weight {            /* a packed GEMM weight matrix [n, K] and its split (knnsvc_split_weight_f16x2) */
+    const float* w; const void* w_f16x2; float w_f16x2_scale; int32_t pad_;
+} knnsvc_weight;
+
+typedef struct knnsvc_wavlm_conv {        /* one layer of the conv feature extractor (wavlm/WavLM.py:401-419, 485-504) */
+    knnsvc_weight w;                      /* [dim, k * cin] (layer 0 with cin = 1: [dim, k], fp32 only)                  */
+    const float* ln_g; const float* ln_b; /* LayerNorm(dim) behind it (extractor_mode "layer_norm")                        */
+    int32_t dim, k, stride, cin;
+    int32_t out_split;                    /* the activation behind this layer may travel in the f16x2 split layout (load-time range plan) */
+    int32_t pad_;
+} knnsvc_wavlm_conv;
+
+typedef struct knnsvc_wavlm_layer {       /* TransformerSentenceEncoderLayer, layer_norm_first (wavlm/WavLM.py:691-714) */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    knnsvc_weight wqkv; const float* bqkv;          /* q | k | v fused: [3E, E]                                            */
+    knnsvc_weight wo;   const float* bo;
+    knnsvc_weight w1;   const float* b1;            /* fc1 [ffn, E] */
+    knnsvc_weight w2;   const float* b2;            /* fc2 [E, ffn] */
+    const float *gate_w, *gate_b, *grep_a;          /* grep_linear summed to [2, 64] / [2]; grep_a [H] (wavlm/modules.py:523-533) */
+    int32_t xn_split, xn2_split, h_split, attn_f16; /* range plan: which activations fit the fixed-scale split layout      */
+} knnsvc_wavlm_layer;
+
+typedef struct knnsvc_wavlm_desc {
+    int32_t n_conv; int32_t n_layers;
+    const knnsvc_wavlm_conv* conv; const knnsvc_wavlm_layer* layers;      /* HOST arrays, copied by knnsvc_wavlm_create    */
+    const float *ln_g, *ln_b; int32_t feats_split; int32_t pad_;          /* layer_norm over the extractor's output (WavLM.py:342) */
+    knnsvc_weight proj; const float* proj_b;                               /* post_extract_proj (:347-348)                  */
+    knnsvc_weight pos; const float* pos_b; int32_t pos_groups, pos_k;      /* pos_conv, weight norm folded, packed per group (:514-527) */
+    float pos_a_scale;                    /* fixed activation scale of the positional conv from the load-time bound (0: a range slot) */
+    int32_t E, H, ffn;
+    const float* layer_mix;               /* HOST [n_layers + 1] weights of a general layer weighting, NULL = the output of layer n_layers */
+} knnsvc_wavlm_desc;
+
+int knnsvc_wavlm_create(const knnsvc_wavlm_desc* d, void** handle);
+int knnsvc_wavlm_free(void* handle);
+/* frames of one chunk of L samples; bytes of workspace knnsvc_wavlm_encode needs for [batches, L] */
+int64_t knnsvc_wavlm_frames(const void* handle, int64_t L);
+size_t knnsvc_wavlm_workspace_bytes(const void* handle, int32_t batches, int64_t L);
+/* WavLM.extract_features up to layer n_layers (wavlm/WavLM.py:323-375, 572-612) for [batches, L] equal-length chunks:
+ * wav -> out [batches * T, E].  lens (may be NULL): DEVICE int32 [batches], valid frames per chunk (WavLM's padding mask:
+ * rows >= lens[b] zeroed in front of the positional conv, excluded as attention keys).  table: [H][2T - 1] relative
+ * position bias with the bucket LUT applied (host-built: wavlm/modules.py:417-455).  Everything is enqueued on `stream`. */
+int knnsvc_wavlm_encode(const void* handle, const float* wav, int32_t batches, int64_t L, const int32_t* lens,
+                        const float* table, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cosine-distance kNN (lib_ongaku_test.py:148-175 fast_cosine_dist + Tensor.topk(k, largest=False),

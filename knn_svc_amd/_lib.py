@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -54,6 +54,35 @@ class PairDesc(C.Structure):
     ]
 
 
+class Weight(C.Structure):
+    """struct knnsvc_weight"""
+    _fields_ = [("w", vp), ("w_f16x2", vp), ("w_f16x2_scale", f32), ("pad_", i32)]
+
+
+class WavlmConv(C.Structure):
+    """struct knnsvc_wavlm_conv"""
+    _fields_ = [("w", Weight), ("ln_g", vp), ("ln_b", vp), ("dim", i32), ("k", i32), ("stride", i32), ("cin", i32),
+                ("out_split", i32), ("pad_", i32)]
+
+
+class WavlmLayer(C.Structure):
+    """struct knnsvc_wavlm_layer"""
+    _fields_ = [("ln1_g", vp), ("ln1_b", vp), ("ln2_g", vp), ("ln2_b", vp),
+                ("wqkv", Weight), ("bqkv", vp), ("wo", Weight), ("bo", vp), ("w1", Weight), ("b1", vp), ("w2", Weight), ("b2", vp),
+                ("gate_w", vp), ("gate_b", vp), ("grep_a", vp),
+                ("xn_split", i32), ("xn2_split", i32), ("h_split", i32), ("attn_f16", i32)]
+
+
+class WavlmDesc(C.Structure):
+    """struct knnsvc_wavlm_desc"""
+    _fields_ = [("n_conv", i32), ("n_layers", i32), ("conv", C.POINTER(WavlmConv)), ("layers", C.POINTER(WavlmLayer)),
+                ("ln_g", vp), ("ln_b", vp), ("feats_split", i32), ("pad_", i32),
+                ("proj", Weight), ("proj_b", vp),
+                ("pos", Weight), ("pos_b", vp), ("pos_groups", i32), ("pos_k", i32),
+                ("pos_a_scale", f32), ("E", i32), ("H", i32), ("ffn", i32),
+                ("layer_mix", C.POINTER(f32))]
+
+
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "knnsvc_abi_version": (i32, []),
@@ -69,6 +98,11 @@ SIGNATURES = {
     "knnsvc_split_weight_f16x2": (i32, [vp, i64, i32, f32, vp, vp]),
     "knnsvc_split_f16x2_dyn": (i32, [vp, i64, i32, vp, vp, vp]),
     "knnsvc_absmax": (i32, [vp, i64, i32, i32, vp, vp]),
+    "knnsvc_wavlm_create": (i32, [C.POINTER(WavlmDesc), C.POINTER(vp)]),
+    "knnsvc_wavlm_free": (i32, [vp]),
+    "knnsvc_wavlm_frames": (i64, [vp, i64]),
+    "knnsvc_wavlm_workspace_bytes": (sz, [vp, i32, i64]),
+    "knnsvc_wavlm_encode": (i32, [vp, vp, i32, i64, vp, vp, vp, vp, sz, vp]),
     "knnsvc_layernorm": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp]),
     "knnsvc_wavlm_conv0": (i32, [vp, i32, i64, vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]),

@@ -80,19 +80,16 @@ def shard_rows(n_local: int, device) -> list:
 
 
 def all_gather_rows_var(t: torch.Tensor, counts=None) -> torch.Tensor:
-    """all_gather_rows for shards of DIFFERENT row counts (a real speaker pool rarely divides evenly).  RCCL: one
-    ``all_gather`` straight into per-rank VIEWS of the result (no padding, no re-concatenation: torch issues it as one grouped
-    collective for uneven sizes).  gloo (CPU tests, one-card rehearsal) cannot take uneven sizes: every rank pads to the largest
-    shard, one all-gather, the padding rows are dropped.  ``counts`` = shard_rows(...) if already known."""
+    """all_gather_rows for shards of DIFFERENT row counts (a real speaker pool rarely divides evenly): every rank pads to the
+    largest shard, ONE all_gather_into_tensor, the padding rows are dropped.  The same code on RCCL and on gloo — until round 4
+    the RCCL branch used ``dist.all_gather`` into uneven views, a form that had never executed anywhere (no multi-GPU node so
+    far); the padding costs at most one shard-size difference per rank (one 30 s clip: 6 MB) and the form below is the one
+    the gloo tests (world sizes 2 and 8) and the one-card rehearsals exercise.  ``counts`` = shard_rows(...) if already known."""
     if not (dist.is_available() and dist.is_initialized()):
         return t
     counts = counts if counts is not None else shard_rows(t.shape[0], t.device)
     if len(set(counts)) == 1:
         return all_gather_rows(t)
-    if dist.get_backend() == "nccl" and t.is_cuda:
-        out = torch.empty((int(sum(counts)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather(list(out.split([int(c) for c in counts], 0)), t.contiguous())
-        return out
     mx = max(counts)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t

@@ -57,6 +57,11 @@ def cat_rows(parts):
     return torch.as_strided(first, (rows, first.shape[1]), (first.shape[1], 1), first.storage_offset())
 
 
+def _lib_mod():
+    from . import _lib
+    return _lib
+
+
 def chunk_plan(n_samples: int, sr: int = C.SAMPLE_RATE, hop: int = C.HOP):
     """get_full_wavlm_features chunking (ddsp_prematch_dataset.py:275-293): 30 s windows, tails of
     <= 0.02*sr samples dropped, zero right-pad of hop - len % hop (a full hop when aligned)."""
@@ -143,6 +148,7 @@ class WavLMEncoder:
         self._graph_pool = None if not torch.cuda.is_available() else torch.cuda.graph_pool_handle()
         self.max_graphs = 32
         self.use_graphs = True
+        self._h = None             # (C-side model handle, the layer mix it was made for): _handle()
 
     # -------------------------------------------------------------------------------------------
     A2_LIMIT = 0.9 * 65504.0 / 16.0          # |x| an activation may reach in the fixed-scale (16) split layout
@@ -259,7 +265,95 @@ class WavLMEncoder:
         g.replay()
         return out.clone()
 
+    # -------------------------------------------------------------------------------------------
+    def _handle(self):
+        """The C-side model (knnsvc_wavlm_create: include/knnsvc_hip.h, "Whole-model entry points"): a copy of the descriptor —
+        pointers to THIS object's packed weights, the range plan, the layer mix — behind which ONE call enqueues the whole
+        layer sequence.  Rebuilt when the layer mix changes."""
+        key = self.layer_mix
+        if self._h is not None and self._h[1] == key:
+            return self._h[0]
+        self._free_handle()
+        import ctypes as Ct
+        from . import _lib
+        lib = _lib.load()
+        plan = self.plan
+
+        def W(t):
+            w = _lib.Weight()
+            w.w = t.data_ptr()
+            w2 = getattr(t, "_w2", None)
+            w.w_f16x2 = w2.data_ptr() if w2 is not None else None
+            w.w_f16x2_scale = float(getattr(t, "_w2_scale", 0.0)) if w2 is not None else 0.0
+            return w
+        convs = (_lib.WavlmConv * len(self.conv))()
+        for i, c in enumerate(self.conv):
+            convs[i].w = W(c["w"]); convs[i].ln_g = c["g"].data_ptr(); convs[i].ln_b = c["b"].data_ptr()
+            convs[i].dim, convs[i].k, convs[i].stride, convs[i].cin = c["dim"], c["k"], c["s"], c["cin"]
+            convs[i].out_split = 1 if plan["conv"][i] else 0
+        layers = (_lib.WavlmLayer * max(1, len(self.layers)))()
+        for i, (ly, pl) in enumerate(zip(self.layers, plan["layers"])):
+            L_ = layers[i]
+            for f_ in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "bqkv", "bo", "b1", "b2", "gate_w", "gate_b", "grep_a"):
+                setattr(L_, f_, ly[f_].data_ptr())
+            L_.wqkv, L_.wo, L_.w1, L_.w2 = W(ly["wqkv"]), W(ly["wo"]), W(ly["w1"]), W(ly["w2"])
+            L_.xn_split, L_.xn2_split, L_.h_split, L_.attn_f16 = (1 if pl[k_] else 0 for k_ in ("xn", "xn2", "h", "attn_f16"))
+        d = _lib.WavlmDesc()
+        d.n_conv, d.n_layers, d.conv, d.layers = len(self.conv), len(self.layers), convs, layers
+        d.ln_g, d.ln_b, d.feats_split = self.ln_g.data_ptr(), self.ln_b.data_ptr(), 1 if plan["feats"] else 0
+        d.proj, d.proj_b = W(self.proj_w), self.proj_b.data_ptr()
+        d.pos, d.pos_b, d.pos_groups, d.pos_k = W(self.pos_w), self.pos_b.data_ptr(), self.G, self.Kpos
+        pb = plan["bounds"]["proj"]
+        d.pos_a_scale = ops.pick_scale(pb) if (math.isfinite(pb) and 0.0 < pb < 1e30) else 0.0
+        d.E, d.H, d.ffn = self.E, self.H, (self.layers[0]["w1"].shape[0] if self.layers else 0)
+        mix = None
+        if self.layer_mix is not None:
+            mix = (Ct.c_float * (self.n_layers + 1))(*self.layer_mix)
+            d.layer_mix = mix
+        h = Ct.c_void_p()
+        ops.check(lib.knnsvc_wavlm_create(Ct.byref(d), Ct.byref(h)), "wavlm_create")
+        self._h = (h, key)
+        return h
+
+    def _free_handle(self):
+        if getattr(self, "_h", None) is not None:
+            from . import _lib
+            _lib.load().knnsvc_wavlm_free(self._h[0])
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._free_handle()
+        except Exception:
+            pass
+
+    def _handle_ok(self) -> bool:
+        """The one-call path covers the PRODUCT configuration; with any of the A/B switches set (another GEMM / attention mode,
+        range slots off, the fp32 layouts, a slot-scaled positional conv) or a debugging tap installed, the launch-by-launch
+        host sequence below runs instead — the same kernels with the same arguments."""
+        return (ops.gemm_mode() == "f16x2" and ops.attention_mode() == "f16x2" and ops.range_slots_on() and
+                os.environ.get("KNNSVC_A2", "1") != "0" and os.environ.get("KNNSVC_POS_SLOT") != "1" and
+                os.environ.get("KNNSVC_WAVLM_HOST_SEQ") != "1" and getattr(self, "_tap", None) is None)
+
     def _encode_batch(self, wav: torch.Tensor, lens: torch.Tensor | None = None) -> torch.Tensor:
+        if self._handle_ok():
+            # WavLM.extract_features (wavlm/WavLM.py:323-375) = ONE call into the library (knnsvc_wavlm_encode)
+            lib = _lib_mod().load()
+            B, L = wav.shape
+            h = self._handle()
+            T = int(lib.knnsvc_wavlm_frames(h, L))
+            out = torch.empty(B * T, self.E, device=wav.device, dtype=torch.float32)
+            nb = int(lib.knnsvc_wavlm_workspace_bytes(h, B, L))
+            ws = torch.empty(nb, device=wav.device, dtype=torch.uint8)
+            x = wav.contiguous()
+            ops.check(lib.knnsvc_wavlm_encode(h, x.data_ptr(), B, L, lens.data_ptr() if lens is not None else None,
+                                              self._table(T).data_ptr(), out.data_ptr(), ws.data_ptr(), nb, ops._stream()), "wavlm_encode")
+            return out.view(B, T, self.E)
+        return self._encode_batch_host(wav, lens)
+
+    def _encode_batch_host(self, wav: torch.Tensor, lens: torch.Tensor | None = None) -> torch.Tensor:
+        """The same forward, launch by launch from the host (rounds 1-4; kept for the A/B switches and as the reference the
+        one-call path is tested against: tests/test_gpu_models.py)."""
         B, L = wav.shape
         dev = wav.device
         x = wav.contiguous()

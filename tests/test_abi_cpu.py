@@ -143,3 +143,52 @@ def test_pool_store_disk_tier(tmp_path):
     pth = next((tmp_path / "store").glob("*.npz")); pth.write_bytes(b"garbage")
     c3 = pool_cache.PoolCache(budget_bytes=0, disk_dir=str(tmp_path / "store"))
     assert c3.get(("z",), dkey) is None
+
+
+def test_struct_layouts_match_the_header_as_a_c_compiler_sees_it(tmp_path):
+    """Every struct that crosses the boundary: sizeof and the offset of its last member as gcc lays the header out == what the
+    ctypes mirror in knn_svc_amd/_lib.py uses (a wrong field order or a missing pad shows up here, not as a corrupted launch)."""
+    import subprocess
+    from knn_svc_amd import _lib
+    pairs = [("knnsvc_conv_desc", _lib.ConvDesc), ("knnsvc_pair_desc", _lib.PairDesc), ("knnsvc_weight", _lib.Weight),
+             ("knnsvc_wavlm_conv", _lib.WavlmConv), ("knnsvc_wavlm_layer", _lib.WavlmLayer), ("knnsvc_wavlm_desc", _lib.WavlmDesc)]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "knnsvc_hip.h"\nint main(void) {\n'
+    for cname, st in pairs:
+        last = st._fields_[-1][0]
+        src += f'  printf("{cname} %zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));\n'
+    src += "  return 0;\n}\n"
+    (tmp_path / "l.c").write_text(src)
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(tmp_path / "l.c"), "-o", str(tmp_path / "l")], check=True)
+    out = subprocess.run([str(tmp_path / "l")], check=True, capture_output=True, text=True).stdout.split("\n")
+    for line, (cname, st) in zip(out, pairs):
+        name, size, off = line.split()
+        assert name == cname and int(size) == ctypes.sizeof(st) and int(off) == getattr(st, st._fields_[-1][0]).offset, (line, ctypes.sizeof(st))
+
+
+def test_wavlm_handle_host_side_without_a_gpu():
+    """knnsvc_wavlm_create / frames / workspace_bytes / free are host code: the frame law of the conv stack (G9: 480 320 padded
+    samples -> 1500 frames) and a workspace plan come out of the handle without touching a device; encode refuses a workspace
+    that is too small before it launches anything."""
+    from knn_svc_amd import _lib, config as C
+    lib = _lib.load()
+    convs = (_lib.WavlmConv * 7)()
+    for i, (dim, k, s) in enumerate(C.conv_layers(C.WAVLM_LARGE)):
+        convs[i].dim, convs[i].k, convs[i].stride, convs[i].cin, convs[i].out_split = dim, k, s, (1 if i == 0 else 512), 1
+        convs[i].w.w = 8; convs[i].ln_g = 8; convs[i].ln_b = 8          # (never dereferenced on the host)
+    layers = (_lib.WavlmLayer * 6)()
+    d = _lib.WavlmDesc()
+    d.n_conv, d.n_layers, d.conv, d.layers = 7, 6, convs, layers
+    d.ln_g = d.ln_b = 8; d.proj.w = 8; d.pos.w = 8; d.pos_groups, d.pos_k = 16, 128
+    d.E, d.H, d.ffn = 1024, 16, 4096
+    h = ctypes.c_void_p()
+    assert lib.knnsvc_wavlm_create(ctypes.byref(d), ctypes.byref(h)) == 0 and h.value
+    assert lib.knnsvc_wavlm_frames(h, 480320) == 1500 and lib.knnsvc_wavlm_frames(h, 16000 + 320) == 50
+    one, eight = lib.knnsvc_wavlm_workspace_bytes(h, 1, 480320), lib.knnsvc_wavlm_workspace_bytes(h, 8, 480320)
+    assert one > 96063 * 512 * 4 and 7 * one < eight < 8.5 * one             # the first conv layer's output dominates; linear in the batch
+    assert lib.knnsvc_wavlm_workspace_bytes(h, 1, 300) == 0                   # shorter than the receptive field
+    rc = lib.knnsvc_wavlm_encode(h, 256, 1, 480320, None, 256, 256, 256, 1024, None)
+    assert rc != 0 and b"workspace" in lib.knnsvc_last_error()
+    d.H = 15
+    h2 = ctypes.c_void_p()
+    assert lib.knnsvc_wavlm_create(ctypes.byref(d), ctypes.byref(h2)) != 0 and b"head_dim" in lib.knnsvc_last_error()
+    assert lib.knnsvc_wavlm_free(h) == 0

@@ -149,3 +149,62 @@ def test_sharded_knn_uneven_shards_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert out[0] and out[1]
+
+
+def _w8_worker(rank, ws, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from knn_svc_amd import dist as kd, synthetic as S
+    ok = True
+    # ---- bench.py --scaling strong at N = 8: 20 pool clips in contiguous, balanced shares (3, 3, 3, 3, 2, 2, 2, 2)
+    lo, hi = kd.contiguous_share(20)
+    clips = [3, 3, 3, 3, 2, 2, 2, 2]
+    ok = ok and hi - lo == clips[rank] and lo == sum(clips[:rank])
+    rows_per_clip = 150                                       # (1500 in the bench; the host logic does not depend on it)
+    counts = [c * rows_per_clip for c in clips]
+    pool = S.clustered_features(20 * rows_per_clip, 64, 9, n_centres=24)
+    mine = pool[lo * rows_per_clip:hi * rows_per_clip].contiguous()
+    ok = ok and kd.shard_rows(mine.shape[0], mine.device) == counts
+    q = S.clustered_features(40, 64, 777, n_centres=24)       # the replicated source
+    ri, rd = kd.sharded_knn(q, mine, 8, _cpu_local_topk, _cpu_merge, replicated=True, counts=counts)
+    fi, fd = _cpu_local_topk(q, pool, 8, 0)
+    ok = ok and bool(torch.equal(rd, fd)) and bool((ri == fi).float().mean() > 0.99)
+    for conv in range(10):                                     # the owner of a conversion's back half rotates over the ranks
+        g = kd.gather_rows_var(mine, counts, conv % ws)
+        ok = ok and ((g is None) if rank != conv % ws else bool(torch.equal(g, pool)))
+    ok = ok and bool(torch.equal(kd.all_gather_rows_var(mine, counts), pool))
+    # ---- BASELINE cfg 4's shape: a 45 000-row speaker pool in 8 uneven shards, every rank's own queries (weak form: all-to-all merge)
+    sizes = [5625 + d for d in (40, -40, 13, -13, 7, -7, 100, -100)]
+    assert sum(sizes) == 45000
+    big = S.clustered_features(45000, 32, 5, n_centres=40)
+    o = sum(sizes[:rank])
+    shard = big[o:o + sizes[rank]].contiguous()
+    qq = S.clustered_features(12, 32, 300 + rank, n_centres=40)
+    idx, d = kd.sharded_knn(qq, shard, 32, _cpu_local_topk, _cpu_merge)
+    ref_i, ref_d = _cpu_local_topk(qq, big, 32, 0)
+    ok = ok and bool(torch.equal(d, ref_d)) and bool((idx == ref_i).float().mean() > 0.99)
+    whole = kd.all_gather_rows_var(shard)                     # (counts read back: one tiny all-gather)
+    ok = ok and whole.shape == big.shape and bool(torch.equal(whole, big))
+    # independent units dealt round-robin (dataset mode's speaker pairs)
+    ok = ok and kd.my_share(list(range(19))) == list(range(rank, 19, 8))
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_world_size_8_uneven_strong_split_and_cfg4_pool_shape():
+    """VERDICT r4 #6a (first-run insurance for the 8-GPU node): the host logic of both scaling modes at world size 8 over
+    gloo — the uneven 20-clip strong split (3, 3, 3, 3, 2, 2, 2, 2) with replicated queries, the rotating owner's point-to-point
+    row gather, the padded uneven all-gather (the ONE form, also on RCCL), and cfg 4's 45 000-row pool in eight uneven shards with
+    per-rank queries and the all-to-all merge.  Every result equals the single-process one."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_w8_worker, args=(r, 8, port, out)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(out[r] for r in range(8)), dict(out)

@@ -226,3 +226,49 @@ def test_vocoder_bucket_graph_equals_exact_length():
             c, f0, harm, y = outs[111]
             ref = vocoder_ref.synthesizer(sd, hcfg, kind, c.cpu()[None], f0.cpu()[None, :, None], harm.cpu()[None])[0, 0]
             assert float((y.cpu() - ref).pow(2).mean().sqrt()) < 2e-6
+
+
+@pytest.mark.parametrize("ckpt_type,post_opt", [("mix", "post_opt_0.2"), ("wavlm_only", "no_post_opt")])
+def test_cfg1_cfg2_sample_pair_at_full_size_vs_oracle(tmp_path, monkeypatch, ckpt_type, post_opt):
+    """BASELINE cfg 2 (ckpt_type=mix, post_opt_0.2) and cfg 1's arguments (wavlm_only, no_post_opt; its `--device cpu` is the
+    oracle's side here) on the reference's own 60 s sample pair (Danakil -> Tiken, 3001 x 3001 frames,
+    ddsp_matcher.py:937-1023 special_match): WavLM-Large (6 layers) and the FULL generators — the additive-synth 'mix' one and
+    the sine-excitation 'f0' one (hifigan/ddsp_models_f0.py) — with seeded weights, through the product entry points
+    (hubconf.knn_vc + KNeighborsVC.special_match, files in -> file out).  The CPU oracle is given the GPU's features of both
+    clips (the encoder has its own full-size oracle tests) and restates everything behind them: 3001 x 3001 search, f0 shift,
+    re-rank, both concat re-selections and both Adam loops (mix) or the uniform weights (wavlm_only), weighted sums, additive
+    synth / sine source, generator.  Waveform within the north-star tolerance (1e-4 RMS)."""
+    import shutil
+    from pathlib import Path
+    from knn_svc_amd import audio_io, hubconf, matching
+    from oracle import pipeline_ref, vocoder_ref
+    fx = Path(__file__).parent / "golden" / "sample_content_full"
+    src, tgt = "Danakil-voice_resampled_16000_cut", "Tiken_lead_07_resampled_16000_cut"
+    for name in (src, tgt):
+        shutil.copy(fx / f"{name}.wav", tmp_path / f"{name}.wav")
+        shutil.copy(fx / f"{name}_f0.npy", tmp_path / f"{name}_f0.npy")
+    monkeypatch.setenv("KNNSVC_SEEDED_WEIGHTS", "1")
+    matching._POOL_CACHE = None
+    knn = hubconf.knn_vc(ckpt_type=ckpt_type, device="cuda", weights="seeded")
+    y = knn.special_match(str(tmp_path / f"{src}.wav"), str(tmp_path / f"{tgt}.wav"), ckpt_type=ckpt_type, post_opt=post_opt).cpu()
+    out_file = tmp_path / f"{src}_to_{tgt}_knn_{ckpt_type}_{post_opt}.wav"
+    assert out_file.is_file() and y.numel() == 3001 * 320
+    # the GPU's features of both clips (the pool store still holds them: nothing is encoded twice)
+    qp, _s, _a, _sp, qf0, _qh = matching.get_complete_spk_pool(tmp_path / f"{src}.wav", knn.wavlm, device=DEV)
+    pp, _s, _a, _sp, pf0, ph = matching.get_complete_spk_pool(tmp_path / f"{tgt}.wav", knn.wavlm, device=DEV)
+    c = lambda d: torch.cat(list(d.values())).cpu()
+    query, pool = dict(feats=c(qp), f0=c(qf0)), dict(feats=c(pp), f0=c(pf0), harm=c(ph))
+    assert query["feats"].shape == (3001, 1024) and pool["feats"].shape == (3001, 1024)
+    f0only = "wavlm_only" in ckpt_type
+    of, hw, sf0 = pipeline_ref.match(query, pool, ckpt_type, "no_post_opt" if f0only else post_opt)[:3]
+    kind = hubconf.generator_kind(ckpt_type)
+    sdg = S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, kind), seed=2)
+    ref = vocoder_ref.synthesizer(sdg, C.HIFIGAN_V1, kind, of[None], sf0[None, :, None], None if f0only else hw[None]).reshape(-1)
+    rms = float((y.double() - ref.double()).pow(2).mean().sqrt())
+    sig = float(ref.double().pow(2).mean().sqrt())
+    print(f"60 s sample pair, {ckpt_type} / {post_opt}: waveform rms vs oracle {rms:.2e} (signal rms {sig:.3f}, {kind} generator, 3001 frames)")
+    assert rms < 1e-4, rms
+    x, sr = audio_io.read_wav(str(out_file))                          # the file the call wrote: save_audio's scaling of the same samples
+    yy = y.numpy().astype(np.float64)
+    assert sr == 16000 and np.abs(x[0].astype(np.float64) - yy / max(1.0, float(np.abs(yy).max()))).max() < 1e-6
+    matching._POOL_CACHE = None

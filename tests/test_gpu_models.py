@@ -342,6 +342,48 @@ def test_lane_pipeline_matches_sequential_order():
         assert torch.equal(a0 * 2.0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
 
 
+@pytest.mark.parametrize("size", ["tiny", "large"])
+def test_wavlm_one_call_equals_the_host_sequenced_forward(size, monkeypatch):
+    """WavLM.extract_features (wavlm/WavLM.py:323-375) behind ONE C call (knnsvc_wavlm_encode: an opaque handle owns
+    the descriptor, the call enqueues the layer sequence) against the launch-by-launch host sequence of rounds 1-4 — same kernels,
+    same arguments: the same bits.  Exact-length batches, ragged batches with a device-side length mask, a general layer
+    weighting, and through the hipGraph cache; tiny config (fp32 layouts between the narrow conv layers: range slots + absmax
+    launches) and WavLM-Large (everything in the split layout)."""
+    from knn_svc_amd.wavlm import WavLMEncoder
+    cfg, nl = (C.WAVLM_TINY, 3) if size == "tiny" else (C.WAVLM_LARGE, 6)
+    enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(cfg, nl), seed=5), cfg, DEV, nl)
+    g = torch.Generator().manual_seed(3)
+    B, Tb = (3, 60) if size == "tiny" else (2, 150)
+    wav = (torch.randn(B, 320 * Tb + 80, generator=g) * 0.1).to(DEV)
+    lens = torch.tensor([Tb, Tb - 7, Tb - 31][:B], dtype=torch.int32, device=DEV)
+
+    def both(lens_, graphs=False):
+        monkeypatch.setenv("KNNSVC_WAVLM_HOST_SEQ", "1")
+        ref = enc._encode_batch(wav, lens_).clone()
+        monkeypatch.delenv("KNNSVC_WAVLM_HOST_SEQ")
+        assert enc._handle_ok()
+        one = enc._encode_batch(wav, lens_).clone()
+        assert torch.equal(ref, one), float((ref - one).abs().max())
+        if graphs:
+            for _ in range(3):                       # first sight eager, capture, replay
+                y = enc.encode_batch(wav, lens_)
+            assert torch.equal(ref, y)
+        return ref
+    a = both(None, graphs=True)
+    b = both(lens, graphs=True)
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])          # the mask does something, and only to the masked rows' batch entries
+    mix = [0.0] * (nl + 1); mix[1], mix[nl] = 0.25, 0.75
+    enc.set_layer_mix(mix)
+    c = both(lens)
+    assert not torch.equal(b, c)
+    enc.set_layer_mix(None)
+    assert torch.equal(both(lens), b)
+    import ctypes
+    from knn_svc_amd import _lib
+    h = enc._handle()
+    assert int(_lib.load().knnsvc_wavlm_frames(h, wav.shape[1])) == Tb
+
+
 @pytest.mark.parametrize("kind", ["mix", "f0"])
 def test_generator_branches_in_one_grid_equal_one_launch_per_branch(kind):
     """the three ResBlock branches of a stage run as ONE grid per step (no per-branch streams any more).  The
