@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 14
+#define KNNSVC_ABI_VERSION 15
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -290,6 +290,41 @@ size_t knnsvc_wavlm_workspace_bytes(const void* handle, int32_t batches, int64_t
  * position bias with the bucket LUT applied (host-built: wavlm/modules.py:417-455).  Everything is enqueued on `stream`. */
 int knnsvc_wavlm_encode(const void* handle, const float* wav, int32_t batches, int64_t L, const int32_t* lens,
                         const float* table, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The conditioned HiFi-GAN generator behind one call: SynthesizerTrn.forward + Generator.forward
+ * (hifigan/ddsp_models.py:108-233, 405-493 'mix'; hifigan/ddsp_models_f0.py:106-216, 320-381 'f0').  Weights are
+ * packed as knn_svc_amd/vocoder.py packs them (weight norm folded; conv [Cout, k*Cin]; transposed conv [u*Cout, (k/u)*Cin]),
+ * each with its f16x2 split.  Three ResBlocks per stage (resblock_kernel_sizes has three entries), three dilations each. */
+typedef struct knnsvc_gen_pair {          /* one iteration of ResBlock1.forward (hifigan/ddsp_models.py:13-44) */
+    knnsvc_weight w1; const float* b1; knnsvc_weight w2; const float* b2;
+    int32_t dil; float t1_bound_mul, t1_bound_add;   /* |convs1(lrelu(x)) + b1| <= mul * max|x| + add (from the weights, at load) */
+    int32_t pad_;
+} knnsvc_gen_pair;
+typedef struct knnsvc_gen_stage {
+    knnsvc_weight up; const float* up_b; int32_t u, k, cin, cout;      /* ups[i]: ConvTranspose1d(cin -> cout, k, stride u)            */
+    knnsvc_weight ccv;                                                 /* concat_conv[i] (k = 3, no bias)                               */
+    int32_t res_k[3]; int32_t pad_; knnsvc_gen_pair res[3][3];         /* resblocks[3 i + j]: kernel size res_k[j], pairs res[j][0..2]  */
+    knnsvc_weight down; const float* down_b; int32_t down_k, down_u;   /* downs[i]: strided conv of the side path                       */
+    knnsvc_weight rbd; const float* rbd_b;                             /* resblocks_downs[i].convs[0] (k = 3)                           */
+} knnsvc_gen_stage;
+typedef struct knnsvc_generator_desc {
+    int32_t kind;                         /* 0 = 'mix' (additive-synth excitation, harmonic amplitudes), 1 = 'f0' (sine excitation) */
+    int32_t n_up, hop, sample_rate, n_harm_in, uic, hubert_dim, hifi_dim;      /* lin_pre: hubert_dim -> hifi_dim; conv_pre: hifi_dim -> uic */
+    int32_t side[8];                      /* channels of the side path's levels: side[0] = condition, side[i + 1] = output of down stage i */
+    knnsvc_weight lin; const float* lin_b; knnsvc_weight pre; const float* pre_b;       /* lin_pre, conv_pre (k = 7)              */
+    knnsvc_weight cpre; const float* cpre_b; knnsvc_weight post;                        /* concat_pre (k = 3), conv_post (k = 7)  */
+    const float *prenet_w, *prenet_b;                                                   /* sin_prenet: Conv1d(1 -> side[0], 3)     */
+    const knnsvc_gen_stage* stages;       /* HOST array [n_up], copied by knnsvc_generator_create */
+} knnsvc_generator_desc;
+
+int knnsvc_generator_create(const knnsvc_generator_desc* d, void** handle);
+int knnsvc_generator_free(void* handle);
+size_t knnsvc_generator_workspace_bytes(const void* handle, int64_t frames);
+/* c [frames, hubert_dim], f0 [frames], harm [frames, n_harm_in] (NULL for kind 1) -> out [frames * hop].  n_dyn (may be NULL):
+ * DEVICE int32 holding the valid frame count <= frames — the launch sequence is laid out for `frames` (a length bucket) and
+ * computes exactly what an exact-length run computes (knnsvc_conv_desc, "Dynamic length").  Enqueues only; capturable. */
+int knnsvc_generator_forward(const void* handle, const float* c, const float* f0, const float* harm, int64_t frames,
+                             const int32_t* n_dyn, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cosine-distance kNN (lib_ongaku_test.py:148-175 fast_cosine_dist + Tensor.topk(k, largest=False),

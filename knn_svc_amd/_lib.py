@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -83,6 +83,30 @@ class WavlmDesc(C.Structure):
                 ("layer_mix", C.POINTER(f32))]
 
 
+class GenPair(C.Structure):
+    """struct knnsvc_gen_pair"""
+    _fields_ = [("w1", Weight), ("b1", vp), ("w2", Weight), ("b2", vp), ("dil", i32), ("t1_bound_mul", f32), ("t1_bound_add", f32), ("pad_", i32)]
+
+
+class GenStage(C.Structure):
+    """struct knnsvc_gen_stage"""
+    _fields_ = [("up", Weight), ("up_b", vp), ("u", i32), ("k", i32), ("cin", i32), ("cout", i32),
+                ("ccv", Weight),
+                ("res_k", i32 * 3), ("pad_", i32), ("res", (GenPair * 3) * 3),
+                ("down", Weight), ("down_b", vp), ("down_k", i32), ("down_u", i32),
+                ("rbd", Weight), ("rbd_b", vp)]
+
+
+class GeneratorDesc(C.Structure):
+    """struct knnsvc_generator_desc"""
+    _fields_ = [("kind", i32), ("n_up", i32), ("hop", i32), ("sample_rate", i32), ("n_harm_in", i32), ("uic", i32), ("hubert_dim", i32), ("hifi_dim", i32),
+                ("side", i32 * 8),
+                ("lin", Weight), ("lin_b", vp), ("pre", Weight), ("pre_b", vp),
+                ("cpre", Weight), ("cpre_b", vp), ("post", Weight),
+                ("prenet_w", vp), ("prenet_b", vp),
+                ("stages", C.POINTER(GenStage))]
+
+
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
     "knnsvc_abi_version": (i32, []),
@@ -103,6 +127,10 @@ SIGNATURES = {
     "knnsvc_wavlm_frames": (i64, [vp, i64]),
     "knnsvc_wavlm_workspace_bytes": (sz, [vp, i32, i64]),
     "knnsvc_wavlm_encode": (i32, [vp, vp, i32, i64, vp, vp, vp, vp, sz, vp]),
+    "knnsvc_generator_create": (i32, [C.POINTER(GeneratorDesc), C.POINTER(vp)]),
+    "knnsvc_generator_free": (i32, [vp]),
+    "knnsvc_generator_workspace_bytes": (sz, [vp, i64]),
+    "knnsvc_generator_forward": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, sz, vp]),
     "knnsvc_layernorm": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp]),
     "knnsvc_wavlm_conv0": (i32, [vp, i32, i64, vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "knnsvc_wavlm_gate": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]),

@@ -104,6 +104,7 @@ class Vocoder:
         self.max_graphs = 48            # (bucket, mode) instances PER tail stream (Vocoder._evict)
         self.use_graphs = True
         self.merge_branches = os.environ.get("KNNSVC_MERGE_BRANCHES", "1") != "0"
+        self._h = None             # C-side model handle (_handle())
 
     def _merged(self) -> bool:
         """One grid per step for the three ResBlock branches of a stage (default); KNNSVC_MERGE_BRANCHES=0 / serial_resblocks():
@@ -191,8 +192,89 @@ class Vocoder:
             extra -= 1
             hard -= 1
 
+    # -------------------------------------------------------------------------------------------
+    def _handle(self):
+        """The C-side model (knnsvc_generator_create, include/knnsvc_hip.h "Whole-model entry points"): pointers to THIS object's
+        packed weights behind which one call enqueues the whole launch sequence."""
+        if self._h is not None:
+            return self._h
+        import ctypes as Ct
+        from . import _lib
+
+        def W(t):
+            w = _lib.Weight()
+            w.w = t.data_ptr()
+            w2 = getattr(t, "_w2", None)
+            w.w_f16x2 = w2.data_ptr() if w2 is not None else None
+            w.w_f16x2_scale = float(getattr(t, "_w2_scale", 0.0)) if w2 is not None else 0.0
+            return w
+        h = self.h
+        stages = (_lib.GenStage * self.n_up)()
+        for i in range(self.n_up):
+            st, up, dn, rb = stages[i], self.ups[i], self.downs[i], self.rbd[i]
+            st.up, st.up_b, st.u, st.k, st.cin, st.cout = W(up["w"]), up["b"].data_ptr(), up["u"], up["k"], up["cin"], up["cout"]
+            st.ccv = W(self.ccv[i])
+            for j, blk in enumerate(self.res[i]):
+                st.res_k[j] = blk["k"]
+                for m, cv in enumerate(blk["convs"]):
+                    pr = st.res[j][m]
+                    pr.w1, pr.b1, pr.w2, pr.b2, pr.dil = W(cv["w1"]), cv["b1"].data_ptr(), W(cv["w2"]), cv["b2"].data_ptr(), cv["d"]
+                    pr.t1_bound_mul, pr.t1_bound_add = float(cv["t1_bound"][0]), float(cv["t1_bound"][1])
+            st.down, st.down_b, st.down_k, st.down_u = W(dn["w"]), dn["b"].data_ptr(), dn["k"], dn["u"]
+            st.rbd, st.rbd_b = W(rb["w"]), rb["b"].data_ptr()
+        d = _lib.GeneratorDesc()
+        d.kind, d.n_up, d.hop, d.sample_rate = (0 if self.kind == "mix" else 1), self.n_up, self.hop, self.sr
+        d.n_harm_in, d.uic, d.hubert_dim, d.hifi_dim = 49, self.uic, self.lin_w.shape[1], self.lin_w.shape[0]
+        for i, v in enumerate(self.side):
+            d.side[i] = v
+        d.lin, d.lin_b, d.pre, d.pre_b = W(self.lin_w), self.lin_b.data_ptr(), W(self.pre_w), self.pre_b.data_ptr()
+        d.cpre, d.cpre_b, d.post = W(self.cpre_w), self.cpre_b.data_ptr(), W(self.post_w)
+        d.prenet_w, d.prenet_b = self.prenet_w.data_ptr(), self.prenet_b.data_ptr()
+        d.stages = stages
+        hd = Ct.c_void_p()
+        ops.check(_lib.load().knnsvc_generator_create(Ct.byref(d), Ct.byref(hd)), "generator_create")
+        self._h = hd
+        return hd
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                from . import _lib
+                _lib.load().knnsvc_generator_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _handle_ok(self) -> bool:
+        """The one-call path covers the PRODUCT configuration (f16x2 GEMMs with range slots, fused pairs at C = 32 / 64, three
+        ResBlocks of three pairs per stage, branches as one grid); any A/B switch sends the forward down the host sequence."""
+        return (self._merged() and ops.gemm_mode() == "f16x2" and ops.range_slots_on() and not ops._SLOT_DBG and
+                os.environ.get("KNNSVC_FUSED_PAIR", "1") != "0" and os.environ.get("KNNSVC_FUSED_PAIR_128", "0") != "1" and
+                os.environ.get("KNNSVC_VOCODER_HOST_SEQ") != "1" and
+                all(len(blocks) == 3 and all(len(b["convs"]) == 3 for b in blocks) for blocks in self.res))
+
     def _forward(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None, n_dyn: torch.Tensor | None = None) -> torch.Tensor:
-        """``n_dyn`` (device int32 [1], <= N): the valid frame count of a forward laid out for N = a bucket's frames."""
+        """``n_dyn`` (device int32 [1], <= N): the valid frame count of a forward laid out for N = a bucket's frames.
+        SynthesizerTrn.forward + Generator.forward = ONE call into the library (knnsvc_generator_forward)."""
+        if not self._handle_ok() or (self.kind == "mix" and (harm is None or harm.shape[1] != 49)):
+            return self._forward_host(c, f0, harm, n_dyn)
+        from . import _lib
+        lib = _lib.load()
+        hd = self._handle()
+        N = c.shape[0]
+        out = torch.empty(N * self.hop, device=c.device, dtype=torch.float32)
+        nb = int(lib.knnsvc_generator_workspace_bytes(hd, N))
+        ws = torch.empty(nb, device=c.device, dtype=torch.uint8)
+        cc, ff = c.contiguous(), f0.contiguous()
+        hh = harm.contiguous() if (self.kind == "mix") else None
+        ops.check(lib.knnsvc_generator_forward(hd, cc.data_ptr(), ff.data_ptr(), hh.data_ptr() if hh is not None else None, N,
+                                               n_dyn.data_ptr() if n_dyn is not None else None, out.data_ptr(), ws.data_ptr(), nb, ops._stream()),
+                  "generator_forward")
+        return out
+
+    def _forward_host(self, c: torch.Tensor, f0: torch.Tensor, harm: torch.Tensor | None = None, n_dyn: torch.Tensor | None = None) -> torch.Tensor:
+        """The same forward, launch by launch from the host (rounds 1-4; kept for the A/B switches and as the reference the one-call
+        path is tested against)."""
         dev = c.device
         N = c.shape[0]
         dyn = self._dyn = None if n_dyn is None else (n_dyn, N)

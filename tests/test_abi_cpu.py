@@ -151,7 +151,8 @@ def test_struct_layouts_match_the_header_as_a_c_compiler_sees_it(tmp_path):
     import subprocess
     from knn_svc_amd import _lib
     pairs = [("knnsvc_conv_desc", _lib.ConvDesc), ("knnsvc_pair_desc", _lib.PairDesc), ("knnsvc_weight", _lib.Weight),
-             ("knnsvc_wavlm_conv", _lib.WavlmConv), ("knnsvc_wavlm_layer", _lib.WavlmLayer), ("knnsvc_wavlm_desc", _lib.WavlmDesc)]
+             ("knnsvc_wavlm_conv", _lib.WavlmConv), ("knnsvc_wavlm_layer", _lib.WavlmLayer), ("knnsvc_wavlm_desc", _lib.WavlmDesc),
+             ("knnsvc_gen_pair", _lib.GenPair), ("knnsvc_gen_stage", _lib.GenStage), ("knnsvc_generator_desc", _lib.GeneratorDesc)]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "knnsvc_hip.h"\nint main(void) {\n'
     for cname, st in pairs:
         last = st._fields_[-1][0]

@@ -401,7 +401,10 @@ def test_generator_branches_in_one_grid_equal_one_launch_per_branch(kind):
         _, f0 = S.synth_clip(N * 320, 40 + N); f0 = torch.from_numpy(f0[:N].copy()).to(DEV)
         with serial_resblocks():
             ref = voc._forward(c, f0, harm).clone()
-        eager = voc._forward(c, f0, harm).clone()
+        host = voc._forward_host(c, f0, harm).clone()             # merged grids, sequenced from the host
+        assert torch.equal(ref, host), float((ref - host).abs().max())
+        assert voc._handle_ok()
+        eager = voc._forward(c, f0, harm).clone()                 # the same sequence behind ONE C call (knnsvc_generator_forward)
         assert torch.equal(ref, eager), float((ref - eager).abs().max())
         for _ in range(3):                                        # first sight eager, capture, replay
             y = voc.forward(c, f0, harm)
