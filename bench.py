@@ -168,7 +168,6 @@ class stage:
             STAGES.setdefault(self.name, []).append((self.e0, e1))
 
 
-_FRONT_SIDE = {}
 _CONV = [0]                            # conversions started so far (the same count on every rank): who owns the next back half
 
 
@@ -177,9 +176,8 @@ def step_front(enc, src, sf0, pool_w, pool_f0, max_batch):
     # The encoder is enqueued first (its first kernels are long, so the host runs ahead); STFT / harmonic
     # amplitudes only need the raw audio and run on a second stream next to it.
     main = torch.cuda.current_stream()
-    if src.device not in _FRONT_SIDE:                    # (created once: `setdefault(..., Stream())` took a pool stream per step)
-        _FRONT_SIDE[src.device] = torch.cuda.Stream(device=src.device)
-    side = _FRONT_SIDE[src.device]
+    from knn_svc_amd.matching import _side_stream
+    side = _side_stream(src.device)                      # the partner stream of whatever stream the front half runs on (created once per stream)
     side.wait_stream(main)
     with stage("wavlm"):
         feats = enc.encode_many(pool_w + [src], max_batch=max_batch)
@@ -467,6 +465,13 @@ def main():
     if STRONG and ws > POOL_CLIPS:
         raise SystemExit(f"--scaling strong splits {POOL_CLIPS} pool clips: at most {POOL_CLIPS} ranks")
 
+    # KNNSVC_BENCH_DUMMY_STREAMS=n (A/B aid): n unrelated streams made and used once before anything else — round 4's headline moved by
+    # +-8 % with the NUMBER of streams a process had created before (HIP's stream -> hardware-queue mapping: profiles/r04_rank1_rccl_ab.txt);
+    # since round 5 the generator needs no streams of its own and the figure must not care (profiles/r05_stream_robustness_ab.txt)
+    _dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("KNNSVC_BENCH_DUMMY_STREAMS", "0")))]
+    for _s in _dummies:
+        with torch.cuda.stream(_s):
+            torch.zeros(8, device=dev)
     enc = WavLMEncoder(S.seeded_state(S.wavlm_param_spec(C.WAVLM_LARGE, 6), seed=1), C.WAVLM_LARGE, dev, 6)
     voc = Vocoder(S.seeded_state(S.generator_param_spec(C.HIFIGAN_V1, "mix"), seed=2), C.HIFIGAN_V1, "mix", dev)
     src, sf0, pool_w, pool_f0 = make_inputs(rank, dev)

@@ -31,7 +31,7 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 15
+#define KNNSVC_ABI_VERSION 16
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
@@ -42,6 +42,10 @@ const char* knnsvc_conv_gemm_last_kernel(void);
  * KNNSVC_WIN160, KNNSVC_GEMM_SMALL) are read from the environment once, at the first launch; this re-reads them (tests and A/B
  * runs that switch a route inside one process). */
 int knnsvc_reload_knobs(void);
+/* Stream-placement probe: `blocks` one-wave workgroups that spin for `spin` shader-clock ticks each (nothing is read or written).
+ * The host side (knn_svc_amd/pipeline.py) times it on two streams at once to MEASURE whether they share a hardware queue or
+ * dispatch pipe, instead of trusting the stream -> queue mapping. */
+int knnsvc_probe_dispatch(int32_t blocks, int32_t spin, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer on fp32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -147,6 +147,7 @@ SIGNATURES = {
     "knnsvc_log_f0_median": (i32, [vp, i64, vp, vp, vp]),
     "knnsvc_shift_f0": (i32, [vp, i64, vp, vp, vp, vp]),
     "knnsvc_reload_knobs": (i32, []),
+    "knnsvc_probe_dispatch": (i32, [i32, i32, vp]),
     "knnsvc_f0_rerank": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "knnsvc_concat_reselect": (i32, [vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, i32, f32, vp, vp]),
     "knnsvc_smooth_workspace_bytes": (sz, [i64]),

@@ -212,7 +212,13 @@ def _side_stream(device) -> "torch.cuda.Stream":
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     if key not in _SIDE:
         from .pipeline import new_stream
-        _SIDE[key] = new_stream(idx, priority=torch.cuda.current_stream(idx).priority, kind="partner")
+        cur = torch.cuda.current_stream(idx)
+        # a partner has to run BESIDE its stream — and beside the lanes, tails and other partners: measured at creation
+        # (pipeline.new_stream, overlap_with="all"), not left to the stream -> hardware-queue mapping
+        from . import pipeline
+        pipeline._KNOWN[:] = [e for e in pipeline._KNOWN if e[0] is None or e[0]() is not None]
+        lanes_tails = [st for _o, k, st in pipeline._KNOWN if k in ("lane", "tail") and st.device.index == idx]
+        _SIDE[key] = new_stream(idx, priority=cur.priority, kind="partner", overlap_with="all", must=[cur] + lanes_tails)
     return _SIDE[key]
 
 
@@ -238,7 +244,7 @@ def _knn_stream(device) -> "torch.cuda.Stream":
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _KNN_STREAMS:
         from .pipeline import new_stream
-        _KNN_STREAMS[key] = new_stream(device, kind="knn")
+        _KNN_STREAMS[key] = new_stream(device, kind="knn", overlap_with="all")
     return _KNN_STREAMS[key]
 
 

@@ -54,13 +54,92 @@ HIPRI_QUEUES = 4
 _STREAMS = []                      # (owner or None, priority, kind): owner = weak reference to the LanePipeline that made it
 
 
-def new_stream(device, priority: int = 0, kind: str = "", owner=None) -> "torch.cuda.Stream":
+_PROBE = {"alone_ms": {}, "tries": 0, "rejected": 0, "log": []}
+_KNOWN = []                        # (owner weakref or None, kind, stream): the package's live streams, for overlap_with="all"
+PROBE_BLOCKS, PROBE_SPIN = 200_000, 2000          # the probe launch: 200 000 one-wave workgroups spinning ~1 us each (~47 us alone)
+
+
+def _probe_launch(streams, device) -> float:
+    """ms from the first launch's start to the last one's end: one dispatch-bound probe launch (knnsvc_probe_dispatch) per stream."""
+    from . import _lib
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        for st in streams:
+            st.synchronize()
+        ev = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                lib.knnsvc_probe_dispatch(PROBE_BLOCKS, PROBE_SPIN, st.cuda_stream)
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                ev.append((e0, e1))
+        for st in streams:
+            st.synchronize()
+        return max(ev[0][0].elapsed_time(e1) for _e0, e1 in ev)
+
+
+def stream_contention(a, b, device) -> float:
+    """How badly do streams a and b get in each other's way?  -> (time of one dispatch-bound launch on EACH, started together) /
+    (time of one alone).  HIP maps streams onto a few hardware queues, and which streams share a queue — or a dispatch pipe — is an
+    accident of how many streams the PROCESS has made before: round 4's bench step moved between 34.8 and 38.3 ms with it
+    (profiles/r04_rank1_rccl_ab.txt), round 5's — without the generator's branch streams — still between 34.8 and 38.5
+    (profiles/r05_stream_robustness_ab_before_probe.txt).  So it is MEASURED.  Three classes show up on MI355X (47 us alone):
+    ~1.5 (70 us: side by side), ~2.1 (98 us: one hardware queue, strictly one after the other — a single-thread spin kernel on each
+    shows the same pairs) and ~3 (140-150 us: they overlap, but their workgroup dispatch collides: a pair like that — encoder lane
+    against the match stage's partner stream — is what the 37 ms placements had and the 34.5 ms ones did not)."""
+    key = (torch.device(device).index, PROBE_BLOCKS)
+    if key not in _PROBE["alone_ms"]:
+        _probe_launch([b], device)                       # (first launch: code object load)
+        _PROBE["alone_ms"][key] = min(_probe_launch([b], device) for _ in range(3))
+    alone = _PROBE["alone_ms"][key]
+    together = _probe_launch([a, b], device)
+    return together / alone
+
+
+CONTENTION_OK = 1.75               # between the "side by side" (~1.5) and the "one queue" (~2.1) classes
+
+
+def new_stream(device, priority: int = 0, kind: str = "", owner=None, overlap_with=(), must=()) -> "torch.cuda.Stream":
     """Every stream of the package.  Streams made for a LanePipeline count while that pipeline is alive (weak reference to the
     PIPELINE — torch's stream objects themselves do not survive being weakly referenced: the process dies in the garbage
-    collector); all others are cached for the life of the process by their makers."""
+    collector); all others are cached for the life of the process by their makers.
+    ``overlap_with``: streams whose kernels this one has to run BESIDE — a list, or "all" = the package's live lane / tail / partner /
+    kNN streams on the device.  torch hands out pool streams round-robin and HIP maps them onto hardware queues; a candidate whose
+    measured contention (stream_contention) with any listed stream is above CONTENTION_OK is set aside and the next pool stream is
+    tried, up to 16; if none passes, the least contended candidate is taken — least against ``must`` first (the streams that
+    matter most: a partner's own stream, the lanes and tails), then against the rest.  KNNSVC_STREAM_PROBE=0: the first pool
+    stream, unmeasured."""
+    import os
     import weakref
     s = torch.cuda.Stream(device=device, priority=priority)
+    if isinstance(overlap_with, str):
+        idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        _KNOWN[:] = [e for e in _KNOWN if e[0] is None or e[0]() is not None]
+        overlap_with = [st for _o, k, st in _KNOWN if st.device.index == idx and k in ("lane", "tail", "partner", "knn")]
+    must = [m for m in must if m is not None]
+    rest = [o for o in overlap_with if not any(o.cuda_stream == m.cuda_stream for m in must)]
+    if (must or rest) and os.environ.get("KNNSVC_STREAM_PROBE", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        best = None
+        klass = lambda r: 0 if r <= CONTENTION_OK else (1 if r <= 2.4 else 2)       # side by side / one queue / colliding dispatch
+        for _try in range(16):
+            _PROBE["tries"] += 1
+            w_must = max((stream_contention(o, s, device) for o in must), default=0.0)
+            w_rest = max((stream_contention(o, s, device) for o in rest), default=0.0)
+            score = (klass(w_must), klass(w_rest), w_must, w_rest)
+            _PROBE["log"].append((kind, int(priority), round(w_must, 2), round(w_rest, 2)))
+            if best is None or score < best[0]:
+                best = (score, s)
+            if score[:2] == (0, 0):
+                break
+            _PROBE["rejected"] += 1
+            s = torch.cuda.Stream(device=device, priority=priority)
+        s = best[1]
+        if os.environ.get("KNNSVC_STREAM_PROBE_LOG") == "1":
+            import sys
+            print(f"[stream probe] {kind} stream (priority {priority}): contention {best[0][2]:.2f} against its {len(must)} partner / lane / tail stream(s), "
+                  f"{best[0][3]:.2f} against {len(rest)} other(s), after {_try + 1} candidate(s)", file=sys.stderr)
     _STREAMS.append((weakref.ref(owner) if owner is not None else None, int(priority), kind))
+    _KNOWN.append((weakref.ref(owner) if owner is not None else None, kind, s))
     return s
 
 
@@ -113,7 +192,9 @@ class LanePipeline:
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         self.device = torch.device(device)
-        self.lanes = [new_stream(self.device, kind="lane", owner=self) for _ in range(lanes)]
+        self.lanes = []
+        for _ in range(lanes):          # every stream of the pipeline has to overlap with every other one: measured, not assumed (new_stream)
+            self.lanes.append(new_stream(self.device, kind="lane", owner=self, overlap_with="all", must=list(self.lanes)))
         # The tail carries the single-workgroup recurrences: high priority puts it (and its partner stream, see
         # matching._side_stream) on hardware queues of their own — normal-priority streams can collide with each
         # other on a queue (more so once RCCL has created its streams) but never with these — and lets a lone
@@ -137,7 +218,9 @@ class LanePipeline:
         # more than three lanes.
         self.n_tails_requested = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
         n_tails = tail_budget(self.n_tails_requested, self.device)
-        self.tail_streams = [new_stream(self.device, priority=pr, kind="tail", owner=self) for _ in range(n_tails)]
+        self.tail_streams = []
+        for _ in range(n_tails):
+            self.tail_streams.append(new_stream(self.device, priority=pr, kind="tail", owner=self, overlap_with="all", must=self.lanes + self.tail_streams))
         self.tail_stream = self.tail_streams[0]
 
     def run(self, items, head, tail=None):

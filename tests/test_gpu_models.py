@@ -342,6 +342,30 @@ def test_lane_pipeline_matches_sequential_order():
         assert torch.equal(a0 * 2.0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
 
 
+def test_pipeline_streams_are_measured_to_run_side_by_side():
+    """Round 5: the stream scheduler no longer trusts HIP's stream -> hardware-queue mapping (the bench step moved by +-8 % with the
+    number of streams the process had created before).  Every lane, tail and partner stream is taken from torch's pool by
+    MEASUREMENT (pipeline.new_stream / stream_contention: a dispatch-bound probe launch on both streams at once): whatever was
+    created before, a pipeline's lane and tail — and the tail's partner — end up side by side, not on one hardware queue."""
+    from knn_svc_amd import matching, pipeline
+    dummies = [torch.cuda.Stream() for _ in range(5)]          # noqa: F841
+    for st in dummies:
+        with torch.cuda.stream(st):
+            torch.zeros(8, device=DEV)
+    pipe = pipeline.LanePipeline(torch.device(DEV, 0), lanes=1)
+    lane, tail = pipe.lanes[0], pipe.tail_streams[0]
+    with torch.cuda.stream(tail):
+        partner = matching._side_stream(torch.device(DEV, 0))
+    c_lt = pipeline.stream_contention(lane, tail, 0)
+    c_tp = pipeline.stream_contention(tail, partner, 0)
+    c_lp = pipeline.stream_contention(lane, partner, 0)
+    same = pipeline.stream_contention(lane, lane, 0)                # one stream against itself: strictly one after the other
+    print(f"contention lane/tail {c_lt:.2f}, tail/partner {c_tp:.2f}, lane/partner {c_lp:.2f}; one stream against itself {same:.2f}; "
+          f"probe log {pipeline._PROBE['log'][-6:]}")
+    assert same > 1.9                                               # the probe can tell
+    assert c_lt <= pipeline.CONTENTION_OK + 0.1 and c_tp <= pipeline.CONTENTION_OK + 0.1 and c_lp <= 2.4
+
+
 @pytest.mark.parametrize("size", ["tiny", "large"])
 def test_wavlm_one_call_equals_the_host_sequenced_forward(size, monkeypatch):
     """WavLM.extract_features (wavlm/WavLM.py:323-375) behind ONE C call (knnsvc_wavlm_encode: an opaque handle owns
