@@ -524,13 +524,18 @@ def main():
         # (only the encoder goes eager: its launches are the ones timed.  The generator keeps replaying its graph — run eagerly,
         #  its ~110 launches on three streams left the HOST behind the GPU, and every timing of the following conversion then
         #  included launch gaps: dominant-kernel fraction 0.47 instead of 0.51, kNN stage 0.86 instead of 0.46 ms)
+        # (and the encoder's launch sequence comes from the host in this pass — KNNSVC_WAVLM_HOST_SEQ: since round 5 the product path
+        #  enqueues it inside ONE C call, knnsvc_wavlm_encode, where no event can be recorded between two launches; same kernels,
+        #  same arguments, same bits: tests/test_gpu_models.py::test_wavlm_one_call_equals_the_host_sequenced_forward)
         enc.use_graphs = False
+        os.environ["KNNSVC_WAVLM_HOST_SEQ"] = "1"
         timer.enabled = True
         stage.on = True                     # five event pairs per step; the table is printed only with --stages
         for _ in range(a.steps):
             step(enc, voc, src, sf0, pool_w, pool_f0, a.max_batch)
         barrier()
         timer.enabled = False
+        os.environ.pop("KNNSVC_WAVLM_HOST_SEQ", None)
         enc.use_graphs = True
     kdist.raise_if_any_nan()                                            # the deferred NaN flags of every sharded search of this run
     if y is not None:                                                   # strong scaling with fewer steps than ranks: not every rank owned one
@@ -600,8 +605,8 @@ def main():
                          "note": f"achieved = algorithmic fp32 FLOP (2*M*N*K per launch) / HIP-event time; peak = dense 16-bit "
                                  f"MFMA peak 2500 TFLOP/s / {mfmas} MFMAs per product; executed MFMA rate = {mfmas} x achieved",
                          "frac_of_fp32_mfma_peak_157.3": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "timing": "HIP events around each launch in an eager re-run of the same K steps right after the "
-                                   "timed region (which replays hipGraphs)",
+                         "timing": "HIP events around each launch in an eager, host-sequenced re-run of the same K steps right after the "
+                                   "timed region (which replays hipGraphs of the one-call encoder)",
                          "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(1, n_launch), 4),
                          "kernel_ms_per_step": round(gemm_ms / a.steps, 3),
                          "secondary": [{"kernel": "+".join(f), "launches": nl, "kernel_ms_per_step": round(ms / a.steps, 3),

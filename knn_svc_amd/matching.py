@@ -216,9 +216,12 @@ def _side_stream(device) -> "torch.cuda.Stream":
         # a partner has to run BESIDE its stream — and beside the lanes, tails and other partners: measured at creation
         # (pipeline.new_stream, overlap_with="all"), not left to the stream -> hardware-queue mapping
         from . import pipeline
-        pipeline._KNOWN[:] = [e for e in pipeline._KNOWN if e[0] is None or e[0]() is not None]
-        lanes_tails = [st for _o, k, st in pipeline._KNOWN if k in ("lane", "tail") and st.device.index == idx]
-        _SIDE[key] = new_stream(idx, priority=cur.priority, kind="partner", overlap_with="all", must=[cur] + lanes_tails)
+        vetted = [st for (d_, _k, _i, _p), st in pipeline._VETTED.items() if d_ == idx]
+        if cur.cuda_stream == 0 or any(cur.cuda_stream == st.cuda_stream for st in vetted):
+            # the partner of the default stream or of a measured (single-lane) pipeline stream: measured too
+            _SIDE[key] = new_stream(idx, priority=cur.priority, kind="partner", overlap_with="all", must=[cur] + vetted)
+        else:
+            _SIDE[key] = new_stream(idx, priority=cur.priority, kind="partner")
     return _SIDE[key]
 
 
@@ -244,7 +247,7 @@ def _knn_stream(device) -> "torch.cuda.Stream":
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _KNN_STREAMS:
         from .pipeline import new_stream
-        _KNN_STREAMS[key] = new_stream(device, kind="knn", overlap_with="all")
+        _KNN_STREAMS[key] = new_stream(device, kind="knn")
     return _KNN_STREAMS[key]
 
 

@@ -187,14 +187,37 @@ def tail_budget(requested: int, device=None) -> int:
     return n
 
 
+_VETTED = {}                       # (device index, kind, position, priority) -> stream: chosen once by measurement, reused by every pipeline
+
+
+def vetted_stream(device, kind: str, position: int, priority: int, must) -> "torch.cuda.Stream":
+    """The position-th lane / tail stream of this device.  Chosen ONCE (new_stream: measured contention against the package's other
+    streams) and handed to every LanePipeline that asks — dataset mode and the serving converter make a pipeline per call, and a
+    stream set that was measured to run side by side is worth keeping (their partner streams, cached per stream, then stay too)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, kind, int(position), int(priority))
+    if key not in _VETTED:
+        _VETTED[key] = new_stream(dev, priority=priority, kind=kind, overlap_with="all", must=must)
+    return _VETTED[key]
+
+
 class LanePipeline:
     def __init__(self, device, lanes: int = 1):
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         self.device = torch.device(device)
+        # ONE lane (one conversion after the other: bench.py's north-star pipeline, special_match): lane, tail and their partner
+        # streams are few enough to give every one a hardware queue it does not fight over — they are chosen by measurement, once
+        # (vetted_stream).  SEVERAL lanes (dataset mode, serving): 3 lanes + their 3 partners + 3 tails + the kNN stream are more
+        # streams than the runtime has hardware queues, some must share, and the greedy measured choice came out WORSE than torch's
+        # round-robin pool order (same box, bench.py's cfg 5 share / cfg 3: 2591 / 2119 xRT against 2868 / 2553): those keep the
+        # pool order, a fresh set per pipeline.
+        self.measured = lanes == 1
         self.lanes = []
-        for _ in range(lanes):          # every stream of the pipeline has to overlap with every other one: measured, not assumed (new_stream)
-            self.lanes.append(new_stream(self.device, kind="lane", owner=self, overlap_with="all", must=list(self.lanes)))
+        for i in range(lanes):
+            self.lanes.append(vetted_stream(self.device, "lane", i, 0, list(self.lanes)) if self.measured
+                              else new_stream(self.device, kind="lane", owner=self))
         # The tail carries the single-workgroup recurrences: high priority puts it (and its partner stream, see
         # matching._side_stream) on hardware queues of their own — normal-priority streams can collide with each
         # other on a queue (more so once RCCL has created its streams) but never with these — and lets a lone
@@ -219,8 +242,9 @@ class LanePipeline:
         self.n_tails_requested = int(os.environ.get("KNNSVC_TAILS", "0")) or (min(3, max(1, 6 - lanes)) if lanes > 1 else 1)
         n_tails = tail_budget(self.n_tails_requested, self.device)
         self.tail_streams = []
-        for _ in range(n_tails):
-            self.tail_streams.append(new_stream(self.device, priority=pr, kind="tail", owner=self, overlap_with="all", must=self.lanes + self.tail_streams))
+        for i in range(n_tails):
+            self.tail_streams.append(vetted_stream(self.device, "tail", i, pr, self.lanes + self.tail_streams) if self.measured
+                                     else new_stream(self.device, priority=pr, kind="tail", owner=self))
         self.tail_stream = self.tail_streams[0]
 
     def run(self, items, head, tail=None):
