@@ -29,6 +29,22 @@ static inline int knnsvc_check_launch(const char* what) {
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Zero-fill as an ORDINARY KERNEL on the caller's stream (bytes % 4 == 0).  Not hipMemsetAsync: with several generators in flight on
+// several streams its fills were not ordered with the kernels that follow them on the same stream the way a kernel is (round 5:
+// csrc/models.hip, zero_slots — run-to-run different samples in the dataset-mode pipeline until the memset became a kernel).
+namespace {
+__global__ __launch_bounds__(256) void kn_zero_kernel(unsigned* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+}  // namespace
+static inline int kn_zero_async(void* p, size_t bytes, hipStream_t st) {
+    const long n = (long)(bytes / 4);
+    if (n == 0) return KNNSVC_OK;
+    hipLaunchKernelGGL(kn_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)p, n);
+    return knnsvc_check_launch("zero_fill");
+}
+
 // GELU(x) = x Phi(x) (torch.nn.functional.gelu, exact erf form: wavlm/modules.py, WavLM.py feature extractor and FFN).
 // Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) = P(t) exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2), P a degree-6 polynomial (minimax fit of
 // erfc(z) exp(z^2), max error 8e-9 in exact arithmetic; the family of Abramowitz & Stegun 7.1.26); Phi(|x|) = 1 - Phi(-|x|).

@@ -673,7 +673,7 @@ extern "C" int knnsvc_f0_harvest(const float* x, int64_t L, int32_t sample_rate,
     hipLaunchKernelGGL(name, dim3 grid, dim3 block, 0, st, __VA_ARGS__);               \
     if ((rc = knnsvc_check_launch("f0_harvest/" #name))) return rc;
 
-    if (hipMemsetAsync(ws + p.o_info, 0, 64, st) != hipSuccess) return knnsvc_fail(KNNSVC_EHIP, "f0_harvest: memset failed");
+    if ((rc = kn_zero_async(ws + p.o_info, 64, st))) return rc;
     const long nchunk = cdiv64(p.text, 64);
     HV_LAUNCH(hv_iir_kernel<true>, ((unsigned)cdiv64(nchunk, 256)), (256), x, (const double*)nullptr, D(p.o_t1), p.text, p.L);
     HV_LAUNCH(hv_iir_kernel<false>, ((unsigned)cdiv64(nchunk, 256)), (256), x, (const double*)D(p.o_t1), D(p.o_t2), p.text, p.L);
@@ -704,7 +704,7 @@ extern "C" int knnsvc_f0_harvest(const float* x, int64_t L, int32_t sample_rate,
     HV_LAUNCH(hv_merge_kernel, (1), (1024), (const double*)D(p.o_s2), (const double*)D(p.o_chs), D(p.o_ms), p.nfr,
               (const int*)I(p.o_st), (const int*)I(p.o_xst), (const int*)I(p.o_xed), I(p.o_keep), (const long*)LL(p.o_woff),
               (const double*)D(p.o_chan), I(p.o_order), D(p.o_s3), D(p.o_s4), I(p.o_gst), I(p.o_ged), p.scap, LL(p.o_soff), p.scratch_cap, 9, I(p.o_info));
-    if (hipMemsetAsync(ws + p.o_sm, 0, p.nfr * 8, st) != hipSuccess) return knnsvc_fail(KNNSVC_EHIP, "f0_harvest: memset failed");
+    if ((rc = kn_zero_async(ws + p.o_sm, (size_t)p.nfr * 8, st))) return rc;
     HV_LAUNCH(hv_smooth_kernel, ((unsigned)cdiv64(p.scap, 64)), (64), (const double*)D(p.o_s4), p.nfr, (const int*)I(p.o_gst),
               (const int*)I(p.o_ged), (const long*)LL(p.o_soff), D(p.o_scratch), D(p.o_sm), (const int*)I(p.o_info));
     HV_LAUNCH(hv_sample_kernel, ((unsigned)cdiv64(p.nout, 256)), (256), (const double*)D(p.o_sm), p.nfr, (double)frame_period, zero_below, f0,

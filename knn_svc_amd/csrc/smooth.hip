@@ -363,7 +363,7 @@ extern "C" int knnsvc_smooth_weights(const int64_t* idx, int64_t nq, const float
     hipStream_t st = (hipStream_t)stream;
     if (nq < 2) {      // no adjacent pair: the reference's loss is NaN and never improves -> softmax(0)
         hipLaunchKernelGGL(fill_quarter_kernel, dim3(1), dim3(64), 0, st, out_w, (long)nq * 4);
-        if (out_iters) (void)hipMemsetAsync(out_iters, 0, sizeof(int), st);
+        if (out_iters) (void)kn_zero_async(out_iters, sizeof(int), st);
         return knnsvc_check_launch("smooth_weights(fill)");
     }
     float* base = (float*)(((uintptr_t)workspace + 63) & ~(uintptr_t)63);
