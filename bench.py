@@ -596,7 +596,8 @@ def main():
                                                          "top-32 lists exchanged with one RCCL all-to-all and merged (lower index first on ties)")),
                        "wavlm_batch_chunks": a.max_batch,
                        "pipeline_depth": a.pipeline_depth,
-                       "pipeline": ("match + vocoder of conversion i run on a second stream under the encoder of conversion i+1"
+                       "pipeline": ("match + vocoder of conversion i run on a second stream under the encoder of conversion i+1; the pipeline's "
+                                    "streams are chosen by measured contention (pipeline.new_stream), not by creation order"
                                     if a.pipeline_depth > 1 else "none: conversions run one after the other"),
                        "sequential_ms_per_step": round(dt_seq / a.steps * 1e3, 3)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

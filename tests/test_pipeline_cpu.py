@@ -96,3 +96,41 @@ def test_cat_rows_is_a_view_for_adjacent_parts_and_a_copy_otherwise():
     assert out.data_ptr() != b.data_ptr() and torch.equal(out, torch.cat(ragged))
     other = [b[0], torch.ones(2, 4)]                               # different buffers
     assert torch.equal(cat_rows(other), torch.cat(other))
+
+
+def test_new_stream_passes_over_colliding_candidates_and_prefers_the_streams_that_matter(monkeypatch):
+    """pipeline.new_stream's choice among torch's pool streams by MEASURED contention (round 5), with the measurement and the pool
+    replaced by tables: a candidate that collides with a stream it has to run beside is passed over; when no candidate is clean the
+    one that is clean against the ``must`` streams wins over one that is clean against the rest; KNNSVC_STREAM_PROBE=0 takes the
+    first pool stream unmeasured."""
+    import torch
+
+    class FakeStream:
+        n = 0
+
+        def __init__(self, device=None, priority=0):
+            FakeStream.n += 1
+            self.cuda_stream, self.priority, self.device = FakeStream.n, priority, torch.device("cuda", 0)
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    lane, tail, other = FakeStream(), FakeStream(), FakeStream()          # ids 1, 2, 3
+    table = {}
+    monkeypatch.setattr(pipeline, "stream_contention", lambda a, b, dev: table.get((a.cuda_stream, b.cuda_stream), 1.5))
+    keep_s, keep_k = pipeline._STREAMS[:], pipeline._KNOWN[:]
+    try:
+        # candidates 4 and 5 share a queue with the lane (2.1) / collide in dispatch with the tail (3.0); 6 is clean
+        table.update({(1, 4): 2.1, (2, 5): 3.0})
+        s = pipeline.new_stream(0, kind="partner", overlap_with=[lane, tail, other], must=[lane, tail])
+        assert s.cuda_stream == 6
+        # no clean candidate at all: 7, 9, 11, ... collide with the lane, the even ones only with `other` -> an even one is taken
+        table.clear()
+        for c in range(7, 40):
+            table[(1, c) if c % 2 else (3, c)] = 2.1
+        s = pipeline.new_stream(0, kind="partner", overlap_with=[lane, tail, other], must=[lane, tail])
+        assert s.cuda_stream % 2 == 0 and s.cuda_stream >= 8
+        first = FakeStream.n + 1
+        monkeypatch.setenv("KNNSVC_STREAM_PROBE", "0")
+        assert pipeline.new_stream(0, kind="partner", overlap_with=[lane], must=[lane]).cuda_stream == first
+    finally:
+        pipeline._STREAMS[:] = keep_s
+        pipeline._KNOWN[:] = keep_k
