@@ -420,14 +420,15 @@ def range_slots_on() -> bool:
     return os.environ.get("KNNSVC_RANGE_SLOTS", "1") != "0"
 
 
-def row_norms(x2d):
+def row_norms(x2d, slot=None):
     """-> (norm [rows], sumsq [rows]).  ``norm._slot``: one-element device tensor holding the largest row norm — an
-    upper bound of max|x| the kernel folds on the way (the kNN's range slot; no extra pass over the features)."""
+    upper bound of max|x| the kernel folds on the way (the kNN's range slot; no extra pass over the features).
+    ``slot``: a ZEROED range slot to fold into (a search zeroes all its small buffers with one fill: knn_topk)."""
     _need(x2d, name="row_norms.x")
     rows, dim = x2d.shape
     norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
     sq = torch.empty(rows, device=x2d.device, dtype=torch.float32)
-    slot = new_slot(x2d.device)
+    slot = new_slot(x2d.device) if slot is None else slot
     check(_lib.load().knnsvc_row_norms(_p(x2d), rows, dim, x2d.stride(0), _p(norm), _p(sq), _p(slot), _stream()), "row_norms")
     norm._slot = slot
     return norm, sq
@@ -495,7 +496,7 @@ def _knn_rescore(wide, q, qn, qs, pc, pn, ps, k, idx_offset, mask, idx_out, dist
                                          mask[0], mask[1], 1 if knn_rescore_on() else 0, _p(idx_out), _p(dist_out), _stream()), "knn_rescore")
 
 
-def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None, allow_fused=True, max_blocks=0):
+def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), prepared=None, allow_fused=True, max_blocks=0, zeros=None):
     """q.p^T on the f16x2 matrix-core loop (Gemm2QuadS), then the reference's distance formula + selection.  Two routes over
     the SAME dot-product bits (both sum over K in the 16x16x32 grouping, whatever the sizes):
       * fused (default from a few hundred query rows on): knnsvc_knn_screen + knnsvc_knn_refine, no dot matrix (_knn_fused_chunk);
@@ -525,7 +526,7 @@ def _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask=(0, 0), pr
         if fused and npc >= KNN_FUSED_MIN_P:
             KNN_ROUTE_COUNTS["fused"] += 1
             _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn[p0:], ps[p0:], k, idx_offset + p0,
-                             (mask[0] - p0, mask[1] - p0), idx, dist, flag, max_blocks)
+                             (mask[0] - p0, mask[1] - p0), idx, dist, flag, max_blocks, zeros)
         else:
             KNN_ROUTE_COUNTS["dot"] += 1
             npad = -(-npc // 4) * 4
@@ -594,7 +595,7 @@ def knn_epochs(nq: int, npc: int, blocks: int = 256):
     return out
 
 
-def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offset, mask, idx_out, dist_out, flag, max_blocks=0):
+def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offset, mask, idx_out, dist_out, flag, max_blocks=0, zeros=None):
     """One pool chunk without a [nq, np] dot matrix: the chunk's rows in epochs (knn_epochs), each one knnsvc_knn_screen (the
     first without thresholds, the later ones against the row's k-th key so far) + one knnsvc_knn_refine (list so far + the new
     candidates -> list, next thresholds).  A row with more survivors than the candidate buffer holds (pathological data: e.g.
@@ -612,7 +613,11 @@ def _knn_fused_chunk(q, q2, q_slot, qn, qs, pc, p2, p_slot, pn, ps, k, idx_offse
         # one fill: candidate counts [m] | the first epoch's workspace: row bounds [m], per-half-tile bounds [2 gy0][m] (the tiles'
         # exchange, knn.hip), arrival counters [gx] one cache line each
         gy0 = epochs[0][1] - epochs[0][0]
-        zeroed = torch.zeros(m * (2 + 2 * gy0) + 32 * -(-m // 256), device=dev, dtype=torch.int32)
+        nz = m * (2 + 2 * gy0) + 32 * -(-m // 256)
+        if zeros is not None and zeros.numel() == nz and q0 == 0:
+            zeroed = zeros                              # part of the search's ONE fill (knn_topk)
+        else:
+            zeroed = torch.zeros(nz, device=dev, dtype=torch.int32)
         cnt, bound = zeroed[:m], zeroed[m:]
         cand = torch.empty(m * KNN_FUSED_CAP * 2, device=dev, dtype=torch.int32)
         wide = torch.empty(m, KNN_WIDE, device=dev, dtype=torch.int64)       # the rows' wide lists, handed from epoch to epoch
@@ -651,11 +656,24 @@ def knn_topk(q, pool, k=32, idx_offset=0, q_stats=None, p_stats=None, check_nan=
     lib = _lib.load()
     nq, dim = q.shape
     npool = pool.shape[0]
-    qn, qs = q_stats if q_stats is not None else row_norms(q)
-    pn, ps = p_stats if p_stats is not None else row_norms(pool)
-    if knn_mode() == "f16x2" and dim % 32 == 0 and npool >= k and nq > 0 and 1 <= k <= 32:
-        flag = torch.zeros(1, device=q.device, dtype=torch.int32)
-        idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask, prepared, max_blocks=max_blocks)
+    f16 = knn_mode() == "f16x2" and dim % 32 == 0 and npool >= k and nq > 0 and 1 <= k <= 32
+    # ONE fill for everything a search needs zeroed — its flag, the two operands' range slots and (fused route, one chunk) the
+    # candidate counts + first-epoch workspace: four tiny fill launches were ~5 us each in front of a 0.4 ms search
+    flag = zeros = None
+    if f16:
+        nz = 0
+        if (prepared is None and knn_fused_on() and nq >= KNN_FUSED_MIN_Q and npool >= KNN_FUSED_MIN_P and
+                npool * dim * 4 < (1 << 30) and nq * dim < (1 << 28) and nq * KNN_FUSED_CAP * 8 <= (1 << 30)):
+            ep = knn_epochs(nq, npool, int(max_blocks) if max_blocks else 256)
+            nz = nq * (2 + 2 * (ep[0][1] - ep[0][0])) + 32 * -(-nq // 256)
+        zbuf = torch.zeros(64 + 2 * SLOT_W + nz, device=q.device, dtype=torch.int32)
+        flag = zbuf[:1]
+        sl_q, sl_p = zbuf[64:64 + SLOT_W].view(torch.float32), zbuf[64 + SLOT_W:64 + 2 * SLOT_W].view(torch.float32)
+        zeros = zbuf[64 + 2 * SLOT_W:] if nz else None
+    qn, qs = q_stats if q_stats is not None else row_norms(q, sl_q if f16 else None)
+    pn, ps = p_stats if p_stats is not None else row_norms(pool, sl_p if f16 else None)
+    if f16:
+        idx, dist = _knn_topk_gemm(q, pool, k, idx_offset, qn, qs, pn, ps, flag, mask, prepared, max_blocks=max_blocks, zeros=zeros)
         if check_nan:
             try:
                 raise_if_nan(flag)
