@@ -160,6 +160,43 @@ def test_sharded_knn_two_ranks_on_one_gpu_equals_unsharded_search():
     assert r0 and r1
 
 
+def _cfg4_worker(rank, ws, port, res):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from knn_svc_amd import dist as kd, ops, synthetic as S
+    dev = "cuda:0"
+    sizes = [11250 + d for d in (300, -300, 77, -77)]                            # 45 000 rows in four uneven shards
+    pool = S.clustered_features(45000, 1024, 9, n_centres=80)
+    o = sum(sizes[:rank])
+    mine = pool[o:o + sizes[rank]].contiguous().to(dev)
+    q = S.clustered_features(400, 1024, 321, n_centres=80).to(dev)              # one utterance, the same on every rank
+    fused0 = ops.KNN_ROUTE_COUNTS["fused"]
+    idx, d = kd.sharded_knn(q, mine, 32, replicated=True, counts=sizes)
+    took_fused = ops.KNN_ROUTE_COUNTS["fused"] > fused0
+    kd.raise_if_any_nan()
+    ok = True
+    if rank == 0:                                                                # the unsharded search, once
+        fi, fd = ops.knn_topk(q, pool.to(dev), 32)
+        ok = bool(torch.equal(idx, fi)) and bool(torch.equal(d, fd))
+    whole = kd.all_gather_rows_var(mine[:, :16].contiguous(), sizes)
+    ok = ok and bool(torch.equal(whole.cpu(), pool[:, :16]))
+    res[rank] = bool(ok and took_fused)
+    dist.destroy_process_group()
+
+
+def test_cfg4_size_pool_in_four_uneven_shards_equals_unsharded_search():
+    """BASELINE cfg 4's search at its pool size with the HIP kernels: a 45 000-row speaker pool (1024-d) in four uneven shards, one
+    utterance's 400 query frames replicated on four ranks sharing the card (gloo, host-staged collectives), every shard searched on
+    the fused route and re-scored exactly, the [400, 32] lists all-gathered and merged: indices and distances BIT-EQUAL to the
+    unsharded search of the whole pool (the exact re-score makes a pair's distance independent of what else its shard holds)."""
+    _clean_parent()
+    port = 39900 + (os.getpid() % 1500)
+    res = _launch(_cfg4_worker, 4, (port,))
+    assert all(res), res
+
+
 def test_bench_self_launches_its_ranks_rehearsal():
     """`python bench.py --gpus 2` with no RANK in the environment — the shape of the driver's own command — starts its two ranks
     itself (child processes of torch.distributed.run, before anything touches the GPU) and relays rank 0's JSON line.  Rehearsal
