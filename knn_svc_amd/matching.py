@@ -436,8 +436,6 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     # 319: both the one-hot on layer 6).  Two DIFFERENT weightings mean two feature sets per target file: the pool is then encoded
     # once per weighting (the reference mixes both from one forward; this case is never taken live — correctness, not speed)
     mix_m, mix_s = _mix_of(match_weights, wavlm), _mix_of(synth_weights, wavlm)
-    if mix_m != mix_s and (pool_sharded or share_items):
-        raise NotImplementedError("different matching and synthesis layer weightings with a sharded pool")
     wavlm.set_layer_mix(mix_m)
     if src_dataset_path is None:
         assert os.path.isfile(src_wav_file)
@@ -456,7 +454,10 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
     if mix_m != mix_s:
         wavlm.set_layer_mix(mix_s)
         try:
-            _m, synth_pool, _a2, _s2, _f2, _h2 = get_complete_spk_pool(ref_wav_file, wavlm, device=device, duration_limit=duration_limit)
+            # (a sharded pool: this rank's share again, under the synthesis weighting; all-gathered below like the matching features —
+            #  the search only ever sees the matching features, the gathers and the smoothness weights read the synthesis ones)
+            _m, synth_pool, _a2, _s2, _f2, _h2 = get_complete_spk_pool(ref_wav_file, wavlm, device=device, duration_limit=duration_limit,
+                                                                       shard_files=pool_sharded)
         finally:
             wavlm.set_layer_mix(mix_m)
         assert list(synth_pool) == keys
@@ -471,6 +472,8 @@ def match_at_inference_time(src_wav_file, ref_wav_file, wavlm: WavLMEncoder, mat
         matching_list = kdist.all_gather_rows_var(shard, counts)
         matching_f0 = kdist.all_gather_rows_var(matching_f0, counts)
         harmonics_list = kdist.all_gather_rows_var(harmonics_list, counts)
+        if synth_list is not None:
+            synth_list = kdist.all_gather_rows_var(synth_list, counts)
 
     out_c, harm_c, audio_c, f0_c = {}, {}, {}, {}
     items = [item for item in query_pool

@@ -639,6 +639,21 @@ def test_pool_sharded_single_file_path_equals_unsharded(golden, tmp_path):
         for k in a:
             if a[k] is not None:
                 assert torch.equal(a[k], b[k]), k
+    # round 5: DIFFERENT matching / synthesis layer weightings with a sharded pool (ddsp_prematch_dataset.py:349-350, 1157, 1260: the
+    # search runs on the matching features, the gathers and the smoothness weights read the synthesis ones) — was NotImplementedError
+    wm = torch.zeros(cfg["encoder_layers"] + 1); wm[2] = 1.0
+    ws_ = torch.zeros(cfg["encoder_layers"] + 1); ws_[1] = 1.0
+    ref2 = matching.match_at_inference_time(Path(srcp), poolp, enc, wm, ws_, pool_sharded=False, **common)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        got2 = matching.match_at_inference_time(Path(srcp), poolp, enc, wm, ws_, pool_sharded=True, **common)
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(ref2, got2):
+        for k in a:
+            if a[k] is not None:
+                assert torch.equal(a[k], b[k]), k
+    assert not all(torch.equal(ref[0][k], ref2[0][k]) for k in ref[0])          # the second weighting changes the features that go out
 
 
 def test_sharded_search_reports_nan_once_agreed():
