@@ -104,18 +104,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int CPL, int KMAXT, int RP>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ x, long L, long T, int k, int stride,
                                                            const float* __restrict__ w, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ out, int split) {
-    __shared__ float xs[64 * 8 + 32];
+                                                           const float* __restrict__ beta, float* __restrict__ out, int split, int subs) {
+    __shared__ float xs[2][64 * 8 + 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = CPL * 64;
     const long b = blockIdx.y;
-    const long m0 = (long)blockIdx.x * 64;
     const float* xb = x + b * L;
     const int span = 63 * stride + k;
-    for (int i = threadIdx.x; i < span; i += 256) {
-        const long p = m0 * stride + i;
-        xs[i] = p < L ? xb[p] : 0.f;
-    }
     constexpr int NP = (CPL + 1) / 2;      // channel pairs (CPL = 1: the second half of the one pair repeats the channel and is dropped)
     // channels in PAIRS: the taps, the affine and the GELU run on v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 — per channel the
     // same operations in the same order as one at a time (bit-identical), at half the issue slots; the LayerNorm sums stay scalar
@@ -127,6 +122,17 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
         g[c] = (f32x2){gamma[ch], gamma[ch1]}; be[c] = (f32x2){beta[ch], beta[ch1]};
 #pragma unroll
         for (int t = 0; t < KMAXT; ++t) wr[c][t] = t < k ? (f32x2){w[ch * k + t], w[ch1 * k + t]} : (f32x2){0.f, 0.f};
+    }
+    // A workgroup walks `subs` consecutive spans of 64 rows (round 5; one span per workgroup before): the 80 filter taps + 16 affine
+    // values a lane loads up front were paid once per 16 rows of its wave — now once per 16 * subs.  Two LDS buffers, one barrier
+    // per span.  Same arithmetic per row: bit-identical.
+  for (int sub = 0; sub < subs; ++sub) {
+    const long m0 = ((long)blockIdx.x * subs + sub) * 64;
+    if (m0 >= T) break;
+    float* xsb = xs[sub & 1];
+    for (int i = threadIdx.x; i < span; i += 256) {
+        const long p = m0 * stride + i;
+        xsb[i] = p < L ? xb[p] : 0.f;
     }
     __syncthreads();
     // RP rows per pass: independent chains (LDS reads, the two reductions, the GELU's rcp / exp2, the stores) interleave, and the
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             const int lm = wave * 16 + r + u;          // rows past T read zeros / stale LDS: finite, never stored
             float xv[KMAXT];
 #pragma unroll
-            for (int t = 0; t < KMAXT; ++t) xv[t] = t < k ? xs[lm * stride + t] : 0.f;
+            for (int t = 0; t < KMAXT; ++t) xv[t] = t < k ? xsb[lm * stride + t] : 0.f;
             s[u] = 0.f;
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
             }
         }
     }
+  }
 }
 
 // one wave per row; lane l covers channels 16l..16l+15 (a quarter of a 64-wide head)
@@ -460,11 +467,14 @@ extern "C" int knnsvc_wavlm_conv0(const float* x, int32_t batches, int64_t L, co
     KN_REQUIRE(channels == 64 || channels == 128 || channels == 256 || channels == 512, "wavlm_conv0: channels must be 64/128/256/512");
     KN_REQUIRE(!out_f16x2 || channels >= 256, "wavlm_conv0: split output needs >= 256 channels");
     const long T = (L - k) / stride + 1;
-    dim3 grid((unsigned)cdiv64(T, 64), (unsigned)batches);
     hipStream_t st = (hipStream_t)stream;
-    static int rp = -1;        // rows per pass and reduction flavour: 2 (default), 4, or 1 = round 2's kernel (shuffle sums), for A/B
+    static int rp = -1, subs_env = -1;        // rows per pass and reduction flavour: 2 (default), 4, or 1 = round 2's kernel (shuffle sums), for A/B
     if (rp < 0) { const char* e = getenv("KNNSVC_CONV0_RP"); rp = e ? atoi(e) : 2; if (rp != 1 && rp != 4) rp = 2; }
-#define KN_C0R(CPL, KM, RP) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, KM, RP>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out, out_f16x2)
+    if (subs_env < 0) { const char* e = getenv("KNNSVC_CONV0_SUBS"); subs_env = e ? atoi(e) : 8; if (subs_env < 1 || subs_env > 64) subs_env = 8; }
+    // spans of 64 rows per workgroup: 8 (21 x 96 063 rows: 1.54 -> 1.34 ms; 4: 1.36, 2: 1.41) where that still leaves several rounds of workgroups (768 are resident), 1 for short inputs
+    const int subs = cdiv64(T, 64L * subs_env) * batches >= 3072 ? subs_env : 1;
+    dim3 grid((unsigned)cdiv64(T, 64L * subs), (unsigned)batches);
+#define KN_C0R(CPL, KM, RP) hipLaunchKernelGGL((conv0_ln_gelu_kernel<CPL, KM, RP>), grid, dim3(256), 0, st, x, (long)L, T, k, stride, w, gamma, beta, out, out_f16x2, subs)
 #define KN_C0(CPL, KM) { if (rp == 2) KN_C0R(CPL, KM, 2); else if (rp == 4) KN_C0R(CPL, KM, 4); else KN_C0R(CPL, KM, 1); }
     if (k <= 10) {        // WavLM's k = 10: no padded taps in the unrolled FIR
         if (channels == 512) KN_C0(8, 10) else if (channels == 256) KN_C0(4, 10) else if (channels == 128) KN_C0(2, 10) else KN_C0(1, 10)
