@@ -120,6 +120,7 @@ def new_stream(device, priority: int = 0, kind: str = "", owner=None, overlap_wi
     rest = [o for o in overlap_with if not any(o.cuda_stream == m.cuda_stream for m in must)]
     if (must or rest) and os.environ.get("KNNSVC_STREAM_PROBE", "1") != "0" and not torch.cuda.is_current_stream_capturing():
         best = None
+        torch.cuda.synchronize(device)      # the probe times launches: nothing else may be running (once per stream, at its creation)
         klass = lambda r: 0 if r <= CONTENTION_OK else (1 if r <= 2.4 else 2)       # side by side / one queue / colliding dispatch
         for _try in range(16):
             _PROBE["tries"] += 1

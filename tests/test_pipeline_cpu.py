@@ -113,6 +113,7 @@ def test_new_stream_passes_over_colliding_candidates_and_prefers_the_streams_tha
             self.cuda_stream, self.priority, self.device = FakeStream.n, priority, torch.device("cuda", 0)
     monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     lane, tail, other = FakeStream(), FakeStream(), FakeStream()          # ids 1, 2, 3
     table = {}
     monkeypatch.setattr(pipeline, "stream_contention", lambda a, b, dev: table.get((a.cuda_stream, b.cuda_stream), 1.5))
