@@ -14,4 +14,8 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 torch.cuda.synchronize(); e0.record()
 for _ in range(20): voc.forward(c, f0, harm)
 e1.record(); torch.cuda.synchronize()
-print(f"N={N}: {e0.elapsed_time(e1) / 20:.3f} ms per replay (graphs: {list(voc._graphs)})")
+import zlib
+y = voc.forward(c, f0, harm); torch.cuda.synchronize()
+crc = zlib.crc32(y.detach().float().cpu().numpy().tobytes())
+print(f"N={N}: crc {crc:08x} ", end="")
+print(f" {e0.elapsed_time(e1) / 20:.3f} ms per replay (graphs: {list(voc._graphs)})")
