@@ -28,6 +28,7 @@ struct ConvArgs {
     float out_scale;            // accumulator -> output factor (1 except on the f16x2 path)
     float a_scale;              // f16x2 path: power-of-two factor applied to activations before the split
     int lin;                    // plain output below 2 GiB: the buffer-addressed epilogue applies (conv_epilogue_lin)
+    int wide;                   // ... and bias (+ residual) (+ range slot) is all there is, 16-byte rows: conv_epilogue_wide32 (windowed kernels)
     // dynamic range of the f16x2 path (include/knnsvc_hip.h, "Range"): device slots holding an upper bound of |x| / |w|;
     // when set, the kernel derives the power-of-two operand scale from the slot (kn_pick_scale) instead of a_scale / w_scale
     const float* x_absmax; const float* w_absmax;
@@ -776,6 +777,67 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
 
 // stride-1 multi-tap convolutions: one window of BM + HALO input rows per 32-channel slab, every tap reads it shifted
 // (gemm2_core.h, Gemm2Win)
+// Epilogue of the windowed kernels for what the generator's ResBlock convolutions have — bias, a residual operand or none, a
+// range slot or none — through wave-private LDS patches like conv_epilogue_wide (the operand stages are idle by now), on the
+// 32x32-tile accumulator layout: a band of 32 rows is written column-per-lane (one ds_write_b32 per element, scaled: a power
+// of two), taken back as four consecutive columns of one row per lane, and leaves as 16-byte stores with 16-byte residual
+// loads (requested before the band is written).  The column-per-lane form (conv_epilogue_lin) spends ~27 VALU and two 4-byte
+// memory instructions per element — a quarter of a k = 3 launch at C = 128.  Same arithmetic per element, same bits.
+template <class G, bool RES>
+__device__ __forceinline__ void conv_epilogue_wide32(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], float* lds_generic,
+                                                     int m0, int n0, int b, int g) {
+    static_assert(G::NR == 16, "32x32-tile accumulator layout");
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    constexpr int ETN = G::TN, ETM = G::TM;
+    constexpr int PITCH = ETN * 32 + 4;
+    constexpr int TRIPS = (32 * ETN * 32 / 4) / 64;
+    constexpr int RSTEP = 64 / (ETN * 8);
+    static_assert(4 * 32 * PITCH * 4 <= G::LDS_BYTES, "patches fit the operand stages");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    lds_f* patch = (lds_f*)lds_generic + wave * (32 * PITCH);
+    float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
+    const float* rz = RES ? a.resid + b * a.r_bstride + g * a.r_gstride : nullptr;
+    const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
+    const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, ((a.m - 1) * a.ldo + a.n) * 4);
+    const __amdgpu_buffer_rsrc_t r_rsrc = uniform_rsrc(RES ? (const void*)rz : (const void*)oz, RES ? ((a.m - 1) * a.ldr + a.n) * 4 : 0);
+    const int wrow0 = m0 + (wave / G::WN) * ETM * 32, wcol0 = n0 + (wave % G::WN) * ETN * 32;
+    const int c = (lane & (ETN * 8 - 1)) * 4, n = wcol0 + c;
+    const int row_in_trip = lane / (ETN * 8);
+    const bool nv = n < a.n;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (bz && nv) bias4 = *(const f32x4*)(bz + n);
+    unsigned amax = 0;
+#pragma unroll
+    for (int i = 0; i < ETM; ++i) {
+        const int mrow0 = wrow0 + i * 32 + row_in_trip;
+        f32x4 rv[TRIPS];
+        if (RES) {
+#pragma unroll
+            for (int it = 0; it < TRIPS; ++it)
+                rv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, nv ? ((mrow0 + it * RSTEP) * a.ldr + n) * 4 : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + j * 32 + li] = acc[i][j][r] * a.out_scale;      // power of two: exact
+        // (the patch is private to this wave and LDS operations of one wave complete in order: no barrier)
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {
+            f32x4 v = *(const lds_f4*)(patch + (it * RSTEP + row_in_trip) * PITCH + c) + bias4;
+            if (RES) v += rv[it];
+            if (a.out_absmax) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const unsigned ab = abs_bits(v[e]); amax = ab > amax ? ab : amax; }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, nv ? ((mrow0 + it * RSTEP) * a.ldo + n) * 4 : OOB, 0, 0);
+        }
+    }
+    if (a.out_absmax) publish_absmax(a.out_absmax, amax);
+}
+
 template <class G>
 __device__ __forceinline__ void conv_gemm2win_body(ConvArgs& a, float* lds) {
     resolve_scales(a);
@@ -811,7 +873,11 @@ __device__ __forceinline__ void conv_gemm2win_body(ConvArgs& a, float* lds) {
     else
         G::mainloop(lds, a.cin / 32, a.taps, a.dil, w_off0, a.ldx * 4, bl, acc, FastALoader<1>::desc(a, xz),
                     Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale, a.a_slope);
-    conv_epilogue_any<G>(a, acc, m0, n0, b, g);
+    if (a.wide) {                                       // wave-uniform
+        __syncthreads();                                // every wave is done with the operand stages: they become the patches
+        if (a.resid) conv_epilogue_wide32<G, true>(a, acc, lds, m0, n0, b, g);
+        else conv_epilogue_wide32<G, false>(a, acc, lds, m0, n0, b, g);
+    } else conv_epilogue_any<G>(a, acc, m0, n0, b, g);
 }
 
 template <class G, int MINB>
@@ -1069,6 +1135,7 @@ struct Knobs {
     bool quad_epi = true;          // KNNSVC_QUAD_EPI=0: generic epilogue behind the quad kernel (bit-identical, slower)
     bool generic_epilogue = false; // KNNSVC_EPILOGUE=g: the generic (64-bit addressed) epilogue everywhere
     bool win = true;               // KNNSVC_WIN=0: tap-major kernel instead of the windowed one (other summation order)
+    bool win_wide = true;          // KNNSVC_WIN_WIDE=0: the windowed kernels keep the column-per-lane epilogue
     bool win_small = true, win_deep = true, win160 = true;      // KNNSVC_WIN_SMALL / _DEEP / WIN160 = 0: tile-shape rules off
     bool gemm_small = true;        // KNNSVC_GEMM_SMALL=0: no 64x64 tile for launches below one round of 128x128 tiles
     bool loaded = false;
@@ -1083,6 +1150,7 @@ void load_knobs() {
     const char* ep = getenv("KNNSVC_EPILOGUE");
     k.generic_epilogue = ep && ep[0] == 'g';
     k.win = !env_off("KNNSVC_WIN"); k.win_small = !env_off("KNNSVC_WIN_SMALL"); k.win_deep = !env_off("KNNSVC_WIN_DEEP");
+    k.win_wide = !env_off("KNNSVC_WIN_WIDE");
     k.win160 = !env_off("KNNSVC_WIN160"); k.gemm_small = !env_off("KNNSVC_GEMM_SMALL");
     k.loaded = true;
     g_knobs = k;
@@ -1133,6 +1201,7 @@ static int conv_prep(const knnsvc_conv_desc* d, ConvArgs& a, bool& fast, bool& v
     a.split_scale = d->out_f16x2_scale > 0.f ? d->out_f16x2_scale : KN_F16X2_A_SCALE;
     a.x_split = d->x_f16x2; a.out_split = d->out_f16x2 != 0; a.split_from = d->out_f16x2 > 1 ? d->out_f16x2 : 0;
     KN_REQUIRE(d->out_f16x2 >= 0 && (d->out_f16x2 <= 1 || d->out_f16x2 % 32 == 0), "conv_gemm: out_f16x2 is 0, 1 or the first split column (a multiple of 32)");
+    a.wide = 0;
     a.lin = !d->convt_u && (long)d->m * d->ldo * 4 < (1L << 31) && (!d->resid || (long)d->m * d->ldr * 4 < (1L << 31)) &&
             !knobs().generic_epilogue;      // KNNSVC_EPILOGUE=g: generic epilogue (A/B)
 
@@ -1169,6 +1238,10 @@ static int conv_prep(const knnsvc_conv_desc* d, ConvArgs& a, bool& fast, bool& v
             (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
             d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
             d->bias_gstride % 4 == 0;
+        a.wide = knobs().win_wide && a.lin && !a.out_split && d->act == KNNSVC_ACT_NONE && !d->accumulate && a.div == 1.0f && d->n % 4 == 0 &&
+            d->ldo % 4 == 0 && ((uintptr_t)d->out & 15) == 0 && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 &&
+            (!d->resid || (d->ldr % 4 == 0 && ((uintptr_t)d->resid & 15) == 0 && d->r_bstride % 4 == 0 && d->r_gstride % 4 == 0)) &&
+            (!d->bias || (!d->bias_period && ((uintptr_t)d->bias & 15) == 0 && d->bias_gstride % 4 == 0));
         KN_REQUIRE(d->fixed_tile != 2 || quad_ok, "conv_gemm: fixed_tile 2 needs the quad kernel's operand layout (split A, 16-byte rows, n % 4 == 0)");
     }
     return KNNSVC_OK;
@@ -1459,6 +1532,9 @@ __device__ __forceinline__ void conv_pair_body(const PairArgs& a, float* lds) {
     const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(a.out, ((T - 1) * a.ldo + C) * 4);
     const int ldo4 = a.ldo * 4, ldx4 = a.ldx * 4;
     unsigned amax = 0;
+    // (column-per-lane on purpose: the LDS-patch form that pays in the single-round windowed launches — conv_epilogue_wide32 — made
+    //  the merged pair launches 2-3 % SLOWER, 286 against 276 us at C = 64: their workgroups are spread over three rounds and an
+    //  epilogue already runs under other workgroups' main loops; the patches only add LDS traffic there)
 #pragma unroll
     for (int j = 0; j < G::TN; ++j) {
         const int col = G::acc_col(wave, lane, j);
