@@ -772,21 +772,28 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     FastALoader<G::A_F4> al(a, m0, threadIdx.x);
     Split2BLoader<G::B_P, G::B_PIECES> bl(a.n, a.K, n0, threadIdx.x);
     G::template mainloop<A2>(lds, a.K / 32, al, bl, acc, FastALoader<G::A_F4>::desc(a, xz), Split2BLoader<G::B_P, G::B_PIECES>::desc(wz, a.n, a.K), a.a_scale);
-    conv_epilogue_any<G>(a, acc, m0, n0, b, g);
+    if (a.wide) {                                       // wave-uniform: bias (+ residual) (+ range slot) only, 16-byte rows
+        __syncthreads();                                // every wave is done with the operand stage: it becomes the patches
+        if (a.convt_u) conv_epilogue_wide32<G, false, true>(a, acc, lds, m0, n0, b, g);
+        else if (a.resid) conv_epilogue_wide32<G, true>(a, acc, lds, m0, n0, b, g);
+        else conv_epilogue_wide32<G, false>(a, acc, lds, m0, n0, b, g);
+    } else conv_epilogue_any<G>(a, acc, m0, n0, b, g);
 }
 
-// stride-1 multi-tap convolutions: one window of BM + HALO input rows per 32-channel slab, every tap reads it shifted
-// (gemm2_core.h, Gemm2Win)
 // Epilogue of the windowed kernels for what the generator's ResBlock convolutions have — bias, a residual operand or none, a
 // range slot or none — through wave-private LDS patches like conv_epilogue_wide (the operand stages are idle by now), on the
 // 32x32-tile accumulator layout: a band of 32 rows is written column-per-lane (one ds_write_b32 per element, scaled: a power
 // of two), taken back as four consecutive columns of one row per lane, and leaves as 16-byte stores with 16-byte residual
 // loads (requested before the band is written).  The column-per-lane form (conv_epilogue_lin) spends ~27 VALU and two 4-byte
 // memory instructions per element — a quarter of a k = 3 launch at C = 128.  Same arithmetic per element, same bits.
-template <class G, bool RES>
+// CONVT: a transposed convolution's output (column n = phase * cout + channel, row m -> output row m * u + phase - pad, rows cropped
+// to [0, t_out)): the four columns of a lane lie in one phase (cout % 4 == 0); the range slot only sees rows that are stored, as in
+// conv_epilogue.  The plain form leaves rows past M to the buffer range check, as conv_epilogue_lin does.
+template <class G, bool RES, bool CONVT = false>
 __device__ __forceinline__ void conv_epilogue_wide32(const ConvArgs& a, typename G::acc_t (&acc)[G::TM][G::TN], float* lds_generic,
                                                      int m0, int n0, int b, int g) {
     static_assert(G::NR == 16, "32x32-tile accumulator layout");
+    static_assert(!(RES && CONVT), "no residual on the transposed form");
     typedef __attribute__((address_space(3))) float lds_f;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
     constexpr int ETN = G::TN, ETM = G::TM;
@@ -800,14 +807,16 @@ __device__ __forceinline__ void conv_epilogue_wide32(const ConvArgs& a, typename
     float* oz = a.out + b * a.o_bstride + g * a.o_gstride;
     const float* rz = RES ? a.resid + b * a.r_bstride + g * a.r_gstride : nullptr;
     const float* bz = a.bias ? a.bias + g * a.bias_gstride : nullptr;
-    const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, ((a.m - 1) * a.ldo + a.n) * 4);
+    const __amdgpu_buffer_rsrc_t o_rsrc = uniform_rsrc(oz, CONVT ? ((a.t_out - 1) * a.ldo + a.convt_cout) * 4 : ((a.m - 1) * a.ldo + a.n) * 4);
     const __amdgpu_buffer_rsrc_t r_rsrc = uniform_rsrc(RES ? (const void*)rz : (const void*)oz, RES ? ((a.m - 1) * a.ldr + a.n) * 4 : 0);
     const int wrow0 = m0 + (wave / G::WN) * ETM * 32, wcol0 = n0 + (wave % G::WN) * ETN * 32;
     const int c = (lane & (ETN * 8 - 1)) * 4, n = wcol0 + c;
     const int row_in_trip = lane / (ETN * 8);
     const bool nv = n < a.n;
+    int phase = 0, col = n;
+    if (CONVT) { phase = n / a.convt_cout; col = n - phase * a.convt_cout; }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (bz && nv) bias4 = *(const f32x4*)(bz + n);
+    if (bz && nv) bias4 = *(const f32x4*)(bz + (a.bias_period ? n % a.bias_period : n));
     unsigned amax = 0;
 #pragma unroll
     for (int i = 0; i < ETM; ++i) {
@@ -828,16 +837,26 @@ __device__ __forceinline__ void conv_epilogue_wide32(const ConvArgs& a, typename
         for (int it = 0; it < TRIPS; ++it) {
             f32x4 v = *(const lds_f4*)(patch + (it * RSTEP + row_in_trip) * PITCH + c) + bias4;
             if (RES) v += rv[it];
-            if (a.out_absmax) {
+            const int m = mrow0 + it * RSTEP;
+            bool ok = nv;
+            int off;
+            if (CONVT) {
+                const int o = m * a.convt_u + phase - a.convt_pad;
+                ok = ok && m < a.m && o >= 0 && o < a.t_out;
+                off = (o * a.ldo + col) * 4;
+            } else off = (m * a.ldo + n) * 4;
+            if (a.out_absmax && (!CONVT || ok)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const unsigned ab = abs_bits(v[e]); amax = ab > amax ? ab : amax; }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, nv ? ((mrow0 + it * RSTEP) * a.ldo + n) * 4 : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, ok ? off : OOB, 0, 0);
         }
     }
     if (a.out_absmax) publish_absmax(a.out_absmax, amax);
 }
 
+// stride-1 multi-tap convolutions: one window of BM + HALO input rows per 32-channel slab, every tap reads it shifted
+// (gemm2_core.h, Gemm2Win)
 template <class G>
 __device__ __forceinline__ void conv_gemm2win_body(ConvArgs& a, float* lds) {
     resolve_scales(a);
@@ -1238,10 +1257,12 @@ static int conv_prep(const knnsvc_conv_desc* d, ConvArgs& a, bool& fast, bool& v
             (!d->resid || ((uintptr_t)d->resid & 15) == 0) && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 && d->r_bstride % 4 == 0 &&
             d->r_gstride % 4 == 0 && (!a.out_split || a.split_from % 128 == 0) && (!d->bias || d->bias_period || ((uintptr_t)d->bias & 15) == 0) &&
             d->bias_gstride % 4 == 0;
-        a.wide = knobs().win_wide && a.lin && !a.out_split && d->act == KNNSVC_ACT_NONE && !d->accumulate && a.div == 1.0f && d->n % 4 == 0 &&
-            d->ldo % 4 == 0 && ((uintptr_t)d->out & 15) == 0 && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 &&
+        const bool plain_t = d->convt_u && !d->resid && d->convt_cout % 4 == 0 && (long)d->t_out * d->ldo * 4 < (1L << 31) &&
+                             (long)d->m * d->convt_u < (1L << 30);
+        a.wide = knobs().win_wide && (a.lin || plain_t) && !a.out_split && d->act == KNNSVC_ACT_NONE && !d->accumulate && a.div == 1.0f &&
+            d->n % 4 == 0 && d->ldo % 4 == 0 && ((uintptr_t)d->out & 15) == 0 && d->o_bstride % 4 == 0 && d->o_gstride % 4 == 0 &&
             (!d->resid || (d->ldr % 4 == 0 && ((uintptr_t)d->resid & 15) == 0 && d->r_bstride % 4 == 0 && d->r_gstride % 4 == 0)) &&
-            (!d->bias || (!d->bias_period && ((uintptr_t)d->bias & 15) == 0 && d->bias_gstride % 4 == 0));
+            (!d->bias || (d->bias_period % 4 == 0 && ((uintptr_t)d->bias & 15) == 0 && d->bias_gstride % 4 == 0));
         KN_REQUIRE(d->fixed_tile != 2 || quad_ok, "conv_gemm: fixed_tile 2 needs the quad kernel's operand layout (split A, 16-byte rows, n % 4 == 0)");
     }
     return KNNSVC_OK;
