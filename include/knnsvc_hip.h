@@ -31,15 +31,18 @@ extern "C" {
 #define KNNSVC_EHIP      3   /* a HIP runtime call failed                  */
 #define KNNSVC_ENAN      4   /* NaN distance (the reference sys.exit()s)   */
 
-#define KNNSVC_ABI_VERSION 16
+#define KNNSVC_ABI_VERSION 17
 
 int knnsvc_abi_version(void);
 const char* knnsvc_last_error(void);
 /* Short tag of the kernel the calling thread's last knnsvc_conv_gemm dispatched to ("F128a2", "W64", "G128v8", ...):
  * measurement hook (bench.py attributes HIP-event times to kernels with it); "" before the first call. */
 const char* knnsvc_conv_gemm_last_kernel(void);
+/* ... and which epilogue that launch took: "patch" (LDS patches, 16-byte stores: conv_epilogue_wide32), "lane" (column per lane) or
+ * "" (kernels with an epilogue of their own: the 256x256-tile kernel, fp32, bf16x3).  Test hook. */
+const char* knnsvc_conv_gemm_last_epilogue(void);
 /* The dispatcher's A/B switches (KNNSVC_QUAD, KNNSVC_QUAD_EPI, KNNSVC_EPILOGUE, KNNSVC_WIN, KNNSVC_WIN_SMALL, KNNSVC_WIN_DEEP,
- * KNNSVC_WIN160, KNNSVC_GEMM_SMALL) are read from the environment once, at the first launch; this re-reads them (tests and A/B
+ * KNNSVC_WIN160, KNNSVC_WIN_WIDE, KNNSVC_GEMM_SMALL) are read from the environment once, at the first launch; this re-reads them (tests and A/B
  * runs that switch a route inside one process). */
 int knnsvc_reload_knobs(void);
 /* Stream-placement probe: `blocks` one-wave workgroups that spin for `spin` shader-clock ticks each (nothing is read or written).

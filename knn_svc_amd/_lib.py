@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KNNSVC_LIB") or os.path.join(_HERE, "libknnsvc_hip.so")      # KNNSVC_LIB: an A/B build (csrc/Makefile)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     "knnsvc_abi_version": (i32, []),
     "knnsvc_last_error": (C.c_char_p, []),
     "knnsvc_conv_gemm_last_kernel": (C.c_char_p, []),
+    "knnsvc_conv_gemm_last_epilogue": (C.c_char_p, []),
     "knnsvc_conv_gemm": (i32, [C.POINTER(ConvDesc), vp]),
     "knnsvc_conv_gemm_multi": (i32, [C.POINTER(ConvDesc), i32, vp]),
     "knnsvc_mean3": (i32, [vp, vp, vp, i64, f32, vp, vp, vp, i64, vp]),

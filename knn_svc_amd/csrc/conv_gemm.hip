@@ -7,6 +7,7 @@
 
 namespace {
 
+thread_local const char* g_last_epilogue = "";    // ... and the epilogue it took ("patch" / "lane" / ""): knnsvc_conv_gemm_last_epilogue
 thread_local const char* g_last_kernel = "";      // which kernel the last knnsvc_conv_gemm of this thread launched
 
 struct ConvArgs {
@@ -1303,6 +1304,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
     if (rc) return rc;
     if (d->m == 0) return KNNSVC_OK;
     hipStream_t st = (hipStream_t)stream;
+    g_last_epilogue = "";
     if (fast && a.w2) {        // fp32 emulated on the fp16 matrix cores (gemm2_core.h)
         if (d->fixed_tile != 1 && quad_ok) {
             // 256x256 block, 128x128 wave tiles, hand-pipelined loop (Gemm2QuadS: v_mfma_f32_16x16x32_f16, 32-k slabs): every A2
@@ -1324,6 +1326,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
                 return launch2quad<Q256S>(a, d->batches, st);
             }
         }
+        g_last_epilogue = a.wide ? "patch" : "lane";      // the windowed and tap-major f16x2 kernels below
         // stride-1 multi-tap convolutions on fp32 input: windowed kernel (A staged once per channel slab, not once per tap)
         switch (win_shape(d, a, (long)d->batches * d->groups)) {
             case WS_128D: g_last_kernel = "W128D"; return launch2win<W128D, 4>(a, d->batches, st);
@@ -1356,6 +1359,7 @@ extern "C" int knnsvc_conv_gemm(const knnsvc_conv_desc* d, void* stream) {
 }
 
 extern "C" const char* knnsvc_conv_gemm_last_kernel(void) { return g_last_kernel; }
+extern "C" const char* knnsvc_conv_gemm_last_epilogue(void) { return g_last_epilogue; }
 
 extern "C" int knnsvc_conv_gemm_multi(const knnsvc_conv_desc* descs, int32_t count, void* stream) {
     KN_REQUIRE(descs && count >= 1 && count <= KN_MAX_MULTI, "conv_gemm_multi: 1..4 descriptors");

@@ -153,6 +153,11 @@ def last_conv_kernel() -> str:
     return _lib.load().knnsvc_conv_gemm_last_kernel().decode()
 
 
+def last_conv_epilogue() -> str:
+    """"patch" / "lane" / "": the epilogue the last conv_gemm launch of this thread took (test hook)."""
+    return _lib.load().knnsvc_conv_gemm_last_epilogue().decode()
+
+
 def conv_gemm(x, w, out, *, m, n, cin, taps=1, stride=1, dil=1, pad=0, t_in=None, ldx=None, ldo=None,
               bias=None, bias_period=0, act=ACT_NONE, act_slope=0.0, a_slope=1.0, resid=None, ldr=None,
               accumulate=False, div=1.0, batches=1, groups=1, x_bstride=0, x_gstride=0, w_gstride=0,

@@ -280,6 +280,58 @@ def test_conv_transpose(cin, cout, k, u, T):
     assert _err(out, ref)[0] < 2e-5
 
 
+@pytest.mark.parametrize("case", ["win_k3_resid_slot", "win_k11_dil5_wide_buffer", "win_k7_n40_ragged", "tapmajor_stride2", "transposed_u8",
+                                  "transposed_u2_concat"])
+def test_patch_epilogue_equals_column_per_lane(case, monkeypatch):
+    """The LDS-patch epilogue with 16-byte stores (conv_epilogue_wide32: windowed and tap-major f16x2 kernels, plain and
+    transposed) writes the bits of the column-per-lane / generic epilogues it replaces — output AND range slot — on ragged row
+    counts, a residual, a wider (concat) output buffer, a bias period, column counts that are no multiple of 32."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(len(case))
+
+    def run():
+        slot = ops.new_slot(DEV)
+        if case.startswith("transposed"):
+            cin, cout, k, u, T = (256, 128, 16, 8, 333) if case == "transposed_u8" else (64, 32, 4, 2, 1001)
+            x = torch.randn(T, cin, generator=torch.Generator().manual_seed(3)).to(DEV)
+            w = torch.randn(cin, cout, k, generator=torch.Generator().manual_seed(4)) / (cin * 2) ** 0.5
+            b = torch.randn(cout, generator=torch.Generator().manual_seed(5)).to(DEV)
+            ld = 2 * cout if case.endswith("concat") else cout
+            out = torch.zeros(T * u, ld, device=DEV)
+            R = k // u
+            ops.conv_gemm(x, ops.attach_split(ops.pack_convT_weight(w, u).to(DEV)), out, m=T + R - 1, n=u * cout, cin=cin, taps=R, stride=1,
+                          dil=-1, pad=0, t_in=T, bias=b, bias_period=cout, a_slope=0.1, ldo=ld, convt_u=u, convt_cout=cout,
+                          convt_pad=(k - u) // 2, t_out=T * u, out_absmax=slot)
+            return out, slot, ops.last_conv_epilogue()
+        cin, cout, k, s_, d, T = {"win_k3_resid_slot": (128, 128, 3, 1, 1, 1217), "win_k11_dil5_wide_buffer": (64, 64, 11, 1, 5, 777),
+                                  "win_k7_n40_ragged": (32, 40, 7, 1, 3, 501), "tapmajor_stride2": (64, 96, 3, 2, 1, 999)}[case]
+        x = torch.randn(T, cin, generator=torch.Generator().manual_seed(6)).to(DEV)
+        w = torch.randn(cout, cin, k, generator=torch.Generator().manual_seed(7)) / (cin * k) ** 0.5
+        b = torch.randn(cout, generator=torch.Generator().manual_seed(8)).to(DEV)
+        pad = (k * d - d) // 2 if s_ == 1 else k // 2
+        To = (T + 2 * pad - d * (k - 1) - 1) // s_ + 1
+        ld = 2 * cout if "wide_buffer" in case else cout
+        out = torch.zeros(To, ld, device=DEV)
+        kw = {}
+        if "resid" in case:
+            kw = dict(resid=x, ldr=cin)
+        ops.conv_gemm(x, ops.attach_split(ops.pack_conv_weight(w).to(DEV)), out, m=To, n=cout, cin=cin, taps=k, stride=s_, dil=d, pad=pad,
+                      t_in=T, bias=b, a_slope=0.1, ldo=ld, out_absmax=slot, **kw)
+        return out, slot, ops.last_conv_epilogue()
+
+    _knob(monkeypatch, "KNNSVC_WIN_WIDE", "0")
+    ref, ref_slot, ref_epi = run()
+    _knob(monkeypatch, "KNNSVC_WIN_WIDE", "1")
+    got, got_slot, got_epi = run()
+    torch.cuda.synchronize()
+    assert (ref_epi, got_epi) == ("lane", "patch")            # both forms really ran
+    assert torch.equal(got, ref)
+    assert float(ref.abs().max()) > 0.1
+    if ref_slot is not None:
+        assert torch.equal(got_slot, ref_slot) and float(ref_slot.max()) > 0.0
+
+
+
 def test_grouped_pos_conv():
     ops = _ops()
     g = torch.Generator().manual_seed(9)
