@@ -30,6 +30,7 @@ struct ConvArgs {
     float a_scale;              // f16x2 path: power-of-two factor applied to activations before the split
     int lin;                    // plain output below 2 GiB: the buffer-addressed epilogue applies (conv_epilogue_lin)
     int wide;                   // ... and bias (+ residual) (+ range slot) is all there is, 16-byte rows: conv_epilogue_wide32 (windowed kernels)
+    int plain;                  // set by the launcher: one column tile and a row-tile count that is no multiple of 8 -> blockIdx.x IS the row tile
     // dynamic range of the f16x2 path (include/knnsvc_hip.h, "Range"): device slots holding an upper bound of |x| / |w|;
     // when set, the kernel derives the power-of-two operand scale from the slot (kn_pick_scale) instead of a_scale / w_scale
     const float* x_absmax; const float* w_absmax;
@@ -744,7 +745,10 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     resolve_scales(a);
     const int z = blockIdx.z;
-    const int b = z / a.groups, g = z - b * a.groups;
+    // group-major: the slices that run side by side on an XCD then share a group's weights through its L2 (batch-major, the 64 blocks
+    // resident on an XCD spanned all 16 groups of the positional conv — 32 MB of weights against 4 MB of L2)
+    const int nbz = (int)gridDim.z / a.groups;
+    const int g = z / nbz, b = z - g * nbz;
     // XCD-aware tile order (see conv_gemm2big_kernel): ids congruent mod 8 share an L2; a group is 8 row tiles x all
     // column tiles, so the column tiles of one row tile run on one XCD, next to each other in time
     // and the columns are walked in patches of CW tiles, so an XCD's ~96 resident blocks form a (12 x 8)-ish patch
@@ -758,7 +762,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm2_kernel(ConvArgs a) {
     if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
     else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
     const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
-    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
+    // (rem + z) & 7: which XCD gets which row tile of a group of 8 rotates with the batch / group index.  The padding rows are the
+    // same in every slice of a batched launch: unrotated, the positional conv's 6 row tiles per (chunk, group) — 336 slices — left
+    // XCDs 6 and 7 nothing but padding ids, a quarter of the chip idle for the whole launch (1.76 ms against 1.37 for the same work
+    // as one long sequence); gemm2_core.h's quad_order_decode rotates for the same reason.
+    // a.plain: a single column tile has no operand panel to share between column tiles, so padding the row tiles to groups of 8
+    // buys nothing and the padding ids still queue for LDS before they can exit (6 row tiles: a quarter of all ids)
+    const int m0 = a.plain ? (int)blockIdx.x * G::BM : (grp * 8 + ((rem + (int)blockIdx.z) & 7)) * G::BM, n0 = a.plain ? 0 : (c0 + (rem >> 3)) * G::BN;
     if (m0 >= a.m) return;                                    // padding of the last group
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;      // 64 halves = 128 B per (row, slab)
@@ -862,7 +872,10 @@ template <class G>
 __device__ __forceinline__ void conv_gemm2win_body(ConvArgs& a, float* lds) {
     resolve_scales(a);
     const int z = blockIdx.z;
-    const int b = z / a.groups, g = z - b * a.groups;
+    // group-major: the slices that run side by side on an XCD then share a group's weights through its L2 (batch-major, the 64 blocks
+    // resident on an XCD spanned all 16 groups of the positional conv — 32 MB of weights against 4 MB of L2)
+    const int nbz = (int)gridDim.z / a.groups;
+    const int g = z / nbz, b = z - g * nbz;
     const int gy = (a.n + G::BN - 1) / G::BN;                 // same XCD-aware column-patch order as conv_gemm2_kernel
     const int gx8 = (int)gridDim.x / gy;
     constexpr int CW = 8;
@@ -872,7 +885,13 @@ __device__ __forceinline__ void conv_gemm2win_body(ConvArgs& a, float* lds) {
     if (L < full) { c0 = (L / (CW * gx8)) * CW; cw = CW; L -= (c0 / CW) * CW * gx8; }
     else { c0 = (gy / CW) * CW; cw = gy - c0; L -= full; }
     const int grp = L / (8 * cw), rem = L - grp * 8 * cw;
-    const int m0 = (grp * 8 + (rem & 7)) * G::BM, n0 = (c0 + (rem >> 3)) * G::BN;
+    // (rem + z) & 7: which XCD gets which row tile of a group of 8 rotates with the batch / group index.  The padding rows are the
+    // same in every slice of a batched launch: unrotated, the positional conv's 6 row tiles per (chunk, group) — 336 slices — left
+    // XCDs 6 and 7 nothing but padding ids, a quarter of the chip idle for the whole launch (1.76 ms against 1.37 for the same work
+    // as one long sequence); gemm2_core.h's quad_order_decode rotates for the same reason.
+    // a.plain: a single column tile has no operand panel to share between column tiles, so padding the row tiles to groups of 8
+    // buys nothing and the padding ids still queue for LDS before they can exit (6 row tiles: a quarter of all ids)
+    const int m0 = a.plain ? (int)blockIdx.x * G::BM : (grp * 8 + ((rem + (int)blockIdx.z) & 7)) * G::BM, n0 = a.plain ? 0 : (c0 + (rem >> 3)) * G::BN;
     if (m0 >= a.m) return;
     const float* xz = a.x + b * a.x_bstride + g * a.x_gstride;
     const unsigned short* wz = a.w2 + (long)g * a.n * (a.K / 32) * 64;
@@ -930,9 +949,12 @@ int launch2win(const ConvArgs& a, int batches, hipStream_t st) {
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
-    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
-    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2win_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, a);
+    const long gx = cdiv64(a.m, G::BM), gy = cdiv64(a.n, G::BN);
+    ConvArgs ap = a;
+    ap.plain = gy == 1 && gx % 8 != 0;
+    const long gx8 = ap.plain ? gx : cdiv64(gx, 8) * 8;
+    dim3 grid((unsigned)(gx8 * gy), 1, (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2win_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, ap);
     return knnsvc_check_launch("conv_gemm2win");
 }
 
@@ -946,9 +968,13 @@ int launch2win_multi(const ConvArgsN& an, int count, hipStream_t st) {
         attr = true;
     }
     const ConvArgs& a = an.b[0];
-    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;
-    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), (unsigned)count, 1);
-    hipLaunchKernelGGL((conv_gemm2win_multi_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, an);
+    const long gx = cdiv64(a.m, G::BM), gy = cdiv64(a.n, G::BN);
+    ConvArgsN ap = an;
+    const int plain = gy == 1 && gx % 8 != 0;
+    for (int i = 0; i < KN_MAX_MULTI; ++i) ap.b[i].plain = plain;
+    const long gx8 = plain ? gx : cdiv64(gx, 8) * 8;
+    dim3 grid((unsigned)(gx8 * gy), (unsigned)count, 1);
+    hipLaunchKernelGGL((conv_gemm2win_multi_kernel<G, MINB>), grid, dim3(256), G::LDS_BYTES, st, ap);
     return knnsvc_check_launch("conv_gemm2win_multi");
 }
 
@@ -1040,9 +1066,12 @@ int launch2v(const ConvArgs& a, int batches, hipStream_t st) {
             return knnsvc_fail(KNNSVC_EHIP, "conv_gemm: hipFuncSetAttribute failed");
         attr = true;
     }
-    const long gx8 = cdiv64(cdiv64(a.m, G::BM), 8) * 8;          // row tiles padded to whole groups of 8 (one per XCD)
-    dim3 grid((unsigned)(gx8 * cdiv64(a.n, G::BN)), 1, (unsigned)(batches * a.groups));
-    hipLaunchKernelGGL((conv_gemm2_kernel<G, A2>), grid, dim3(256), G::LDS_BYTES, st, a);
+    const long gx = cdiv64(a.m, G::BM), gy = cdiv64(a.n, G::BN);
+    ConvArgs ap = a;
+    ap.plain = gy == 1 && gx % 8 != 0;
+    const long gx8 = ap.plain ? gx : cdiv64(gx, 8) * 8;          // row tiles padded to whole groups of 8 (one per XCD)
+    dim3 grid((unsigned)(gx8 * gy), 1, (unsigned)(batches * a.groups));
+    hipLaunchKernelGGL((conv_gemm2_kernel<G, A2>), grid, dim3(256), G::LDS_BYTES, st, ap);
     return knnsvc_check_launch("conv_gemm2");
 }
 template <class G>
@@ -1221,7 +1250,7 @@ static int conv_prep(const knnsvc_conv_desc* d, ConvArgs& a, bool& fast, bool& v
     a.split_scale = d->out_f16x2_scale > 0.f ? d->out_f16x2_scale : KN_F16X2_A_SCALE;
     a.x_split = d->x_f16x2; a.out_split = d->out_f16x2 != 0; a.split_from = d->out_f16x2 > 1 ? d->out_f16x2 : 0;
     KN_REQUIRE(d->out_f16x2 >= 0 && (d->out_f16x2 <= 1 || d->out_f16x2 % 32 == 0), "conv_gemm: out_f16x2 is 0, 1 or the first split column (a multiple of 32)");
-    a.wide = 0;
+    a.wide = 0; a.plain = 0;
     a.lin = !d->convt_u && (long)d->m * d->ldo * 4 < (1L << 31) && (!d->resid || (long)d->m * d->ldr * 4 < (1L << 31)) &&
             !knobs().generic_epilogue;      // KNNSVC_EPILOGUE=g: generic epilogue (A/B)
 
