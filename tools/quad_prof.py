@@ -33,3 +33,9 @@ for name, col in (("prologue", 0), ("main loop", 1), ("epilogue", 2)):
 order = np.argsort(t[:, 0])
 starts = t[order, 0] - t0
 print("  block start times (us), every 64th in start order:", np.round(starts[::64], 1).tolist())
+ids = np.nonzero(live)[0]
+ends = t[:, 3] - t0
+print("  last tile end per XCD (block id mod 8), us:", [round(float(ends[ids % 8 == x].max()), 1) for x in range(8)],
+      " tiles per XCD:", [int((ids % 8 == x).sum()) for x in range(8)])
+busy = (t[:, 3] - t[:, 0])
+print(f"  sum of tile times / (256 CUs x span) = {busy.sum() / (256 * (t[:, 3].max() - t0)):.3f}")
